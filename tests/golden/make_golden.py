@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the reference itself.  Runs ONLY in the
+build container (needs /root/reference); the GPU box and the test-suite only
+read the .npz files this writes.  Nothing from the reference is copied: the
+fixtures are numbers (inputs, weights-as-data, expected outputs, gradients).
+
+How the reference is driven
+---------------------------
+``models/gvp_layers.py`` and ``models/protein_gnn.py`` are imported unmodified
+from /root/reference.  Three modules they import are not installed here and are
+replaced by minimal stand-ins registered in ``sys.modules`` *before* the import:
+
+* ``torch_geometric.nn.MessagePassing``: base class of ``GVPConv``.  The stand-in
+  implements PyG's documented ``propagate`` contract for the default
+  ``flow='source_to_target'``: arguments named ``*_j`` are ``x[edge_index[0]]``,
+  ``*_i`` are ``x[edge_index[1]]``, other kwargs pass through, and messages are
+  reduced over ``edge_index[1]`` with ``aggr`` in {'add','sum','mean'}.  This is
+  third-party behaviour restated, not reference code: parity is UNPINNED at
+  exactly this boundary (see oracle/gvp_oracle.py docstring).
+* ``torch_scatter.scatter_add``: only used on the autoregressive branch, never hit.
+* ``ipdb``: debugger import, unused.
+
+All GVP / LayerNorm / GVPConv.message / GVPConvLayer / LBA-model arithmetic in the
+fixtures is therefore the reference's own code executing on CPU (fp32, plus an
+fp64 run for tolerance budgeting), with the pretrained BindingDB checkpoint
+loaded through ``torch.load(weights_only=True)``.
+"""
+import inspect
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(REPO, "caster-dta_amd"))
+import davis_synth as ds  # noqa: E402
+
+
+def install_standins():
+    class MessagePassing(torch.nn.Module):
+        def __init__(self, aggr="add", **kw):
+            super().__init__()
+            self.aggr = aggr
+
+        def propagate(self, edge_index, **kwargs):
+            names = list(inspect.signature(self.message).parameters)
+            args = {}
+            for nm in names:
+                if nm.endswith("_j"):
+                    args[nm] = kwargs[nm[:-2]].index_select(0, edge_index[0])
+                elif nm.endswith("_i"):
+                    args[nm] = kwargs[nm[:-2]].index_select(0, edge_index[1])
+                else:
+                    args[nm] = kwargs[nm]
+            msg = self.message(**args)
+            some = next(v for v in kwargs.values() if isinstance(v, torch.Tensor))
+            n = some.shape[0]
+            out = torch.zeros(n, msg.shape[1], dtype=msg.dtype).index_add_(0, edge_index[1], msg)
+            if self.aggr == "mean":
+                deg = torch.zeros(n, dtype=msg.dtype).index_add_(
+                    0, edge_index[1], torch.ones(edge_index.shape[1], dtype=msg.dtype))
+                out = out / deg.clamp(min=1).unsqueeze(-1)
+            elif self.aggr not in ("add", "sum"):
+                raise ValueError(self.aggr)
+            return out
+
+    pyg = types.ModuleType("torch_geometric")
+    pyg.nn = types.ModuleType("torch_geometric.nn")
+    pyg.utils = types.ModuleType("torch_geometric.utils")
+    pyg.nn.MessagePassing = MessagePassing
+    pyg.utils.degree = None
+    ts = types.ModuleType("torch_scatter")
+    ts.scatter_add = None
+    sys.modules.update({"torch_geometric": pyg, "torch_geometric.nn": pyg.nn,
+                        "torch_geometric.utils": pyg.utils, "torch_scatter": ts,
+                        "ipdb": types.ModuleType("ipdb")})
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def main():
+    install_standins()
+    sys.path.insert(0, REF)
+    import models.gvp_layers as gvp                      # reference, unmodified
+    from models.protein_gnn import SelectableProteinModelWrapper
+
+    ckpt = torch.load(os.path.join(REF, "pretrained_model_downstream",
+                                   "bestvalmodel_bindingdb_val0.6889_epoch01011.pt"),
+                      map_location="cpu", weights_only=True)
+    ckpt = {k.replace("_orig_mod.", ""): v for k, v in ckpt.items()}
+    kw = json.load(open(os.path.join(REF, "pretrained_model_downstream", "model_kwargs.json")))
+    pk = dict(kw["protein_gnn_kwargs"])
+    for k in ("in_channels", "edge_dim", "hidden_channels", "edge_hidden_channels"):
+        pk[k] = tuple(pk[k])
+
+    # ---- weights as data: encoder slices (+ the full state dict for the head) ----
+    np.savez_compressed(os.path.join(HERE, "pretrained_state.npz"), **{k: np_(v) for k, v in ckpt.items()})
+
+    model = SelectableProteinModelWrapper(**pk).eval()
+    psd = {k[len("protein_gnn."):]: v for k, v in ckpt.items() if k.startswith("protein_gnn.")}
+    print("load_state_dict:", model.load_state_dict(psd, strict=True))
+
+    # ---- (4)/(6)/(7): full LBA model on a ragged 3-graph batch (incl. kNN graph) ----
+    rng = np.random.default_rng(11)
+    graphs = [ds.protein_graph(24, rng, 4.0, "dist"), ds.protein_graph(37, rng, 10.0, "dist"),
+              ds.protein_graph(19, rng, 6, "num")]
+    gb = ds.collate(graphs)
+    d = ds.to_torch(gb)
+    xs, xv = d["x"]
+    es, ev = d["eattr"]
+    xs.requires_grad_(True); xv.requires_grad_(True); es.requires_grad_(True); ev.requires_grad_(True)
+
+    stages = {}
+    lba = model.gnn_model
+    hooks = [lba.gvp_node.register_forward_hook(lambda m, i, o: stages.__setitem__("node_embed", o)),
+             lba.gvp_edge.register_forward_hook(lambda m, i, o: stages.__setitem__("edge_embed", o))]
+    for l, conv in enumerate(lba.conv_list):
+        hooks.append(conv.register_forward_hook(lambda m, i, o, l=l: stages.__setitem__(f"conv{l}", o)))
+        hooks.append(conv.conv.register_forward_hook(lambda m, i, o, l=l: stages.__setitem__(f"conv{l}_dh", o)))
+    out = model((xs, xv), d["edge_index"], d["ntypes"], d["etypes"], eattr=(es, ev), batch=d["batch"])
+    for h in hooks:
+        h.remove()
+    r = torch.from_numpy(np.random.default_rng(5).normal(size=tuple(out.shape)).astype(np.float32))
+    (out * r).sum().backward()
+    grads = {"g_" + n.replace("gnn_model.", ""): np_(p.grad) for n, p in model.named_parameters() if p.numel()}
+    m64 = SelectableProteinModelWrapper(**pk).double().eval()
+    m64.load_state_dict({k: v.double() for k, v in psd.items()})
+    out64 = m64((xs.detach().double(), xv.detach().double()), d["edge_index"], d["ntypes"], d["etypes"],
+                eattr=(es.detach().double(), ev.detach().double()))
+    np.savez_compressed(
+        os.path.join(HERE, "lba_small.npz"),
+        x_s=gb.x_s, x_v=gb.x_v, edge_index=gb.edge_index, e_s=gb.e_s, e_v=gb.e_v, ntypes=gb.ntypes,
+        etypes=gb.etypes, batch=gb.batch, ptr=gb.ptr, out=np_(out), out64=np_(out64), r=np_(r),
+        gin_x_s=np_(xs.grad), gin_x_v=np_(xv.grad), gin_e_s=np_(es.grad), gin_e_v=np_(ev.grad),
+        **{f"stage_{k}_s": np_(v[0]) for k, v in stages.items()},
+        **{f"stage_{k}_v": np_(v[1]) for k, v in stages.items()}, **grads)
+    print("lba_small: N", gb.num_nodes, "E", gb.num_edges, "out", tuple(out.shape),
+          "fp32 vs fp64 max-abs/max", float((out.double() - out64).abs().max() / out64.abs().max()))
+
+    # ---- (1)/(2): standalone GVP / LayerNorm instances, every dim signature of the path ----
+    import torch.nn.functional as F
+    torch.manual_seed(1234)
+    units = {}
+    cases = [  # name, in, out, activations, gate
+        ("node_embed", (37, 3), (16, 4), (None, None), True),
+        ("edge_embed", (33, 1), (32, 1), (None, None), True),
+        ("msg0", (64, 9), (16, 4), (F.relu, None), True),
+        ("msg1", (16, 4), (16, 4), (F.relu, None), True),
+        ("msg2", (16, 4), (16, 4), (None, None), True),
+        ("ff0", (16, 4), (64, 8), (F.relu, None), True),
+        ("ff1", (64, 8), (16, 4), (None, None), True),
+        ("to_scalar", (16, 4), (64, 0), (F.relu, None), True),
+        ("nogate_sigmoid", (16, 4), (16, 4), (F.relu, torch.sigmoid), False),   # PocketMiner-style
+        ("gate_sigmoid", (16, 4), (16, 4), (F.relu, torch.sigmoid), True),
+        ("scalar_only_in", (12, 0), (8, 2), (F.relu, None), False),             # vi = 0 branch
+    ]
+    for name, din, dout, acts, gate in cases:
+        mod = gvp.GVP(din, dout, activations=acts, vector_gate=gate).eval()
+        n = 13
+        s = torch.randn(n, din[0])
+        if din[1]:
+            v = torch.randn(n, din[1], 3)
+            v[0] = 0.0                      # all-zero vectors: exercises the 1e-8 clamp
+            v[1, 0] = 0.0
+            o = mod((s, v))
+        else:
+            v = torch.zeros(n, 0, 3)
+            o = mod(s)
+        os_, ov = (o if isinstance(o, tuple) else (o, torch.zeros(n, 0, 3)))
+        units[f"gvp_{name}_in_s"] = np_(s); units[f"gvp_{name}_in_v"] = np_(v)
+        units[f"gvp_{name}_out_s"] = np_(os_); units[f"gvp_{name}_out_v"] = np_(ov)
+        for k, p in mod.state_dict().items():
+            units[f"gvp_{name}_w_{k}"] = np_(p)
+    for name, dims in [("node", (16, 4)), ("edge", (32, 1))]:
+        mod = gvp.LayerNorm(dims).eval()
+        with torch.no_grad():
+            mod.scalar_norm.weight.uniform_(0.5, 1.5); mod.scalar_norm.bias.normal_()
+        s, v = torch.randn(13, dims[0]), torch.randn(13, dims[1], 3)
+        v[0] = 0.0
+        o = mod((s, v))
+        units[f"ln_{name}_in_s"] = np_(s); units[f"ln_{name}_in_v"] = np_(v)
+        units[f"ln_{name}_out_s"] = np_(o[0]); units[f"ln_{name}_out_v"] = np_(o[1])
+        for k, p in mod.state_dict().items():
+            units[f"ln_{name}_w_{k}"] = np_(p)
+
+    # ---- (3)/(5): GVPConv (sum and mean) and GVPConvLayer with random weights ----
+    for aggr in ("sum", "mean"):
+        for gate, vact, tag in ((True, None, "gate"), (False, torch.sigmoid, "nogate")):
+            torch.manual_seed(77)
+            layer = gvp.GVPConvLayer((16, 4), (32, 1), drop_rate=0.2, activations=(F.relu, vact),
+                                     vector_gate=gate, aggr=aggr).eval()
+            g2 = ds.collate([ds.protein_graph(24, np.random.default_rng(3), 4.0),
+                             ds.protein_graph(31, np.random.default_rng(4), 8, "num")])
+            n, e = g2.num_nodes, g2.num_edges
+            tg = torch.Generator().manual_seed(9)
+            hs, hv = torch.randn(n, 16, generator=tg), torch.randn(n, 4, 3, generator=tg)
+            e_s, e_v = torch.randn(e, 32, generator=tg), torch.randn(e, 1, 3, generator=tg)
+            e_v[::5] = 0.0
+            ei = torch.from_numpy(g2.edge_index)
+            dh = layer.conv((hs, hv), ei, (e_s, e_v))
+            o = layer((hs, hv), ei, (e_s, e_v))
+            key = f"convlayer_{aggr}_{tag}"
+            units[key + "_edge_index"] = g2.edge_index
+            for nm, t in (("in_s", hs), ("in_v", hv), ("e_s", e_s), ("e_v", e_v), ("dh_s", dh[0]),
+                          ("dh_v", dh[1]), ("out_s", o[0]), ("out_v", o[1])):
+                units[f"{key}_{nm}"] = np_(t)
+            for k, p in layer.state_dict().items():
+                units[f"{key}_w_{k}"] = np_(p)
+    np.savez_compressed(os.path.join(HERE, "gvp_units.npz"), **units)
+    print("gvp_units:", len(units), "arrays")
+
+    # ---- invariances measured on the reference ----
+    q, _ = np.linalg.qr(np.random.default_rng(2).normal(size=(3, 3)))
+    R = torch.from_numpy(q)
+    xs64, xv64 = xs.detach().double(), xv.detach().double()
+    es64, ev64 = es.detach().double(), ev.detach().double()
+    rot = m64((xs64, xv64 @ R), d["edge_index"], d["ntypes"], d["etypes"], eattr=(es64, ev64 @ R))
+    perm = torch.from_numpy(np.random.default_rng(8).permutation(gb.num_edges))
+    prm = m64((xs64, xv64), d["edge_index"][:, perm], d["ntypes"], d["etypes"][perm],
+              eattr=(es64[perm], ev64[perm]))
+    print("fp64 rotation delta", float((rot - out64).abs().max()),
+          "edge-permutation delta", float((prm - out64).abs().max()))
+
+
+if __name__ == "__main__":
+    main()
