@@ -1,0 +1,510 @@
+// gvp_kernels.hip -- gfx950 kernels and the C ABI of libcaster_gvp.so
+// (declarations and reference citations: include/caster_gvp.h).
+//
+// Mapping (round 1): one residue / one edge per lane, 64-lane workgroups.
+//   * conv: a workgroup owns `npw` consecutive TARGET nodes (dst-sorted CSR), so
+//     the rows it reduces into are private: messages go lane -> LDS, a
+//     segmented reduction over the sorted targets runs in LDS, and the finished
+//     [npw][28] block is written with coalesced stores -- no atomics, no
+//     zero-fill, bitwise reproducible.  The raw edge features stream through
+//     the edge-embedding GVP + LayerNorm in registers (never materialised).
+//   * node kernels: row-per-lane, outputs transposed through LDS so global
+//     stores are contiguous.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/caster_gvp.h"
+#include "gvp_math.h"
+
+using namespace gvp;
+
+namespace {
+
+constexpr int WAVE = 64;
+
+inline int check_dims(const cgvp_dims* d) {
+  if (!d) return CGVP_ERR_BAD_ARG;
+  if (d->node_in_s != NODE_IN_S || d->node_in_v != NODE_IN_V || d->edge_in_s != EDGE_IN_S ||
+      d->edge_in_v != EDGE_IN_V || d->hidden_s != NS || d->hidden_v != NV ||
+      d->edge_hidden_s != ES || d->edge_hidden_v != EV || d->out_s != OUT)
+    return CGVP_ERR_UNSUPPORTED_DIMS;
+  return 0;
+}
+
+inline EncLayout cvt(const cgvp_layout& l) {
+  EncLayout L;
+  L.nt_node = l.nt_node; L.nt_edge = l.nt_edge; L.node_gvp = l.node_gvp; L.node_ln = l.node_ln;
+  L.edge_gvp = l.edge_gvp; L.edge_ln = l.edge_ln; L.conv0 = l.conv0; L.conv_stride = l.conv_stride;
+  L.ln_out = l.ln_out; L.head = l.head; L.total = l.total;
+  return L;
+}
+inline int num_convs_of(const cgvp_layout& l) { return l.conv_stride > 0 ? (l.ln_out - l.conv0) / l.conv_stride : 0; }
+
+inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+// ------------------------------------------------------------------ CSR build
+__global__ void csr_count_kernel(const int64_t* __restrict__ ei, int64_t N, int64_t E,
+                                 int32_t* __restrict__ cnt) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int64_t s = ei[e], d = ei[E + e];
+  if (s < 0 || s >= N || d < 0 || d >= N) return;   // malformed edge: dropped, never faults
+  atomicAdd(&cnt[d], 1);
+}
+
+// Exclusive scan of cnt[0..N) by ONE 1024-thread block; rowptr[N] = total;
+// cnt is rewritten with the scan so the fill kernel can use it as a cursor.
+__global__ __launch_bounds__(1024) void csr_scan_kernel(int32_t* __restrict__ cnt, int64_t N,
+                                                        int32_t* __restrict__ rowptr) {
+  __shared__ int32_t part[1024];
+  const int t = threadIdx.x;
+  const int64_t chunk = (N + 1023) / 1024;
+  const int64_t lo = t * chunk, hi = (lo + chunk < N) ? lo + chunk : N;
+  int32_t sum = 0;
+  for (int64_t i = lo; i < hi; ++i) sum += cnt[i];
+  part[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int32_t v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int32_t run = part[t] - sum;   // exclusive prefix of this thread's chunk
+  for (int64_t i = lo; i < hi; ++i) {
+    int32_t c = cnt[i];
+    rowptr[i] = run;
+    cnt[i] = run;
+    run += c;
+  }
+  if (t == 1023) rowptr[N] = part[1023];
+}
+
+__global__ void csr_fill_kernel(const int64_t* __restrict__ ei, int64_t N, int64_t E,
+                                int32_t* __restrict__ cursor, int32_t* __restrict__ eperm) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int64_t s = ei[e], d = ei[E + e];
+  if (s < 0 || s >= N || d < 0 || d >= N) return;
+  int32_t pos = atomicAdd(&cursor[d], 1);
+  eperm[pos] = (int32_t)e;
+}
+
+// Order every target's segment by original edge id (stable CSR => the fp32
+// summation order per node is the reference's index_add order) and emit the
+// sorted source / target tables.
+__global__ void csr_finish_kernel(const int64_t* __restrict__ ei, int64_t N, int64_t E,
+                                  const int32_t* __restrict__ rowptr, int32_t* __restrict__ eperm,
+                                  int32_t* __restrict__ esrc, int32_t* __restrict__ edst) {
+  int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int32_t lo = rowptr[n], hi = rowptr[n + 1];
+  for (int32_t i = lo + 1; i < hi; ++i) {
+    int32_t key = eperm[i];
+    int32_t j = i - 1;
+    while (j >= lo && eperm[j] > key) { eperm[j + 1] = eperm[j]; --j; }
+    eperm[j + 1] = key;
+  }
+  for (int32_t i = lo; i < hi; ++i) {
+    esrc[i] = (int32_t)ei[eperm[i]];
+    edst[i] = (int32_t)n;
+  }
+}
+
+// Launder the arena pointer through an empty asm so the optimiser cannot hoist
+// (loop-invariant) weight addresses / constant-space loads out of a loop body
+// and then spill them: weights are re-read from the scalar cache per iteration.
+__device__ __forceinline__ const float* opaque(const float* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+// ------------------------------------------------------------- row staging
+// Coalesced copy of `count` floats global -> LDS rows of ROWLEN with stride RS.
+template <int ROWLEN, int RS>
+__device__ __forceinline__ void stage_in(const float* __restrict__ g, int count, float* lds, int lane) {
+  for (int i = lane; i < count; i += WAVE) lds[(i / ROWLEN) * RS + (i % ROWLEN)] = g[i];
+}
+template <int ROWLEN, int RS>
+__device__ __forceinline__ void stage_out(float* __restrict__ g, int count, const float* lds, int lane) {
+  for (int i = lane; i < count; i += WAVE) g[i] = lds[(i / ROWLEN) * RS + (i % ROWLEN)];
+}
+
+__device__ __forceinline__ void load_row28(const float* __restrict__ base, int64_t row, float (&r)[ROW]) {
+  const float4* p = reinterpret_cast<const float4*>(base + row * ROW);
+#pragma unroll
+  for (int i = 0; i < ROW / 4; ++i) {
+    float4 q = p[i];
+    r[4 * i] = q.x; r[4 * i + 1] = q.y; r[4 * i + 2] = q.z; r[4 * i + 3] = q.w;
+  }
+}
+
+// ------------------------------------------------------------- node embed
+struct NodeEmbedArgs {
+  const float* params; EncLayout L; const float* x_s; const float* x_v; const int64_t* ntypes;
+  int64_t N; float* h;
+};
+
+template <int NTN>
+__global__ __launch_bounds__(WAVE) void node_embed_kernel(NodeEmbedArgs a) {
+  constexpr int RS_S = NODE_IN_S;              // 17: odd stride, conflict-free
+  constexpr int RS_V = 3 * NODE_IN_V;          // 9
+  constexpr int RS_O = ROW + 1;                // 29
+  __shared__ float lds[WAVE * RS_O];           // reused: inputs (17+9 per row) then outputs
+  const int lane = threadIdx.x;
+  const int64_t n0 = (int64_t)blockIdx.x * WAVE;
+  const int cnt = (int)((a.N - n0 < WAVE) ? (a.N - n0) : WAVE);
+  float* lds_s = lds;
+  float* lds_v = lds + WAVE * RS_S;
+  stage_in<NODE_IN_S, RS_S>(a.x_s + n0 * NODE_IN_S, cnt * NODE_IN_S, lds_s, lane);
+  stage_in<RS_V, RS_V>(a.x_v + n0 * RS_V, cnt * RS_V, lds_v, lane);
+  __syncthreads();
+  float row[ROW];
+  if (lane < cnt) {
+    float xs[NODE_IN_S], xv[NODE_IN_V][3];
+#pragma unroll
+    for (int k = 0; k < NODE_IN_S; ++k) xs[k] = lds_s[lane * RS_S + k];
+#pragma unroll
+    for (int i = 0; i < NODE_IN_V; ++i)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) xv[i][d] = lds_v[lane * RS_V + 3 * i + d];
+    int type = 0;
+    if (NTN > 0) {
+      type = (int)a.ntypes[n0 + lane];
+      type = type < 0 ? 0 : (type >= NTN ? NTN - 1 : type);
+    }
+    node_embed_item<NTN>(a.params, a.L, type, xs, xv, row);
+  }
+  __syncthreads();
+  if (lane < cnt) {
+#pragma unroll
+    for (int k = 0; k < ROW; ++k) lds[lane * RS_O + k] = row[k];
+  }
+  __syncthreads();
+  stage_out<ROW, RS_O>(a.h + n0 * ROW, cnt * ROW, lds, lane);
+}
+
+// ------------------------------------------------------------- conv
+struct ConvArgs {
+  const float* params; EncLayout L; int layer;
+  const float* h; const float* e_s; const float* e_v; const int64_t* etypes;
+  const int32_t* rowptr; const int32_t* eperm; const int32_t* esrc; const int32_t* edst;
+  int64_t N; int npw; int mean; float* dh;
+};
+
+template <int NTE>
+__global__ __launch_bounds__(WAVE) void conv_fwd_kernel(ConvArgs a) {
+  constexpr int RS = ROW + 1;                  // 29
+  __shared__ float msg[WAVE * RS];
+  __shared__ float acc[WAVE * ROW];
+  __shared__ int dloc[WAVE];
+  const int lane = threadIdx.x;
+  const int64_t n0 = (int64_t)blockIdx.x * a.npw;
+  const int nn = (int)((a.N - n0 < a.npw) ? (a.N - n0) : a.npw);
+  const int32_t e0 = a.rowptr[n0], e1 = a.rowptr[n0 + nn];
+  for (int i = lane; i < nn * ROW; i += WAVE) acc[i] = 0.f;
+
+  for (int32_t base = e0; base < e1; base += WAVE) {
+    const int32_t p = base + lane;
+    const bool active = p < e1;
+    float m[ROW];
+    int dl = -1;
+    if (active) {
+      const int32_t eid = a.eperm[p];
+      const int32_t src = a.esrc[p];
+      const int32_t dst = a.edst[p];
+      dl = dst - (int)n0;
+      float es_raw[EDGE_IN_S], ev_raw[EDGE_IN_V][3], xj[ROW], xi[ROW];
+      const float4* pe = reinterpret_cast<const float4*>(a.e_s + (int64_t)eid * EDGE_IN_S);
+#pragma unroll
+      for (int i = 0; i < EDGE_IN_S / 4; ++i) {
+        float4 q = pe[i];
+        es_raw[4 * i] = q.x; es_raw[4 * i + 1] = q.y; es_raw[4 * i + 2] = q.z; es_raw[4 * i + 3] = q.w;
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) ev_raw[0][d] = a.e_v[(int64_t)eid * 3 + d];
+      int et = 0;
+      if (NTE > 0) {
+        et = (int)a.etypes[eid];
+        et = et < 0 ? 0 : (et >= NTE ? NTE - 1 : et);
+      }
+      load_row28(a.h, src, xj);
+      load_row28(a.h, dst, xi);
+      conv_message_item<NTE>(opaque(a.params), a.L, a.layer, et, es_raw, ev_raw, xj, xi, m);
+    }
+    __syncthreads();                           // previous chunk's reduction has drained msg[]
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < ROW; ++k) msg[lane * RS + k] = m[k];
+    }
+    dloc[lane] = dl;
+    __syncthreads();
+    // Segmented reduction over the (sorted) targets of this chunk.  Lanes 0..27
+    // walk rows 0..31, lanes 32..59 walk rows 32..63, one channel each.  Only the
+    // second half's FIRST segment can share a node with the first half, so it is
+    // held back and added after a barrier; every other flush is exclusive.
+    const int cntc = (e1 - base < WAVE) ? (e1 - base) : WAVE;
+    const int half = lane >> 5, c = lane & 31;
+    const int r0 = half * 32, r1 = (cntc < r0 + 32) ? cntc : r0 + 32;
+    float first_run = 0.f;
+    int first_cur = -1;
+    if (c < ROW && r0 < r1) {
+      int cur = dloc[r0];
+      float run = 0.f;
+      bool first = true;
+      for (int r = r0; r < r1; ++r) {
+        const int d = dloc[r];
+        if (d != cur) {
+          if (first && half == 1) { first_run = run; first_cur = cur; }
+          else acc[cur * ROW + c] += run;
+          first = false;
+          run = 0.f;
+          cur = d;
+        }
+        run += msg[r * RS + c];
+      }
+      if (first && half == 1) { first_run = run; first_cur = cur; }
+      else acc[cur * ROW + c] += run;
+    }
+    __syncthreads();
+    if (first_cur >= 0) acc[first_cur * ROW + c] += first_run;
+  }
+  __syncthreads();
+  float* out = a.dh + n0 * ROW;
+  for (int i = lane; i < nn * ROW; i += WAVE) {
+    float v = acc[i];
+    if (a.mean) {
+      const int nd = i / ROW;
+      const int deg = a.rowptr[n0 + nd + 1] - a.rowptr[n0 + nd];
+      v = v / (float)(deg > 1 ? deg : 1);
+    }
+    out[i] = v;
+  }
+}
+
+// ------------------------------------------------------------- node update
+struct NodeUpdateArgs {
+  const float* params; EncLayout L; int layer;
+  const float* h; const float* dh; int64_t N; float* h_out; float* out;
+};
+
+template <bool HEAD>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void node_update_kernel(NodeUpdateArgs a) {
+  constexpr int RS = HEAD ? (OUT + 1) : (ROW + 1);
+  __shared__ float lds[WAVE * RS];
+  const int lane = threadIdx.x;
+  const int64_t n0 = (int64_t)blockIdx.x * WAVE;
+  const int cnt = (int)((a.N - n0 < WAVE) ? (a.N - n0) : WAVE);
+  if (lane < cnt) {
+    float x[ROW], dh[ROW], row[ROW], out[OUT];
+    load_row28(a.h, n0 + lane, x);
+    load_row28(a.dh, n0 + lane, dh);
+    node_update_item<HEAD>(a.params, a.L, a.layer, x, dh, row, out);
+    if (HEAD) {
+#pragma unroll
+      for (int k = 0; k < OUT; ++k) lds[lane * RS + k] = out[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < ROW; ++k) lds[lane * RS + k] = row[k];
+    }
+  }
+  __syncthreads();
+  if (HEAD) stage_out<OUT, RS>(a.out + n0 * OUT, cnt * OUT, lds, lane);
+  else stage_out<ROW, RS>(a.h_out + n0 * ROW, cnt * ROW, lds, lane);
+}
+
+// ------------------------------------------------------------- GINE
+struct GineArgs {
+  const float* x; const int64_t* ntypes; int nt; const float* eattr; const int64_t* etypes;
+  int net; int ed; const int32_t* rowptr; const int32_t* eperm; const int32_t* esrc;
+  int64_t N; int cin; int chid; int cout;
+  const float* eps; const float* we; const float* be; const float* w0; const float* b0;
+  const float* w1; const float* b1; float slope; float* out;
+};
+
+constexpr int GINE_APB = 4;   // atoms (waves) per block
+constexpr int GINE_MAXKE = 16;
+
+// One wave per target atom, one lane per channel.
+__global__ __launch_bounds__(WAVE * GINE_APB) void gine_conv_kernel(GineArgs a) {
+  __shared__ float hbuf[GINE_APB][WAVE];
+  __shared__ float tbuf[GINE_APB][WAVE];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int w = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * GINE_APB + w;
+  const bool valid = i < a.N;
+  const int ke = a.net + a.ed;
+  const int xw = a.cin - a.nt;                  // raw feature width
+  float hval = 0.f;
+  if (valid && lane < a.cin) {
+    float wa[GINE_MAXKE];                        // this channel's W_e columns for the bond features
+#pragma unroll
+    for (int k = 0; k < GINE_MAXKE; ++k) wa[k] = (k < a.ed) ? a.we[lane * ke + a.net + k] : 0.f;
+    const float bias = a.be[lane];
+    auto xcat = [&](int64_t n) -> float {
+      if (lane < a.nt) return ((int)a.ntypes[n] == lane) ? 1.f : 0.f;
+      return a.x[n * xw + (lane - a.nt)];
+    };
+    float agg = 0.f;
+    const int32_t p0 = a.rowptr[i], p1 = a.rowptr[i + 1];
+    for (int32_t p = p0; p < p1; ++p) {
+      const int32_t eid = a.eperm[p];
+      const int32_t j = a.esrc[p];
+      float e = bias;
+      if (a.net > 0) {                            // one-hot bond type = column lookup
+        int et = (int)a.etypes[eid];
+        et = et < 0 ? 0 : (et >= a.net ? a.net - 1 : et);
+        e += a.we[lane * ke + et];
+      }
+      const float* ea = a.eattr + (int64_t)eid * a.ed;
+#pragma unroll
+      for (int k = 0; k < GINE_MAXKE; ++k)
+        if (k < a.ed) e = fmaf(wa[k], ea[k], e);
+      const float mj = xcat(j) + e;
+      agg += mj > 0.f ? mj : 0.f;
+    }
+    hval = fmaf(1.0f + a.eps[0], xcat(i), agg);
+  }
+  hbuf[w][lane] = hval;
+  __syncthreads();
+  float t = 0.f;
+  if (valid && lane < a.chid) {
+    t = a.b0[lane];
+    const float* wr = a.w0 + lane * a.cin;
+    for (int k = 0; k < a.cin; ++k) t = fmaf(wr[k], hbuf[w][k], t);
+    t = t > 0.f ? t : t * a.slope;
+  }
+  tbuf[w][lane] = t;
+  __syncthreads();
+  if (valid && lane < a.cout) {
+    float y = a.b1[lane];
+    const float* wr = a.w1 + lane * a.chid;
+    for (int k = 0; k < a.chid; ++k) y = fmaf(wr[k], tbuf[w][k], y);
+    y = y > 0.f ? y : y * a.slope;
+    a.out[i * a.cout + lane] = y;
+  }
+}
+
+}  // namespace
+
+// ===================================================================== C ABI
+extern "C" {
+
+int cgvp_abi_version(void) { return CGVP_ABI_VERSION; }
+const char* cgvp_build_info(void) { return "libcaster_gvp gfx950 (HIP, wave64), built " __DATE__ " " __TIME__; }
+
+int cgvp_csr_from_coo(const int64_t* edge_index, int64_t N, int64_t E, int32_t* rowptr,
+                      int32_t* eperm, int32_t* esrc, int32_t* edst, int32_t* work, void* stream) {
+  if (N < 0 || E < 0 || !rowptr || !work || (E > 0 && (!edge_index || !eperm || !esrc || !edst)))
+    return CGVP_ERR_BAD_ARG;
+  if (N >= (int64_t)1 << 31 || E >= (int64_t)1 << 31) return CGVP_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t err = hipMemsetAsync(work, 0, (size_t)(N + 1) * sizeof(int32_t), s);
+  if (err != hipSuccess) return (int)err;
+  const int B = 256;
+  if (E > 0) hipLaunchKernelGGL(csr_count_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, work);
+  hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, s, work, N, rowptr);
+  if (E > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, work, eperm);
+  if (N > 0 && E > 0) hipLaunchKernelGGL(csr_finish_kernel, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, rowptr, eperm, esrc, edst);
+  return launch_status();
+}
+
+int cgvp_lba_layout(const cgvp_dims* dims, int32_t num_ntypes, int32_t num_etypes, int32_t num_convs,
+                    cgvp_layout* out) {
+  if (int rc = check_dims(dims)) return rc;
+  if (!out || num_ntypes < 0 || num_etypes < 0 || num_convs < 0) return CGVP_ERR_BAD_ARG;
+  const EncLayout L = make_layout(num_ntypes, num_etypes, num_convs);
+  out->nt_node = L.nt_node; out->nt_edge = L.nt_edge; out->node_gvp = L.node_gvp; out->node_ln = L.node_ln;
+  out->edge_gvp = L.edge_gvp; out->edge_ln = L.edge_ln; out->conv0 = L.conv0;
+  out->conv_stride = L.conv_stride; out->ln_out = L.ln_out; out->head = L.head; out->total = L.total;
+  return 0;
+}
+
+int cgvp_node_embed_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* params,
+                        const float* x_s, const float* x_v, const int64_t* ntypes, int64_t N,
+                        float* h, void* stream) {
+  if (int rc = check_dims(dims)) return rc;
+  if (N < 0 || !layout || !params || (layout->nt_node > 0 && N > 0 && !ntypes)) return CGVP_ERR_BAD_ARG;
+  if (N == 0) return 0;
+  if (!x_s || !x_v || !h) return CGVP_ERR_BAD_ARG;
+  NodeEmbedArgs a{params, cvt(*layout), x_s, x_v, ntypes, N, h};
+  const dim3 grid((unsigned)((N + WAVE - 1) / WAVE));
+  hipStream_t st = (hipStream_t)stream;
+  switch (layout->nt_node) {   // one-hot width is a compile-time constant of the kernel
+    case 0: hipLaunchKernelGGL(node_embed_kernel<0>, grid, dim3(WAVE), 0, st, a); break;
+    case 20: hipLaunchKernelGGL(node_embed_kernel<20>, grid, dim3(WAVE), 0, st, a); break;
+    case 21: hipLaunchKernelGGL(node_embed_kernel<21>, grid, dim3(WAVE), 0, st, a); break;
+    default: return CGVP_ERR_UNSUPPORTED_DIMS;
+  }
+  return launch_status();
+}
+
+int cgvp_conv_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* params, int32_t layer,
+                  const float* h, const float* e_s, const float* e_v, const int64_t* etypes,
+                  const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
+                  const int32_t* edst, int64_t N, int64_t E, int32_t aggr_mean, float* dh,
+                  void* stream) {
+  if (int rc = check_dims(dims)) return rc;
+  if (N < 0 || E < 0 || !layout || !params) return CGVP_ERR_BAD_ARG;
+  if (layer < 0 || layer >= num_convs_of(*layout)) return CGVP_ERR_BAD_ARG;
+  if (N == 0) return 0;
+  if (!h || !dh || !rowptr) return CGVP_ERR_BAD_ARG;
+  if (E > 0 && (!e_s || !e_v || !eperm || !esrc || !edst || (layout->nt_edge > 0 && !etypes))) return CGVP_ERR_BAD_ARG;
+  if (((uintptr_t)h & 15) || ((uintptr_t)e_s & 15)) return CGVP_ERR_BAD_ARG;   // float4 row loads
+  // target nodes per workgroup: aim at ~48 of the 64 edge lanes per chunk
+  int64_t deg = (E + N - 1) / N;
+  if (deg < 1) deg = 1;
+  int npw = (int)(48 / deg);
+  npw = npw < 1 ? 1 : (npw > WAVE ? WAVE : npw);
+  ConvArgs a{params, cvt(*layout), layer, h, e_s, e_v, etypes, rowptr, eperm, esrc, edst, N, npw,
+             aggr_mean ? 1 : 0, dh};
+  const dim3 grid((unsigned)((N + npw - 1) / npw));
+  hipStream_t st = (hipStream_t)stream;
+  switch (layout->nt_edge) {
+    case 0: hipLaunchKernelGGL(conv_fwd_kernel<0>, grid, dim3(WAVE), 0, st, a); break;
+    case 1: hipLaunchKernelGGL(conv_fwd_kernel<1>, grid, dim3(WAVE), 0, st, a); break;
+    default: return CGVP_ERR_UNSUPPORTED_DIMS;
+  }
+  return launch_status();
+}
+
+int cgvp_node_update_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* params,
+                         int32_t layer, const float* h, const float* dh, int64_t N, int32_t with_head,
+                         float* h_out, float* out, void* stream) {
+  if (int rc = check_dims(dims)) return rc;
+  if (N < 0 || !layout || !params) return CGVP_ERR_BAD_ARG;
+  if (layer < 0 || layer >= num_convs_of(*layout)) return CGVP_ERR_BAD_ARG;
+  if (N == 0) return 0;
+  if (!h || !dh || (with_head ? !out : !h_out)) return CGVP_ERR_BAD_ARG;
+  if (((uintptr_t)h & 15) || ((uintptr_t)dh & 15)) return CGVP_ERR_BAD_ARG;
+  NodeUpdateArgs a{params, cvt(*layout), layer, h, dh, N, h_out, out};
+  dim3 grid((unsigned)((N + WAVE - 1) / WAVE));
+  if (with_head) hipLaunchKernelGGL(node_update_kernel<true>, grid, dim3(WAVE), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(node_update_kernel<false>, grid, dim3(WAVE), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+int cgvp_gine_conv_fwd(const float* x, const int64_t* ntypes, int32_t num_ntypes, const float* eattr,
+                       const int64_t* etypes, int32_t num_etypes, int32_t edge_dim,
+                       const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc, int64_t N,
+                       int64_t E, int32_t cin, int32_t chid, int32_t cout, const cgvp_gine_w* w,
+                       float act_slope, float* out, void* stream) {
+  if (N < 0 || E < 0 || !w) return CGVP_ERR_BAD_ARG;
+  if (num_ntypes < 0 || num_etypes < 0 || edge_dim < 0 || cin <= num_ntypes) return CGVP_ERR_BAD_ARG;
+  if (cin > WAVE || chid > WAVE || cout > WAVE || chid < 1 || cout < 1 || num_etypes + edge_dim > GINE_MAXKE)
+    return CGVP_ERR_UNSUPPORTED_DIMS;
+  if (N == 0) return 0;
+  if (!x || !out || !rowptr || (num_ntypes > 0 && !ntypes)) return CGVP_ERR_BAD_ARG;
+  if (E > 0 && (!eperm || !esrc || (edge_dim > 0 && !eattr) || (num_etypes > 0 && !etypes))) return CGVP_ERR_BAD_ARG;
+  GineArgs a{x, ntypes, num_ntypes, eattr, etypes, num_etypes, edge_dim, rowptr, eperm, esrc, N, cin,
+             chid, cout, w->eps, w->we, w->be, w->w0, w->b0, w->w1, w->b1, act_slope, out};
+  hipLaunchKernelGGL(gine_conv_kernel, dim3((unsigned)((N + GINE_APB - 1) / GINE_APB)),
+                     dim3(WAVE * GINE_APB), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+}  // extern "C"

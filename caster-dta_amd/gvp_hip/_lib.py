@@ -1,0 +1,98 @@
+"""ctypes binding of libcaster_gvp.so (C ABI: include/caster_gvp.h).
+
+The library is the product: there is no Python / CPU fallback.  Importing this
+module never fails (so CPU-only tooling can introspect the package), but the
+first call that needs a kernel raises `HipLibraryError` when the shared object
+is missing or stale.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the HIP runtime we bind to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcaster_gvp.so")
+ABI_VERSION = 1
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "node_in_s", "node_in_v", "edge_in_s", "edge_in_v", "hidden_s", "hidden_v",
+        "edge_hidden_s", "edge_hidden_v", "out_s")]
+
+
+class Layout(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "nt_node", "nt_edge", "node_gvp", "node_ln", "edge_gvp", "edge_ln", "conv0",
+        "conv_stride", "ln_out", "head", "total")]
+
+
+class GineW(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("eps", "we", "be", "w0", "b0", "w1", "b1")]
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_I32 = C.c_int32
+
+_SIGNATURES = {
+    "cgvp_abi_version": (C.c_int, []),
+    "cgvp_build_info": (C.c_char_p, []),
+    "cgvp_csr_from_coo": (C.c_int, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P]),
+    "cgvp_lba_layout": (C.c_int, [C.POINTER(Dims), _I32, _I32, _I32, C.POINTER(Layout)]),
+    "cgvp_node_embed_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _P, _P, _I64, _P, _P]),
+    "cgvp_conv_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _P, _P, _P, _P, _P,
+                                _P, _I64, _I64, _I32, _P, _P]),
+    "cgvp_node_update_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _I64, _I32,
+                                       _P, _P, _P]),
+    "cgvp_gine_conv_fwd": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _I64, _I64, _I32, _I32,
+                                     _I32, C.POINTER(GineW), C.c_float, _P, _P]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names include/caster_gvp.h declares (the CPU test-suite checks the .so exports all)."""
+    return tuple(_SIGNATURES)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  caster-dta_amd has no CPU or PyTorch fallback.")
+        try:
+            handle = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in _SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise HipLibraryError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
+            fn.restype, fn.argtypes = res, args
+        if handle.cgvp_abi_version() != ABI_VERSION:
+            raise HipLibraryError(f"{LIB_PATH} has ABI {handle.cgvp_abi_version()}, binding expects {ABI_VERSION}")
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc == -2:
+        raise NotImplementedError(
+            f"{what}: dimensions outside the compiled CASTER-DTA(s,v) configuration "
+            "(node (17,3)/hidden (16,4)/edge (32,1)/out 64, one-hot widths {0,20,21}/{0,1})")
+    if rc < 0:
+        raise ValueError(f"{what}: bad argument (code {rc})")
+    raise RuntimeError(f"{what}: HIP launch failed with hipError_t {rc}")

@@ -1,0 +1,165 @@
+"""Host-side launch plumbing for the HIP kernels: tensor checks, workspace
+allocation (through PyTorch's caching allocator) and calls into the C ABI on
+PyTorch's current HIP stream.  No arithmetic happens here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from ._lib import Dims, GineW, Layout
+
+CASTER_DIMS = dict(node_in_s=17, node_in_v=3, edge_in_s=32, edge_in_v=1, hidden_s=16, hidden_v=4,
+                   edge_hidden_s=32, edge_hidden_v=1, out_s=64)
+ROW = 28  # merged node row: 16 scalars + 4x3 vector channels
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else C.c_void_p(0)
+
+
+def _f32(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: caster-dta_amd runs on MI355X only (got a {t.device} tensor); "
+                           "there is no CPU path")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+def _i64(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: caster-dta_amd runs on MI355X only (got a {t.device} tensor)")
+    if t.dtype != torch.int64:
+        t = t.long()
+    return t.contiguous()
+
+
+def make_dims(**kw):
+    d = dict(CASTER_DIMS)
+    d.update(kw)
+    return Dims(**d)
+
+
+def lba_layout(dims, num_ntypes, num_etypes, num_convs):
+    out = Layout()
+    _lib.check(_lib.lib().cgvp_lba_layout(C.byref(dims), num_ntypes, num_etypes, num_convs, C.byref(out)),
+               "cgvp_lba_layout")
+    return out
+
+
+@dataclass
+class Csr:
+    """Destination-sorted CSR of a batched graph (int32 tables on the GPU)."""
+    rowptr: torch.Tensor
+    eperm: torch.Tensor
+    esrc: torch.Tensor
+    edst: torch.Tensor
+    num_nodes: int
+    num_edges: int
+
+
+def build_csr(edge_index, num_nodes):
+    ei = _i64(edge_index, "edge_index")
+    if ei.dim() != 2 or ei.shape[0] != 2:
+        raise ValueError(f"edge_index must be [2, E], got {tuple(ei.shape)}")
+    E = int(ei.shape[1])
+    dev = ei.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    rowptr = torch.empty(num_nodes + 1, **i32)
+    work = torch.empty(num_nodes + 1, **i32)
+    eperm = torch.empty(max(E, 1), **i32)
+    esrc = torch.empty(max(E, 1), **i32)
+    edst = torch.empty(max(E, 1), **i32)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().cgvp_csr_from_coo(_ptr(ei), num_nodes, E, _ptr(rowptr), _ptr(eperm), _ptr(esrc),
+                                          _ptr(edst), _ptr(work), _stream())
+    _lib.check(rc, "cgvp_csr_from_coo")
+    return Csr(rowptr, eperm, esrc, edst, num_nodes, E)
+
+
+def lba_encoder_forward(params, layout, dims, num_convs, x_s, x_v, ntypes, e_s, e_v, etypes, csr,
+                        aggr_mean=False, return_stages=False):
+    """VectorProteinGNN_LBAModel.forward (protein_gnn.py:361-388), eval mode,
+    as 1 + 2*num_convs launches: node embed, then (conv, node update) per layer
+    with the output head fused into the last node update."""
+    L = _lib.lib()
+    x_s, x_v = _f32(x_s, "x_s"), _f32(x_v, "x_v")
+    e_s, e_v = _f32(e_s, "eattr_s"), _f32(e_v, "eattr_v")
+    N, E = int(x_s.shape[0]), int(e_s.shape[0])
+    if tuple(x_s.shape) != (N, dims.node_in_s) or tuple(x_v.shape) != (N, dims.node_in_v, 3):
+        raise NotImplementedError(f"node features {tuple(x_s.shape)}/{tuple(x_v.shape)} do not match the "
+                                  "compiled CASTER-DTA configuration")
+    if tuple(e_s.shape) != (E, dims.edge_in_s) or tuple(e_v.shape) != (E, dims.edge_in_v, 3):
+        raise NotImplementedError(f"edge features {tuple(e_s.shape)}/{tuple(e_v.shape)} do not match the "
+                                  "compiled CASTER-DTA configuration")
+    if csr.num_nodes != N or csr.num_edges != E:
+        raise ValueError("CSR tables were built for a different graph")
+    if num_convs < 1:
+        raise NotImplementedError("num_convs must be >= 1 (the output head is fused into the last layer)")
+    nt = _i64(ntypes, "ntypes") if layout.nt_node > 0 else None
+    et = _i64(etypes, "etypes") if layout.nt_edge > 0 else None
+    dev = x_s.device
+    h = torch.empty(N, ROW, dtype=torch.float32, device=dev)
+    h2 = torch.empty(N, ROW, dtype=torch.float32, device=dev)
+    dh = torch.empty(N, ROW, dtype=torch.float32, device=dev)
+    out = torch.empty(N, dims.out_s, dtype=torch.float32, device=dev)
+    stages = {}
+    with torch.cuda.device(dev):
+        st = _stream()
+        d, lay, P = C.byref(dims), C.byref(layout), _ptr(params)
+        _lib.check(L.cgvp_node_embed_fwd(d, lay, P, _ptr(x_s), _ptr(x_v), _ptr(nt), N, _ptr(h), st),
+                   "cgvp_node_embed_fwd")
+        if return_stages:
+            stages["node_embed"] = h.clone()
+        for layer in range(num_convs):
+            _lib.check(L.cgvp_conv_fwd(d, lay, P, layer, _ptr(h), _ptr(e_s), _ptr(e_v), _ptr(et),
+                                       _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst),
+                                       N, E, 1 if aggr_mean else 0, _ptr(dh), st), "cgvp_conv_fwd")
+            if return_stages:
+                stages[f"conv{layer}_dh"] = dh.clone()
+            last = layer == num_convs - 1
+            if return_stages and last:      # materialise the last hidden state as well
+                _lib.check(L.cgvp_node_update_fwd(d, lay, P, layer, _ptr(h), _ptr(dh), N, 0, _ptr(h2),
+                                                  C.c_void_p(0), st), "cgvp_node_update_fwd")
+                stages[f"conv{layer}"] = h2.clone()
+            _lib.check(L.cgvp_node_update_fwd(d, lay, P, layer, _ptr(h), _ptr(dh), N, 1 if last else 0,
+                                              _ptr(h2), _ptr(out), st), "cgvp_node_update_fwd")
+            if not last:
+                if return_stages:
+                    stages[f"conv{layer}"] = h2.clone()
+                h, h2 = h2, h
+    return (out, stages) if return_stages else out
+
+
+def gine_conv_forward(x, ntypes, num_ntypes, eattr, etypes, num_etypes, csr, w, cin, chid, cout, slope):
+    """One GINEConv + activation (molecule_gnn.py:260-266).  `w` maps the
+    cgvp_gine_w field names to contiguous fp32 CUDA tensors."""
+    L = _lib.lib()
+    x = _f32(x, "x")
+    eattr = _f32(eattr, "eattr")
+    N = int(x.shape[0])
+    nt = _i64(ntypes, "ntypes") if num_ntypes > 0 else None
+    et = _i64(etypes, "etypes") if num_etypes > 0 else None
+    edge_dim = int(eattr.shape[1])
+    if x.shape[1] != cin - num_ntypes:
+        raise ValueError(f"x has {x.shape[1]} columns, expected {cin - num_ntypes}")
+    ws = {k: _f32(v, k) for k, v in w.items()}
+    gw = GineW(**{k: v.data_ptr() for k, v in ws.items()})
+    out = torch.empty(N, cout, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = L.cgvp_gine_conv_fwd(_ptr(x), _ptr(nt), num_ntypes, _ptr(eattr), _ptr(et), num_etypes, edge_dim,
+                                  _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), N, csr.num_edges,
+                                  cin, chid, cout, C.byref(gw), float(slope), _ptr(out), _stream())
+    _lib.check(rc, "cgvp_gine_conv_fwd")
+    return out

@@ -1,0 +1,194 @@
+"""`models.protein_gnn`: the residue-graph encoder behind the reference's module
+API (protein_gnn.py:14-82 wrapper, :86-152 base, :289-388 LBA model).
+
+`VectorProteinGNN_LBAModel` owns exactly the reference's parameters (same names
+and shapes) but keeps them as views into one fp32 arena and runs its forward as
+1 + 2*num_convs launches of libcaster_gvp.so on MI355X:
+
+    node embed            gvp_node (GVP + LayerNorm)                 per residue
+    conv l                gvp_edge + 3-GVP message + segmented sum   per edge / target
+    node update l         residual+LN, 2-GVP feed-forward, residual+LN
+                          (+ gvp_norm_before_scalar + gvp_to_scalar on the last layer)
+
+There is no eager/CPU fallback: CPU tensors, a missing library or dimensions the
+kernels were not compiled for raise.
+"""
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+import models.gvp_layers as gvp
+from gvp_hip import ops
+from gvp_hip.arena import ParamArena, lba_param_keys
+from models.model_utils import _select_activation
+
+_VECTOR_MODELS = ("lbamodel", "pocketminer", "cpdmodel")
+
+
+class SelectableProteinModelWrapper(nn.Module):
+    """Picks the protein encoder by `base_conv`; forwards calls and unknown
+    attributes (e.g. `.out_channels`, `.num_ntypes`) to the wrapped model."""
+
+    def __init__(self, in_channels, edge_dim, base_conv, **kwargs):
+        super().__init__()
+        if type(in_channels) is not type(edge_dim):
+            raise ValueError("in_channels and edge_dim must be the same type - either both are ints to "
+                             "represent scalars or both are tuples to represent (scalar, vector)")
+        self.base_conv = base_conv
+        self.is_scalar_data = isinstance(in_channels, int)
+        if self.is_scalar_data and base_conv in _VECTOR_MODELS:
+            raise ValueError(f"Cannot use a vector model {base_conv} with scalar input data {in_channels} "
+                             "(either define the input as (n, 0) or include vector data)")
+        if not self.is_scalar_data and base_conv not in _VECTOR_MODELS:
+            raise ValueError(f"Cannot use a scalar model {base_conv} with vector input data {in_channels} "
+                             "(either define the input as n or exclude vector data)")
+        registry = {
+            "lbamodel": VectorProteinGNN_LBAModel,
+            "pocketminer": _not_accelerated("VectorProteinGNN_PocketMiner"),
+            "cpdmodel": _not_accelerated("VectorProteinGNN_CPDModel"),
+            "gatv2": _not_accelerated("HomoScalarProteinGNN_GATv2"),
+            "heat": _not_accelerated("HeteroScalarProteinGNN_HEAT"),
+        }
+        self.gnn_model = registry[base_conv](in_channels=in_channels, edge_dim=edge_dim, **kwargs)
+
+    def forward(self, x, edge_index, ntypes, etypes, eattr=None, batch=None):
+        return self.gnn_model(x, edge_index, ntypes, etypes, eattr=eattr, batch=batch)
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(super().__getattr__("gnn_model"), name)
+
+
+def _not_accelerated(name):
+    def build(**kwargs):
+        raise NotImplementedError(
+            f"{name} is outside the MI355X hot path of this build (only the default 'lbamodel' GVP encoder "
+            "selected by train_model.py:276 is implemented); see DESIGN.md, 'Out of scope'")
+    return build
+
+
+class BaseProteinGNN(nn.Module):
+    """Shared constructor state: channel bookkeeping and the type encoders
+    (one-hot by default, nn.Embedding when an embedding width is given)."""
+
+    def __init__(self, in_channels, edge_dim, num_ntypes, num_etypes, ntype_emb_dim, etype_emb_dim,
+                 num_convs=1, hidden_channels=None, out_channels=8, dropout_rate=0.2, activation="relu"):
+        super().__init__()
+        self.in_channels = in_channels
+        self.edge_dim = edge_dim
+        self.num_ntypes = num_ntypes
+        self.num_etypes = num_etypes
+        self.num_convs = num_convs
+        self.hidden_channels = hidden_channels if hidden_channels is not None else out_channels
+        self.out_channels = out_channels
+        self.dropout_rate = dropout_rate
+        self.ntype_emb_dim = ntype_emb_dim
+        self.etype_emb_dim = etype_emb_dim
+        self._onehot_ntypes = ntype_emb_dim is None
+        self._onehot_etypes = etype_emb_dim is None
+        if self._onehot_ntypes:
+            self.ntype_embedding = partial(nn.functional.one_hot, num_classes=num_ntypes)
+            self.ntype_emb_dim = num_ntypes
+        else:
+            self.ntype_embedding = nn.Embedding(num_ntypes, ntype_emb_dim)
+        if self._onehot_etypes:
+            self.etype_embedding = partial(nn.functional.one_hot, num_classes=num_etypes)
+            self.etype_emb_dim = num_etypes
+        else:
+            self.etype_embedding = nn.Embedding(num_etypes, etype_emb_dim)
+        self.activation = _select_activation(activation)
+        self.dropout = nn.Dropout(dropout_rate)
+
+    def _embed_types_and_cat(self, x, eattr, ntypes, etypes):
+        """Type encodings go IN FRONT of the features (column order of ws.weight)."""
+        x = torch.cat([self.ntype_embedding(ntypes), x], dim=-1)
+        eattr = torch.cat([self.etype_embedding(etypes), eattr], dim=-1)
+        return x, eattr
+
+
+class VectorProteinGNN_LBAModel(BaseProteinGNN):
+    """GVP-GNN residue encoder (LBA-style): (N x 17, N x 3 x 3) residue features
+    over a radius / kNN graph -> N x 64 residue embeddings."""
+
+    def __init__(self, edge_hidden_channels, aggr="mean", **kwargs):
+        super().__init__(**kwargs)
+        self.edge_hidden_channels = edge_hidden_channels
+        self.aggr = aggr
+        if isinstance(self.hidden_channels, int):
+            self.hidden_channels = (self.hidden_channels, 0)
+        if isinstance(self.out_channels, int):
+            self.out_channels = (self.out_channels, 0)
+        self.in_channels = tuple(self.in_channels)
+        self.edge_dim = tuple(self.edge_dim)
+        self.hidden_channels = tuple(self.hidden_channels)
+        self.edge_hidden_channels = tuple(edge_hidden_channels)
+        node_in = (self.in_channels[0] + self.ntype_emb_dim, self.in_channels[1])
+        edge_in = (self.edge_dim[0] + self.etype_emb_dim, self.edge_dim[1])
+        plain = dict(activations=(None, None), vector_gate=True)
+        self.gvp_node = nn.Sequential(gvp.GVP(node_in, self.hidden_channels, **plain),
+                                      gvp.LayerNorm(self.hidden_channels))
+        self.gvp_edge = nn.Sequential(gvp.GVP(edge_in, self.edge_hidden_channels, **plain),
+                                      gvp.LayerNorm(self.edge_hidden_channels))
+        self.gvp_relu = nn.ReLU()
+        self.conv_list = nn.ModuleList([
+            gvp.GVPConvLayer(self.hidden_channels, self.edge_hidden_channels, drop_rate=self.dropout_rate,
+                             activations=(self.gvp_relu, None), vector_gate=True, aggr=aggr)
+            for _ in range(self.num_convs)])
+        self.gvp_norm_before_scalar = gvp.LayerNorm(self.hidden_channels)
+        self.gvp_to_scalar = gvp.GVP(self.hidden_channels, self.out_channels,
+                                     activations=(self.gvp_relu, None), vector_gate=True)
+        self._arena = None
+        self._hip_cfg = None
+
+    # ------------------------------------------------------------------ HIP path
+    def _hip_config(self):
+        if self._hip_cfg is None:
+            if self.out_channels[1] != 0:
+                raise NotImplementedError("the fused head produces scalars only (out_channels = (n, 0))")
+            dims = ops.make_dims(node_in_s=self.in_channels[0], node_in_v=self.in_channels[1],
+                                 edge_in_s=self.edge_dim[0], edge_in_v=self.edge_dim[1],
+                                 hidden_s=self.hidden_channels[0], hidden_v=self.hidden_channels[1],
+                                 edge_hidden_s=self.edge_hidden_channels[0],
+                                 edge_hidden_v=self.edge_hidden_channels[1], out_s=self.out_channels[0])
+            # with nn.Embedding type encoders the embedded columns are ordinary scalar inputs
+            if not (self._onehot_ntypes and self._onehot_etypes):
+                raise NotImplementedError("ntype_emb_dim / etype_emb_dim (nn.Embedding type encoders) are not "
+                                          "compiled into the fused kernels; use the default one-hot encoding")
+            layout = ops.lba_layout(dims, self.num_ntypes, self.num_etypes, self.num_convs)
+            self._hip_cfg = (dims, layout)
+        return self._hip_cfg
+
+    def _arena_buffer(self):
+        if self._arena is None:
+            named = dict(self.named_parameters())
+            self._arena = ParamArena([named[k] for k in lba_param_keys(self.num_convs)])
+        dims, layout = self._hip_config()
+        if self._arena.total != layout.total:
+            raise RuntimeError(f"parameter arena has {self._arena.total} floats, kernels expect {layout.total}")
+        return self._arena.buffer()
+
+    def forward(self, x, edge_index, ntypes, etypes, eattr=None, batch=None):
+        x_s, x_v = x
+        if eattr is None:
+            raise NotImplementedError("the LBA encoder needs edge features (eattr)")
+        e_s, e_v = eattr
+        if self.aggr not in ("sum", "add", "mean"):
+            raise ValueError(f"unsupported aggregation {self.aggr!r}")
+        dims, layout = self._hip_config()
+        params = self._arena_buffer()
+        if params.dtype != torch.float32:
+            raise TypeError("the MI355X kernels are fp32; call .float() on the model")
+        needs_grad = torch.is_grad_enabled() and (
+            params.requires_grad or any(p.requires_grad for p in self._arena.params)
+            or any(t.requires_grad for t in (x_s, x_v, e_s, e_v)))
+        train_dropout = self.training and self.dropout_rate > 0
+        csr = ops.cached_csr(edge_index, int(x_s.shape[0]))
+        if needs_grad or train_dropout:
+            from gvp_hip import autograd_ops
+            return autograd_ops.lba_encoder(self, params, layout, dims, x_s, x_v, ntypes, e_s, e_v, etypes,
+                                            csr, train_dropout)
+        return ops.lba_encoder_forward(params, layout, dims, self.num_convs, x_s, x_v, ntypes, e_s, e_v,
+                                       etypes, csr, aggr_mean=(self.aggr == "mean"))

@@ -1,0 +1,152 @@
+/* caster_gvp.h -- C ABI of libcaster_gvp.so: the MI355X (gfx950) implementation
+ * of CASTER-DTA's GVP / GINE message-passing hot path.
+ *
+ * The reference (stelleg/caster-dta) is 100 % Python and has no FFI; this is the
+ * boundary a maintainer binds (ctypes stub in INTEGRATION.md) underneath the
+ * reference's nn.Module API.  Each entry point names the reference code it
+ * replaces (file:line under the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch tensors);
+ *     nothing is allocated, freed or retained; outputs are preallocated;
+ *   - float tensors are contiguous fp32, row-major; nn.Linear weights are
+ *     [out][in]; index tensors are int64 as PyG delivers them, CSR tables int32;
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream);
+ *     launches are asynchronous, no call synchronises;
+ *   - return value: 0 = launched, >0 = hipError_t from the launch,
+ *     <0 = CGVP_ERR_* argument error.  Re-entrant, no global state.
+ *   - node state between stages is the merged row [s(16) | v(4x3)] = 28 floats
+ *     per residue, exactly gvp_layers.py:101 `_merge` of the (16,4) hidden tuple.
+ */
+#ifndef CASTER_GVP_H
+#define CASTER_GVP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CGVP_ABI_VERSION 1
+#define CGVP_ERR_BAD_ARG (-1)
+#define CGVP_ERR_UNSUPPORTED_DIMS (-2)
+
+/* PARAMETER ARENA.  All weights of VectorProteinGNN_LBAModel live in ONE
+ * contiguous fp32 buffer, in the reference's state_dict order with the
+ * zero-size dummy_params skipped (protein_gnn.py:325-358; key list in
+ * pretrained_model_downstream/*.pt):
+ *
+ *   gvp_node.0 {wh.weight, ws.weight, ws.bias, wv.weight, wsv.weight, wsv.bias}
+ *   gvp_node.1 {scalar_norm.weight, scalar_norm.bias}
+ *   gvp_edge.0 {...}, gvp_edge.1 {...}
+ *   for l in range(num_convs):
+ *     conv_list.l.conv.message_func.{0,1,2} {...}
+ *     conv_list.l.norm.{0,1}.scalar_norm {weight, bias}
+ *     conv_list.l.ff_func.{0,1} {...}
+ *   gvp_norm_before_scalar.scalar_norm {weight, bias}
+ *   gvp_to_scalar {wh.weight, ws.weight, ws.bias}
+ *
+ * Every tensor is row-major nn.Linear layout [out][in].  ws.weight has
+ * (num_types + si + h) input columns: one-hot type columns FIRST
+ * (protein_gnn.py:139-152), then scalar features, then vector norms.
+ * 15,117 floats for the shipped CASTER-DTA(2,2) model.  The host keeps the
+ * nn.Parameters as views into this buffer, so optimizers update it in place and
+ * no per-step packing exists.  Gradients use a second arena of the same layout. */
+typedef struct {
+  int32_t nt_node, nt_edge;   /* one-hot widths (num_ntypes, num_etypes)            */
+  int32_t node_gvp, node_ln;  /* float offsets of gvp_node.0 / gvp_node.1           */
+  int32_t edge_gvp, edge_ln;  /* gvp_edge.0 / gvp_edge.1                            */
+  int32_t conv0;              /* conv_list.0 block                                  */
+  int32_t conv_stride;        /* floats per conv_list.l block                       */
+  int32_t ln_out, head;       /* gvp_norm_before_scalar / gvp_to_scalar             */
+  int32_t total;              /* arena length in floats                             */
+} cgvp_layout;
+
+/* Encoder dimensions; the kernels are compiled for the CASTER-DTA(s,v)
+ * configuration and return CGVP_ERR_UNSUPPORTED_DIMS for anything else. */
+typedef struct {
+  int32_t node_in_s, node_in_v;     /* 17, 3 */
+  int32_t edge_in_s, edge_in_v;     /* 32, 1 */
+  int32_t hidden_s, hidden_v;       /* 16, 4 */
+  int32_t edge_hidden_s, edge_hidden_v; /* 32, 1 */
+  int32_t out_s;                    /* 64 */
+} cgvp_dims;
+
+/* Destination-sorted CSR of a batched graph.  Replaces the gather/scatter
+ * bookkeeping inside PyG MessagePassing.propagate (called at
+ * gvp_layers.py:298-300; torch_geometric is third party, not vendored):
+ * messages are reduced over edge_index[1].
+ *   rowptr[N+1]  first sorted-edge position of every target node
+ *   eperm[E]     original edge id of every sorted position (stable in edge id)
+ *   esrc[E], edst[E]  source / target node of every sorted position
+ *   work[N+1]    scratch
+ * Launches 5 small kernels on `stream`. */
+int cgvp_csr_from_coo(const int64_t* edge_index, int64_t num_nodes, int64_t num_edges,
+                      int32_t* rowptr, int32_t* eperm, int32_t* esrc, int32_t* edst,
+                      int32_t* work, void* stream);
+
+/* Fill `out` with the arena layout for the given one-hot widths and depth.
+ * Host-only, no GPU work. */
+int cgvp_lba_layout(const cgvp_dims* dims, int32_t num_ntypes, int32_t num_etypes,
+                    int32_t num_convs, cgvp_layout* out);
+
+/* gvp_node = Sequential(GVP, LayerNorm) on one-hot(ntypes) ++ x_s, x_v
+ * (protein_gnn.py:368-375).  x_s [N][17], x_v [N][3][3], ntypes [N] -> h [N][28]. */
+int cgvp_node_embed_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* params,
+                        const float* x_s, const float* x_v, const int64_t* ntypes,
+                        int64_t num_nodes, float* h, void* stream);
+
+/* GVPConv.forward (gvp_layers.py:291-308) of conv layer `layer` for every edge
+ * plus the reduction over target nodes (aggr 'sum'/'add' or 'mean'), with
+ * gvp_edge (protein_gnn.py:376) fused in: the edge embedding is recomputed in
+ * registers from the raw edge features and never written to HBM.
+ * h [N][28]; e_s [E][32], e_v [E][1][3], etypes [E] in ORIGINAL edge order; CSR
+ * tables from cgvp_csr_from_coo.  -> dh [N][28] (every row written, zero for
+ * isolated nodes). */
+int cgvp_conv_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* params,
+                  int32_t layer, const float* h, const float* e_s, const float* e_v,
+                  const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,
+                  const int32_t* esrc, const int32_t* edst, int64_t num_nodes, int64_t num_edges,
+                  int32_t aggr_mean, float* dh, void* stream);
+
+/* Rest of GVPConvLayer.forward in eval mode (gvp_layers.py:407-410):
+ * h_out = LN1(y + FF(y)), y = LN0(h + dh).  When `with_head` != 0 also applies
+ * gvp_norm_before_scalar + gvp_to_scalar (protein_gnn.py:385-386) and writes
+ * out [N][64]; h_out may then be NULL. */
+int cgvp_node_update_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* params,
+                         int32_t layer, const float* h, const float* dh, int64_t num_nodes,
+                         int32_t with_head, float* h_out, float* out, void* stream);
+
+/* One GINEConv + activation of HomoMoleculeGNN_GINE (molecule_gnn.py:254-268,
+ * :271-280; PyG GINEConv / MLP restated):
+ *   x'_i = LeakyReLU_slope( Lin1( LeakyReLU_slope( Lin0( (1+eps) x_i +
+ *            sum_{j->i} ReLU(x_j + W_e [onehot(etype) ++ eattr] + b_e) ) ) ) )
+ * `x` is [N][cin] when `ntypes` is NULL; for the first layer pass the raw atom
+ * features [N][cin - num_ntypes] and `ntypes`, and the one-hot columns are
+ * synthesised on the fly (molecule_gnn.py:127-140).  cin <= 64, chid <= 64,
+ * cout <= 64, edge_dim + num_etypes <= 16. */
+typedef struct {
+  const float* eps;     /* [1]                conv_list.l.eps            */
+  const float* we;      /* [cin][net+edge_dim] conv_list.l.lin.weight     */
+  const float* be;      /* [cin]              conv_list.l.lin.bias       */
+  const float* w0;      /* [chid][cin]        conv_list.l.nn.lins.0.weight */
+  const float* b0;      /* [chid]                                         */
+  const float* w1;      /* [cout][chid]       conv_list.l.nn.lins.1.weight */
+  const float* b1;      /* [cout]                                         */
+} cgvp_gine_w;
+
+int cgvp_gine_conv_fwd(const float* x, const int64_t* ntypes, int32_t num_ntypes,
+                       const float* eattr, const int64_t* etypes, int32_t num_etypes,
+                       int32_t edge_dim, const int32_t* rowptr, const int32_t* eperm,
+                       const int32_t* esrc, int64_t num_nodes, int64_t num_edges, int32_t cin,
+                       int32_t chid, int32_t cout, const cgvp_gine_w* w, float act_slope,
+                       float* out, void* stream);
+
+/* Library self-description (checked by the loader and the CPU test-suite). */
+int cgvp_abi_version(void);
+const char* cgvp_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CASTER_GVP_H */
