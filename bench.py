@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- graph-pairs/sec of the CASTER-DTA encoder hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of Davis-shaped synthetic
+pairs resident in HBM: destination-sorted CSR build for both graphs, the protein
+GVP encoder (node embed, 2 x [conv, node update], head) and the drug GINE encoder
+(2 layers).  N>1: one process per GPU (torchrun), each rank runs its own shard of
+pairs -- the encoders have no cross-pair term, so there is no data-path
+collective (weak scaling); timing is barrier + synchronize on both sides, MAX
+over ranks.
+
+Prints ONE JSON line (see DESIGN.md "Measurement" for the definitions of
+`roofline` and `cpu_baseline`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(REPO, "caster-dta_amd"), REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: Davis, batch 64 pairs, CASTER-DTA(2,2), 300-residue radius graphs (4 A)
+    "davis_b64": dict(pairs=64, length=300, thresh=4.0, thresh_type="dist"),
+    # configs[3]: 1000-residue proteins, ~20 edges/residue (kNN 20), replicated to fill the device
+    "long_graph_x64": dict(pairs=64, length=1000, thresh=20, thresh_type="num"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="davis_b64", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="fwd", choices=["fwd"])
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--cache-csr", action="store_true", help="reuse the CSR tables across steps")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import davis_synth as ds
+    from gvp_hip import ops
+    import __graft_entry__ as entry
+
+    wl = WORKLOADS[args.workload]
+    model, state = entry._load_model(dev)
+    pb, mb = ds.pair_batch(wl["pairs"], seed=rank, length=wl["length"], thresh=wl["thresh"],
+                           thresh_type=wl["thresh_type"])
+    to = lambda d: {k: (tuple(t.to(dev) for t in v) if isinstance(v, tuple) else v.to(dev)) for k, v in d.items()}
+    pdata_cpu, mdata_cpu = ds.to_torch(pb), ds.to_torch(mb)
+    pdata, mdata = to(pdata_cpu), to(mdata_cpu)
+    ops.CSR_CACHE_ENABLED = bool(args.cache_csr)
+    side = torch.cuda.Stream(device=dev)
+
+    def step():
+        main_s = torch.cuda.current_stream()
+        side.wait_stream(main_s)
+        with torch.cuda.stream(side):                 # drug graphs are tiny: run them beside the protein kernels
+            atoms = model.molecule_gnn(**mdata)
+        residues = model.protein_gnn(**pdata)
+        main_s.wait_stream(side)
+        return residues, atoms
+
+    with torch.no_grad():
+        out = step()
+        torch.cuda.synchronize()
+        graph = None
+        if not args.no_graph:
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = step()
+        run = graph.replay if graph is not None else step
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            run()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+
+        # ---- roofline leg: per-launch duration of the dominant kernel (conv_fwd), HIP events on its stream
+        roof = None
+        if rank == 0:
+            ops.KERNEL_EVENTS = []
+            for _ in range(min(args.steps, 50)):
+                model.protein_gnn(**pdata)
+            torch.cuda.synchronize()
+            times = [a.elapsed_time(b) * 1e-3 for (_, a, b) in ops.KERNEL_EVENTS]
+            ops.KERNEL_EVENTS = None
+            N, E = pb.num_nodes, pb.num_edges
+            conv_bytes = 224 * N + 156 * E            # per conv launch
+            times.sort()
+            avg = sum(times) / len(times)
+            peak = 8000.0
+            roof = dict(bound="hbm", achieved=round(conv_bytes / avg / 1e9, 1), peak=peak, unit="GB/s",
+                        frac=round(conv_bytes / avg / 1e9 / peak, 4), traffic=None, kernel="conv_fwd_kernel",
+                        avg_us=round(avg * 1e6, 2), median_us=round(times[len(times) // 2] * 1e6, 2),
+                        bytes_per_launch=conv_bytes, launches=len(times))
+
+    pairs_per_step = wl["pairs"] * world
+    value = pairs_per_step * args.steps / dt
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import gvp_oracle as O
+        pp = {k[len("protein_gnn.gnn_model."):]: v for k, v in state.items() if k.startswith("protein_gnn.gnn_model.")}
+        mp = {k[len("molecule_gnn.gnn_model."):]: v for k, v in state.items() if k.startswith("molecule_gnn.gnn_model.")}
+
+        def cpu_step():
+            O.protein_lba_forward(pp, pdata_cpu["x"], pdata_cpu["edge_index"], pdata_cpu["ntypes"],
+                                  pdata_cpu["etypes"], pdata_cpu["eattr"])
+            O.molecule_gine_forward(mp, mdata_cpu["x"], mdata_cpu["edge_index"], mdata_cpu["ntypes"],
+                                    mdata_cpu["etypes"], mdata_cpu["eattr"])
+        with torch.no_grad():
+            cpu_step()
+            n, t0 = 0, time.perf_counter()
+            while n < 3 or time.perf_counter() - t0 < args.cpu_seconds:
+                cpu_step()
+                n += 1
+            cdt = time.perf_counter() - t0
+        cpu = dict(value=round(wl["pairs"] * n / cdt, 1), unit="graph-pairs/sec", cores=torch.get_num_threads(),
+                   kind="port", sample=f"{n} forward passes of the same {wl['pairs']}-pair batch through "
+                   "oracle/gvp_oracle.py (torch CPU eager fp32)")
+
+    if rank == 0:
+        line = {
+            "metric": "graph-pairs/sec (Davis-shaped protein+drug), encoders forward",
+            "value": round(value, 1), "unit": "graph-pairs/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic Davis-shaped graphs (davis_synth, seed=rank); pretrained CASTER-DTA(2,2) weights",
+            "config": {"workload": args.workload, "pairs_per_gpu": wl["pairs"], "residues_per_gpu": pb.num_nodes,
+                       "protein_edges_per_gpu": pb.num_edges, "atoms_per_gpu": mb.num_nodes,
+                       "drug_edges_per_gpu": mb.num_edges, "encoder": "CASTER-DTA(2,2)", "pass": args.mode,
+                       "csr_build_in_step": not args.cache_csr, "hip_graph": graph is not None,
+                       "parallelism": f"pairs sharded x{world}, no collective"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

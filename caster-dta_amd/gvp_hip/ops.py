@@ -88,6 +88,46 @@ def build_csr(edge_index, num_nodes):
     return Csr(rowptr, eperm, esrc, edst, num_nodes, E)
 
 
+CSR_CACHE_ENABLED = True
+# bench.py's roofline leg: when this is a list, every conv launch appends a
+# (start, end) pair of timing events recorded on the launch stream.
+KERNEL_EVENTS = None
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if KERNEL_EVENTS is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()
+
+    def __exit__(self, *exc):
+        if KERNEL_EVENTS is not None:
+            self.ev[1].record()
+            KERNEL_EVENTS.append((self.name,) + self.ev)
+
+
+def cached_csr(edge_index, num_nodes):
+    """CSR of `edge_index`, memoised ON the tensor object itself (attribute
+    `_cgvp_csr`), so protein layers, repeated forwards on one batch and the
+    backward pass share one build.  The memo dies with the tensor and is ignored
+    after any in-place write (`_version` bump); a different tensor object -- every
+    freshly collated training batch -- is always rebuilt."""
+    if CSR_CACHE_ENABLED:
+        memo = getattr(edge_index, "_cgvp_csr", None)
+        if memo is not None and memo[0] == edge_index._version and memo[1].num_nodes == num_nodes:
+            return memo[1]
+    csr = build_csr(edge_index, num_nodes)
+    if CSR_CACHE_ENABLED:
+        try:
+            edge_index._cgvp_csr = (edge_index._version, csr)
+        except (AttributeError, RuntimeError):
+            pass
+    return csr
+
+
 def lba_encoder_forward(params, layout, dims, num_convs, x_s, x_v, ntypes, e_s, e_v, etypes, csr,
                         aggr_mean=False, return_stages=False):
     """VectorProteinGNN_LBAModel.forward (protein_gnn.py:361-388), eval mode,
@@ -123,9 +163,10 @@ def lba_encoder_forward(params, layout, dims, num_convs, x_s, x_v, ntypes, e_s, 
         if return_stages:
             stages["node_embed"] = h.clone()
         for layer in range(num_convs):
-            _lib.check(L.cgvp_conv_fwd(d, lay, P, layer, _ptr(h), _ptr(e_s), _ptr(e_v), _ptr(et),
-                                       _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst),
-                                       N, E, 1 if aggr_mean else 0, _ptr(dh), st), "cgvp_conv_fwd")
+            with _timed("conv_fwd"):
+                _lib.check(L.cgvp_conv_fwd(d, lay, P, layer, _ptr(h), _ptr(e_s), _ptr(e_v), _ptr(et),
+                                           _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst),
+                                           N, E, 1 if aggr_mean else 0, _ptr(dh), st), "cgvp_conv_fwd")
             if return_stages:
                 stages[f"conv{layer}_dh"] = dh.clone()
             last = layer == num_convs - 1

@@ -1,0 +1,262 @@
+"""`models.joint_gnn`: the caller of the hot path, with the reference's API
+(joint_gnn.py:15-288 JointGNN, :321-409 CrossAttentionModule, :411-451 stack).
+
+The two encoders (`protein_gnn`, `molecule_gnn`) are the MI355X kernels; what
+follows them -- per-node Linear, padding to a dense batch, residue<->atom
+cross-attention, masked pooling and the affinity MLP -- is stock torch.nn on the
+same device, with the reference's parameter names so checkpoints load strictly.
+It does not import torch_geometric (`to_dense_batch` is restated below).
+
+Multi-GPU: independent protein/drug pairs shard across ranks (one process per
+GPU).  `enable_pair_parallel()` inserts ONE all-gather of the per-pair embedding
+`cat[protein_embed, molecule_embed]` ([B_local, 512] fp32 -> [B, 512], RCCL over
+xGMI) right before `pm_embed_lin` (joint_gnn.py:272-273); the affinity head then
+runs replicated and every rank returns all B predictions.
+"""
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from models.model_utils import _select_activation
+from models.molecule_gnn import SelectableMoleculeModelWrapper as MoleculeGNN
+from models.protein_gnn import SelectableProteinModelWrapper as ProteinGNN
+
+
+def to_dense_batch(x, batch=None, batch_size=None):
+    """[N, D] rows grouped by a sorted `batch` vector -> ([B, Lmax, D] zero padded,
+    bool mask [B, Lmax]).  Same contract as torch_geometric.utils.to_dense_batch."""
+    if batch is None:
+        return x.unsqueeze(0), x.new_ones(1, x.shape[0], dtype=torch.bool)
+    if batch_size is None:
+        batch_size = int(batch.max()) + 1 if batch.numel() else 0
+    counts = torch.bincount(batch, minlength=batch_size)
+    lmax = int(counts.max()) if counts.numel() else 0
+    start = torch.cumsum(counts, 0) - counts
+    slot = batch * lmax + (torch.arange(batch.numel(), device=batch.device) - start[batch])
+    dense = x.new_zeros(batch_size * lmax, x.shape[1])
+    dense[slot] = x
+    mask = torch.zeros(batch_size * lmax, dtype=torch.bool, device=x.device)
+    mask[slot] = True
+    return dense.view(batch_size, lmax, x.shape[1]), mask.view(batch_size, lmax)
+
+
+class _BatchNorm(nn.Module):
+    """Key-compatible stand-in for pyg.nn.BatchNorm (parameters live under `.module`)."""
+
+    def __init__(self, channels, allow_single_element=True):
+        super().__init__()
+        self.module = nn.BatchNorm1d(channels)
+        self.allow_single_element = allow_single_element
+
+    def forward(self, x):
+        if self.allow_single_element and x.shape[0] <= 1:
+            return nn.functional.batch_norm(x, self.module.running_mean, self.module.running_var,
+                                            self.module.weight, self.module.bias, False, 0.0, self.module.eps)
+        return self.module(x)
+
+
+class JointGNN(nn.Module):
+    """Protein encoder + drug encoder + cross-attention + affinity head -> [B, 1]."""
+
+    def __init__(self, protein_gnn_kwargs, molecule_gnn_kwargs, residue_lin_depth, atom_lin_depth,
+                 n_attention_heads, attention_dropout, protein_lin_depth, molecule_lin_depth,
+                 pairwise_embedding_dim, out_lin_depth, out_lin_factor=0.5, out_lin_norm_type=None,
+                 activation="relu", dropout=0.0, element_pooling="mean", include_residual_stream=True,
+                 residual_dim_ff_scale=2, num_cross_attn_layers=1, include_post_pool_layernorm=False):
+        super().__init__()
+        self.pairwise_embedding_dim = pairwise_embedding_dim
+        self.n_attention_heads = n_attention_heads
+        self.attention_dropout = attention_dropout
+        self.element_pooling = element_pooling
+        self.num_cross_attn_layers = num_cross_attn_layers
+        self.include_residual_stream = include_residual_stream
+        self.residual_dim_ff_scale = residual_dim_ff_scale
+        self.include_post_pool_layernorm = include_post_pool_layernorm
+        self.out_lin_factor = out_lin_factor
+        self.out_lin_norm_type = out_lin_norm_type
+        self.activation = _select_activation(activation)
+        self.dropout = nn.Dropout(dropout)
+
+        self.protein_gnn = ProteinGNN(**_tupled(protein_gnn_kwargs))
+        self.molecule_gnn = MoleculeGNN(**molecule_gnn_kwargs)
+        p_out, m_out = self.protein_gnn.out_channels, self.molecule_gnn.out_channels
+        p_out = p_out[0] if isinstance(p_out, tuple) else p_out
+        m_out = m_out[0] if isinstance(m_out, tuple) else m_out
+
+        self.residue_lins, self.residue_norms, r_dim = self._make_lins_from_depth(residue_lin_depth, p_out)
+        self.atom_lins, self.atom_norms, a_dim = self._make_lins_from_depth(atom_lin_depth, m_out)
+        if num_cross_attn_layers > 0:
+            block = partial(CrossAttentionModule, embed_dim_1=r_dim, embed_dim_2=a_dim,
+                            n_attention_heads=n_attention_heads, attn_dropout=attention_dropout,
+                            include_residual_stream=include_residual_stream,
+                            dim_feedforward_scale=residual_dim_ff_scale, feedforward_dropout=dropout)
+            self.cross_attn_module = StackedCrossAttentionModule(block, num_layers=num_cross_attn_layers)
+        else:
+            self.cross_attn_module = None
+        if include_post_pool_layernorm:
+            self.protein_post_pool_norm = nn.LayerNorm(r_dim)
+            self.molecule_post_pool_norm = nn.LayerNorm(a_dim)
+        self.protein_lins, self.protein_norms, p_dim = self._make_lins_from_depth(protein_lin_depth, r_dim)
+        self.molecule_lins, self.molecule_norms, m_dim = self._make_lins_from_depth(molecule_lin_depth, a_dim)
+        self.pm_embed_lin = nn.Linear(p_dim + m_dim, pairwise_embedding_dim)
+        self.out_fc_layers, self.out_fc_norms, head_dim = self._make_lins_from_depth(
+            out_lin_depth, pairwise_embedding_dim, scale_factor=out_lin_factor, include_norms=out_lin_norm_type)
+        self.output_layer = nn.Linear(head_dim, 1)
+        self._pair_group = None
+        self._pair_parallel = False
+
+    # ------------------------------------------------------------ multi-GPU
+    def enable_pair_parallel(self, group=None):
+        """Shard pairs over the ranks of `group`: all-gather pair embeddings before the head."""
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self._pair_group, self._pair_parallel = group, True
+        return self
+
+    def _gather_pairs(self, pair):
+        import torch.distributed as dist
+        world = dist.get_world_size(self._pair_group)
+        if world == 1:
+            return pair
+        counts = [torch.zeros(1, dtype=torch.long, device=pair.device) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([pair.shape[0]], dtype=torch.long, device=pair.device),
+                        group=self._pair_group)
+        counts = [int(c) for c in counts]
+        width = max(counts)
+        padded = pair if pair.shape[0] == width else torch.cat(
+            [pair, pair.new_zeros(width - pair.shape[0], pair.shape[1])])
+        if pair.requires_grad and torch.is_grad_enabled():
+            from torch.distributed.nn.functional import all_gather as ag
+            parts = ag(padded.contiguous(), group=self._pair_group)
+        else:
+            parts = [torch.empty_like(padded) for _ in range(world)]
+            dist.all_gather(parts, padded.contiguous(), group=self._pair_group)
+        return torch.cat([p[:c] for p, c in zip(parts, counts)])
+
+    # ------------------------------------------------------------ forward
+    def forward_with_graphs(self, protein_graph, molecule_graph):
+        return self.forward(*self._graphs_to_dicts(protein_graph, molecule_graph))
+
+    @staticmethod
+    def _graphs_to_dicts(protein_graph, molecule_graph):
+        def as_dict(g):
+            ei = g.edge_index if getattr(g, "edge_index", None) is not None else g.adj_t
+            return {"x": g.x, "edge_index": ei, "ntypes": g.node_type, "etypes": g.edge_type,
+                    "eattr": g.edge_attr, "batch": g.batch}
+        return as_dict(protein_graph), as_dict(molecule_graph)
+
+    def _stack(self, t, lins, norms):
+        for lin, norm in zip(lins, norms):
+            t = self.dropout(self.activation(norm(lin(t))))
+        return t
+
+    def _pool(self, dense, mask):
+        m = mask.unsqueeze(-1)
+        if self.element_pooling == "mean":
+            return (dense * m).sum(dim=1) / mask.sum(dim=1, keepdim=True)
+        if self.element_pooling == "sum":
+            return (dense * m).sum(dim=1)
+        if self.element_pooling == "max":
+            return (dense - (~m) * 1.0e10).max(dim=1).values
+        raise ValueError(self.element_pooling)
+
+    def forward(self, protein_graph_data={}, molecule_graph_data={}):
+        pbatch = protein_graph_data.get("batch", None)
+        mbatch = molecule_graph_data.get("batch", None)
+        residue = self.protein_gnn(**protein_graph_data)          # MI355X kernels
+        atom = self.molecule_gnn(**molecule_graph_data)           # MI355X kernels
+        residue = self._stack(residue, self.residue_lins, self.residue_norms)
+        atom = self._stack(atom, self.atom_lins, self.atom_norms)
+        residue, rmask = to_dense_batch(residue, pbatch)
+        atom, amask = to_dense_batch(atom, mbatch)
+        attn = None
+        if self.cross_attn_module is not None:
+            residue, atom, attn = self.cross_attn_module(residue, atom, rmask, amask)
+        protein, molecule = self._pool(residue, rmask), self._pool(atom, amask)
+        if self.include_post_pool_layernorm:
+            protein, molecule = self.protein_post_pool_norm(protein), self.molecule_post_pool_norm(molecule)
+        protein = self.dropout(self.activation(protein))
+        molecule = self.dropout(self.activation(molecule))
+        protein = self._stack(protein, self.protein_lins, self.protein_norms)
+        molecule = self._stack(molecule, self.molecule_lins, self.molecule_norms)
+        pair = torch.cat([protein, molecule], dim=-1)
+        if self._pair_parallel:
+            pair = self._gather_pairs(pair)
+        z = self.dropout(self.activation(self.pm_embed_lin(pair)))
+        z = self._stack(z, self.out_fc_layers, self.out_fc_norms)
+        return self.output_layer(z), attn
+
+    @staticmethod
+    def _make_lins_from_depth(depth, in_dim, scale_factor=2, include_norms=None):
+        """`depth` Linear layers, each scaling the width by `scale_factor` (truncated)."""
+        norm = {"layer": nn.LayerNorm, "batch": _BatchNorm}.get(include_norms, nn.Identity)
+        lins, norms, width = [], [], in_dim
+        for _ in range(depth):
+            nxt = int(width * scale_factor)
+            lins.append(nn.Linear(width, nxt))
+            norms.append(norm(nxt))
+            width = nxt
+        return nn.ModuleList(lins), nn.ModuleList(norms), width
+
+
+def _tupled(kwargs):
+    """model_kwargs.json stores (s, v) dims as lists; the encoders expect tuples."""
+    out = dict(kwargs)
+    for k in ("in_channels", "edge_dim", "hidden_channels", "edge_hidden_channels", "out_channels"):
+        if isinstance(out.get(k), list):
+            out[k] = tuple(out[k])
+    return out
+
+
+class CrossAttentionModule(nn.Module):
+    """Pre-norm bidirectional cross attention (residues <-> atoms) with optional
+    residual feed-forward streams."""
+
+    def __init__(self, embed_dim_1, embed_dim_2, n_attention_heads, attn_dropout, include_residual_stream=True,
+                 dim_feedforward_scale=2, feedforward_dropout=0.2):
+        super().__init__()
+        self.include_residual_stream = include_residual_stream
+        self.preattn_norm1 = nn.LayerNorm(embed_dim_1)
+        self.preattn_norm2 = nn.LayerNorm(embed_dim_2)
+        self.embed1_to_2 = nn.MultiheadAttention(embed_dim=embed_dim_1, kdim=embed_dim_2, vdim=embed_dim_2,
+                                                 num_heads=n_attention_heads, dropout=attn_dropout,
+                                                 batch_first=True)
+        self.embed2_to_1 = nn.MultiheadAttention(embed_dim=embed_dim_2, kdim=embed_dim_1, vdim=embed_dim_1,
+                                                 num_heads=n_attention_heads, dropout=attn_dropout,
+                                                 batch_first=True)
+        self.ff_norm1 = nn.LayerNorm(embed_dim_1)
+        self.ff_norm2 = nn.LayerNorm(embed_dim_2)
+        self.ff_dropout = nn.Dropout(feedforward_dropout)
+        if include_residual_stream:
+            def ff(d):
+                return nn.Sequential(nn.Linear(d, d * dim_feedforward_scale), nn.ReLU(),
+                                     nn.Dropout(feedforward_dropout), nn.Linear(d * dim_feedforward_scale, d))
+            self.ff1, self.ff2 = ff(embed_dim_1), ff(embed_dim_2)
+
+    def forward(self, embed_1, embed_2, mask1, mask2, return_weights=True):
+        n1, n2 = self.preattn_norm1(embed_1), self.preattn_norm2(embed_2)
+        a1, w1 = self.embed1_to_2(n1, n2, n2, key_padding_mask=~mask2)
+        a2, w2 = self.embed2_to_1(n2, n1, n1, key_padding_mask=~mask1)
+        if self.include_residual_stream:
+            embed_1 = embed_1 + self.ff_dropout(a1)
+            embed_1 = embed_1 + self.ff_dropout(self.ff1(self.ff_norm1(embed_1)))
+            embed_2 = embed_2 + self.ff_dropout(a2)
+            embed_2 = embed_2 + self.ff_dropout(self.ff2(self.ff_norm2(embed_2)))
+        else:
+            embed_1, embed_2 = a1, a2
+        return (embed_1, embed_2, (w1, w2)) if return_weights else (embed_1, embed_2)
+
+
+class StackedCrossAttentionModule(nn.Module):
+    def __init__(self, cross_attn_base, num_layers):
+        super().__init__()
+        self.cross_attn_layers = nn.ModuleList([cross_attn_base() for _ in range(num_layers)])
+
+    def forward(self, embed_1, embed_2, mask1, mask2, return_weights=True):
+        weights = []
+        for layer in self.cross_attn_layers:
+            embed_1, embed_2, w = layer(embed_1, embed_2, mask1, mask2, return_weights=True)
+            weights.append(w)
+        return (embed_1, embed_2, weights) if return_weights else (embed_1, embed_2)

@@ -1,0 +1,122 @@
+"""GPU parity at the drop-in boundary: the `models.*` nn.Modules (what
+train_model.py / inference_utils.py instantiate) against the reference's golden
+vectors and the CPU oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import davis_synth as ds
+from conftest import GOLDEN, rel_err
+from oracle import gvp_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 2e-5
+
+
+def _to(d, dev=DEV):
+    return {k: (tuple(t.to(dev) for t in v) if isinstance(v, tuple) else v.to(dev)) for k, v in d.items()}
+
+
+@pytest.fixture(scope="module")
+def joint(pretrained):
+    from models.joint_gnn import JointGNN
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))
+    m = JointGNN(protein_gnn_kwargs=kw["protein_gnn_kwargs"], molecule_gnn_kwargs=kw["molecule_gnn_kwargs"],
+                 **kw["joint_gnn_kwargs"])
+    m.load_state_dict(pretrained, strict=True)
+    return m.to(DEV).eval()
+
+
+def test_protein_module_golden(joint, lba_small):
+    g = lba_small
+    T = torch.from_numpy
+    d = dict(x=(T(g["x_s"]), T(g["x_v"])), edge_index=T(g["edge_index"]), ntypes=T(g["ntypes"]),
+             etypes=T(g["etypes"]), eattr=(T(g["e_s"]), T(g["e_v"])), batch=T(g["batch"]))
+    with torch.no_grad():
+        out = joint.protein_gnn(**_to(d))
+    assert rel_err(out, g["out"]) < TOL
+
+
+def test_joint_model_vs_oracle(joint, pretrained):
+    """Encoders (HIP) + head (stock torch on the GPU) == oracle end to end, on a
+    ragged batch; exercises to_dense_batch padding and the attention masks."""
+    p, m = ds.pair_batch(5, 21, lengths=[40, 75, 33, 120, 64])
+    pd, md = ds.to_torch(p), ds.to_torch(m)
+    with torch.no_grad():
+        y, attn = joint(_to(pd), _to(md))
+        atoms = joint.molecule_gnn(**_to(md))
+    ref = O.joint_forward(pretrained, pd, md)
+    mp = {k[len("molecule_gnn.gnn_model."):]: v for k, v in pretrained.items() if k.startswith("molecule_gnn.gnn_model.")}
+    ref_atoms = O.molecule_gine_forward(mp, md["x"], md["edge_index"], md["ntypes"], md["etypes"], md["eattr"])
+    assert rel_err(atoms, ref_atoms) < TOL
+    assert y.shape == (5, 1) and rel_err(y, ref) < 1e-4
+    assert attn[0][0].shape[0] == 5
+
+
+def test_state_dict_roundtrip_and_arena_refresh(joint, pretrained):
+    """Weights changed through the ordinary nn.Module API reach the kernels."""
+    p = ds.protein_batch(2, 3, lengths=[50, 31])
+    d = _to(ds.to_torch(p))
+    with torch.no_grad():
+        base = joint.protein_gnn(**d).clone()
+        w = joint.protein_gnn.gnn_model.gvp_to_scalar.ws.bias
+        w.add_(0.5)
+        bumped = joint.protein_gnn(**d)
+        assert float((bumped - base).abs().max()) > 0.1
+        joint.load_state_dict(pretrained, strict=True)
+        assert torch.equal(joint.protein_gnn(**d), base)
+        sd = {k: v.clone() for k, v in joint.state_dict().items()}
+    assert all(torch.equal(sd[k].cpu(), pretrained[k]) for k in pretrained)
+
+
+def test_csr_memo_semantics(joint):
+    from gvp_hip import ops
+    p = ds.protein_batch(1, 5, length=40)
+    d = _to(ds.to_torch(p))
+    ei = d["edge_index"]
+    a = ops.cached_csr(ei, p.num_nodes)
+    assert ops.cached_csr(ei, p.num_nodes) is a
+    assert ops.cached_csr(ei.clone(), p.num_nodes) is not a      # new tensor object: rebuilt
+    ei[0, 0] = ei[0, 0]                                          # in-place write bumps _version
+    assert ops.cached_csr(ei, p.num_nodes) is not a
+
+
+def test_hip_graph_capture_replays(joint):
+    """The whole encoder step (CSR build included) is capturable in a HIP graph."""
+    from gvp_hip import ops
+    p, m = ds.pair_batch(4, 9, length=80)
+    pd, md = _to(ds.to_torch(p)), _to(ds.to_torch(m))
+    old = ops.CSR_CACHE_ENABLED
+    ops.CSR_CACHE_ENABLED = False
+    try:
+        with torch.no_grad():
+            eager = joint.protein_gnn(**pd).clone()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                joint.protein_gnn(**pd)
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = joint.protein_gnn(**pd)
+            out.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, eager)
+    finally:
+        ops.CSR_CACHE_ENABLED = old
+
+
+def test_training_mode_not_silently_wrong(joint):
+    """Until the backward kernels land, asking for gradients must raise, not fall back."""
+    p = ds.protein_batch(1, 5, length=30)
+    d = _to(ds.to_torch(p))
+    try:
+        from gvp_hip import autograd_ops  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError):
+            joint.protein_gnn(**d)
