@@ -132,7 +132,8 @@ def main():
             avg = sum(times) / len(times)
             peak = 8000.0
             roof = dict(bound="hbm", achieved=round(conv_bytes / avg / 1e9, 1), peak=peak, unit="GB/s",
-                        frac=round(conv_bytes / avg / 1e9 / peak, 4), traffic=None, kernel="conv_fwd_kernel",
+                        frac=round(conv_bytes / avg / 1e9 / peak, 4), traffic=None,
+                        kernel="conv_quad_kernel" if ops.VARIANT == "mfma" else "conv_fwd_kernel",
                         avg_us=round(avg * 1e6, 2), median_us=round(times[len(times) // 2] * 1e6, 2),
                         bytes_per_launch=conv_bytes, launches=len(times))
 
@@ -172,6 +173,7 @@ def main():
                        "protein_edges_per_gpu": pb.num_edges, "atoms_per_gpu": mb.num_nodes,
                        "drug_edges_per_gpu": mb.num_edges, "encoder": "CASTER-DTA(2,2)", "pass": args.mode,
                        "csr_build_in_step": not args.cache_csr, "hip_graph": graph is not None,
+                       "kernels": ops.VARIANT,
                        "parallelism": f"pairs sharded x{world}, no collective"},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -13,8 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../include/caster_gvp.h"
-#include "gvp_math.h"
+#include "gvp_internal.h"
 
 using namespace gvp;
 
@@ -57,14 +56,24 @@ __global__ void csr_count_kernel(const int64_t* __restrict__ ei, int64_t N, int6
 
 // Exclusive scan of cnt[0..N) by ONE 1024-thread block; rowptr[N] = total;
 // cnt is rewritten with the scan so the fill kernel can use it as a cursor.
+// Tables up to SCAN_LDS entries are scanned in LDS with coalesced global
+// traffic; longer ones fall back to per-thread contiguous chunks.
+constexpr int SCAN_LDS = 36 * 1024;   // 144 KB of the 160 KB LDS
 __global__ __launch_bounds__(1024) void csr_scan_kernel(int32_t* __restrict__ cnt, int64_t N,
                                                         int32_t* __restrict__ rowptr) {
-  __shared__ int32_t part[1024];
+  extern __shared__ int32_t sbuf[];             // [N if it fits][1024 partials]
   const int t = threadIdx.x;
+  const bool in_lds = N <= SCAN_LDS;
+  int32_t* part = sbuf + (in_lds ? (int)N : 0);
   const int64_t chunk = (N + 1023) / 1024;
   const int64_t lo = t * chunk, hi = (lo + chunk < N) ? lo + chunk : N;
+  if (in_lds) {
+    for (int64_t i = t; i < N; i += 1024) sbuf[i] = cnt[i];
+    __syncthreads();
+  }
+  const int32_t* src = in_lds ? sbuf : cnt;
   int32_t sum = 0;
-  for (int64_t i = lo; i < hi; ++i) sum += cnt[i];
+  for (int64_t i = lo; i < hi; ++i) sum += src[i];
   part[t] = sum;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
@@ -74,11 +83,12 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int32_t* __restrict__ cn
     __syncthreads();
   }
   int32_t run = part[t] - sum;   // exclusive prefix of this thread's chunk
-  for (int64_t i = lo; i < hi; ++i) {
-    int32_t c = cnt[i];
-    rowptr[i] = run;
-    cnt[i] = run;
-    run += c;
+  if (in_lds) {
+    for (int64_t i = lo; i < hi; ++i) { const int32_t c = sbuf[i]; sbuf[i] = run; run += c; }
+    __syncthreads();
+    for (int64_t i = t; i < N; i += 1024) { const int32_t v = sbuf[i]; rowptr[i] = v; cnt[i] = v; }
+  } else {
+    for (int64_t i = lo; i < hi; ++i) { const int32_t c = cnt[i]; rowptr[i] = run; cnt[i] = run; run += c; }
   }
   if (t == 1023) rowptr[N] = part[1023];
 }
@@ -407,7 +417,7 @@ int cgvp_csr_from_coo(const int64_t* edge_index, int64_t N, int64_t E, int32_t* 
   if (err != hipSuccess) return (int)err;
   const int B = 256;
   if (E > 0) hipLaunchKernelGGL(csr_count_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, work);
-  hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, s, work, N, rowptr);
+  hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), (size_t)((N <= SCAN_LDS ? N : 0) + 1024) * sizeof(int32_t), s, work, N, rowptr);
   if (E > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, work, eperm);
   if (N > 0 && E > 0) hipLaunchKernelGGL(csr_finish_kernel, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, rowptr, eperm, esrc, edst);
   return launch_status();
@@ -424,13 +434,36 @@ int cgvp_lba_layout(const cgvp_dims* dims, int32_t num_ntypes, int32_t num_etype
   return 0;
 }
 
+int64_t cgvp_lba_image_floats(const cgvp_dims* dims, const cgvp_layout* layout) {
+  if (int rc = check_dims(dims)) return rc;
+  if (!layout) return CGVP_ERR_BAD_ARG;
+  QuadOffsets o;
+  if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
+  return o.total;
+}
+
+int cgvp_lba_prepare(const cgvp_dims* dims, const cgvp_layout* layout, const float* params, float* image,
+                     void* stream) {
+  if (int rc = check_dims(dims)) return rc;
+  if (!layout || !params || !image) return CGVP_ERR_BAD_ARG;
+  if (int rc = quad::prepare(cvt(*layout), num_convs_of(*layout), params, image, (hipStream_t)stream)) return rc;
+  return launch_status();
+}
+
 int cgvp_node_embed_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* params,
-                        const float* x_s, const float* x_v, const int64_t* ntypes, int64_t N,
-                        float* h, void* stream) {
+                        const float* image, const float* x_s, const float* x_v, const int64_t* ntypes,
+                        int64_t N, float* h, void* stream) {
   if (int rc = check_dims(dims)) return rc;
   if (N < 0 || !layout || !params || (layout->nt_node > 0 && N > 0 && !ntypes)) return CGVP_ERR_BAD_ARG;
   if (N == 0) return 0;
   if (!x_s || !x_v || !h) return CGVP_ERR_BAD_ARG;
+  if (image) {
+    if ((uintptr_t)h & 15) return CGVP_ERR_BAD_ARG;
+    QuadOffsets o;
+    if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
+    if (int rc = quad::node_embed(layout->nt_node, image + o.emb, x_s, x_v, ntypes, N, h, (hipStream_t)stream)) return rc;
+    return launch_status();
+  }
   NodeEmbedArgs a{params, cvt(*layout), x_s, x_v, ntypes, N, h};
   const dim3 grid((unsigned)((N + WAVE - 1) / WAVE));
   hipStream_t st = (hipStream_t)stream;
@@ -443,7 +476,8 @@ int cgvp_node_embed_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
   return launch_status();
 }
 
-int cgvp_conv_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* params, int32_t layer,
+int cgvp_conv_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* params,
+                  const float* image, int32_t layer,
                   const float* h, const float* e_s, const float* e_v, const int64_t* etypes,
                   const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
                   const int32_t* edst, int64_t N, int64_t E, int32_t aggr_mean, float* dh,
@@ -455,6 +489,13 @@ int cgvp_conv_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float*
   if (!h || !dh || !rowptr) return CGVP_ERR_BAD_ARG;
   if (E > 0 && (!e_s || !e_v || !eperm || !esrc || !edst || (layout->nt_edge > 0 && !etypes))) return CGVP_ERR_BAD_ARG;
   if (((uintptr_t)h & 15) || ((uintptr_t)e_s & 15)) return CGVP_ERR_BAD_ARG;   // float4 row loads
+  if (image) {
+    QuadOffsets o;
+    if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
+    if (int rc = quad::conv(layout->nt_edge, image + o.conv0 + layer * o.layer_stride, h, e_s, e_v, etypes, rowptr,
+                            eperm, esrc, edst, N, E, aggr_mean ? 1 : 0, dh, (hipStream_t)stream)) return rc;
+    return launch_status();
+  }
   // target nodes per workgroup: aim at ~48 of the 64 edge lanes per chunk
   int64_t deg = (E + N - 1) / N;
   if (deg < 1) deg = 1;
@@ -473,14 +514,22 @@ int cgvp_conv_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float*
 }
 
 int cgvp_node_update_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* params,
-                         int32_t layer, const float* h, const float* dh, int64_t N, int32_t with_head,
-                         float* h_out, float* out, void* stream) {
+                         const float* image, int32_t layer, const float* h, const float* dh, int64_t N,
+                         int32_t with_head, float* h_out, float* out, void* stream) {
   if (int rc = check_dims(dims)) return rc;
   if (N < 0 || !layout || !params) return CGVP_ERR_BAD_ARG;
   if (layer < 0 || layer >= num_convs_of(*layout)) return CGVP_ERR_BAD_ARG;
   if (N == 0) return 0;
   if (!h || !dh || (with_head ? !out : !h_out)) return CGVP_ERR_BAD_ARG;
   if (((uintptr_t)h & 15) || ((uintptr_t)dh & 15)) return CGVP_ERR_BAD_ARG;
+  if (image) {
+    if (((uintptr_t)h_out & 15) || ((uintptr_t)out & 15)) return CGVP_ERR_BAD_ARG;
+    QuadOffsets o;
+    if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
+    if (int rc = quad::node_update(image + o.node0 + layer * o.layer_stride, image + o.head, h, dh, N,
+                                   with_head ? 1 : 0, h_out, out, (hipStream_t)stream)) return rc;
+    return launch_status();
+  }
   NodeUpdateArgs a{params, cvt(*layout), layer, h, dh, N, h_out, out};
   dim3 grid((unsigned)((N + WAVE - 1) / WAVE));
   if (with_head) hipLaunchKernelGGL(node_update_kernel<true>, grid, dim3(WAVE), 0, (hipStream_t)stream, a);

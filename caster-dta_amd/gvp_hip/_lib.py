@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcaster_gvp.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class HipLibraryError(RuntimeError):
@@ -46,10 +46,12 @@ _SIGNATURES = {
     "cgvp_build_info": (C.c_char_p, []),
     "cgvp_csr_from_coo": (C.c_int, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P]),
     "cgvp_lba_layout": (C.c_int, [C.POINTER(Dims), _I32, _I32, _I32, C.POINTER(Layout)]),
-    "cgvp_node_embed_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _P, _P, _I64, _P, _P]),
-    "cgvp_conv_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _P, _P, _P, _P, _P,
+    "cgvp_lba_image_floats": (C.c_int64, [C.POINTER(Dims), C.POINTER(Layout)]),
+    "cgvp_lba_prepare": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _P]),
+    "cgvp_node_embed_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _P, _P, _P, _I64, _P, _P]),
+    "cgvp_conv_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P,
                                 _P, _I64, _I64, _I32, _P, _P]),
-    "cgvp_node_update_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _I64, _I32,
+    "cgvp_node_update_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _I32, _P, _P, _I64, _I32,
                                        _P, _P, _P]),
     "cgvp_gine_conv_fwd": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _I64, _I64, _I32, _I32,
                                      _I32, C.POINTER(GineW), C.c_float, _P, _P]),

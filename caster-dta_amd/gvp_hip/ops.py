@@ -5,6 +5,7 @@ PyTorch's current HIP stream.  No arithmetic happens here.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import torch
@@ -89,6 +90,9 @@ def build_csr(edge_index, num_nodes):
 
 
 CSR_CACHE_ENABLED = True
+# "mfma": 16-item MFMA tiles fed from the fragment image (production path);
+# "simt": one item per lane straight from the arena (cross-check / A-B timing).
+VARIANT = os.environ.get("CGVP_VARIANT", "mfma")
 # bench.py's roofline leg: when this is a list, every conv launch appends a
 # (start, end) pair of timing events recorded on the launch stream.
 KERNEL_EVENTS = None
@@ -128,8 +132,21 @@ def cached_csr(edge_index, num_nodes):
     return csr
 
 
+def prepare_image(params, layout, dims):
+    """Fragment image of the arena for the MFMA kernels (one small launch)."""
+    L = _lib.lib()
+    n = int(L.cgvp_lba_image_floats(C.byref(dims), C.byref(layout)))
+    if n < 0:
+        _lib.check(n, "cgvp_lba_image_floats")
+    image = torch.empty(n, dtype=torch.float32, device=params.device)
+    with torch.cuda.device(params.device):
+        _lib.check(L.cgvp_lba_prepare(C.byref(dims), C.byref(layout), _ptr(params), _ptr(image), _stream()),
+                   "cgvp_lba_prepare")
+    return image
+
+
 def lba_encoder_forward(params, layout, dims, num_convs, x_s, x_v, ntypes, e_s, e_v, etypes, csr,
-                        aggr_mean=False, return_stages=False):
+                        aggr_mean=False, return_stages=False, image=None):
     """VectorProteinGNN_LBAModel.forward (protein_gnn.py:361-388), eval mode,
     as 1 + 2*num_convs launches: node embed, then (conv, node update) per layer
     with the output head fused into the last node update."""
@@ -155,26 +172,30 @@ def lba_encoder_forward(params, layout, dims, num_convs, x_s, x_v, ntypes, e_s, 
     dh = torch.empty(N, ROW, dtype=torch.float32, device=dev)
     out = torch.empty(N, dims.out_s, dtype=torch.float32, device=dev)
     stages = {}
+    if VARIANT == "mfma" and image is None:
+        image = prepare_image(params, layout, dims)
+    elif VARIANT != "mfma":
+        image = None
     with torch.cuda.device(dev):
         st = _stream()
-        d, lay, P = C.byref(dims), C.byref(layout), _ptr(params)
-        _lib.check(L.cgvp_node_embed_fwd(d, lay, P, _ptr(x_s), _ptr(x_v), _ptr(nt), N, _ptr(h), st),
+        d, lay, P, I = C.byref(dims), C.byref(layout), _ptr(params), _ptr(image)
+        _lib.check(L.cgvp_node_embed_fwd(d, lay, P, I, _ptr(x_s), _ptr(x_v), _ptr(nt), N, _ptr(h), st),
                    "cgvp_node_embed_fwd")
         if return_stages:
             stages["node_embed"] = h.clone()
         for layer in range(num_convs):
             with _timed("conv_fwd"):
-                _lib.check(L.cgvp_conv_fwd(d, lay, P, layer, _ptr(h), _ptr(e_s), _ptr(e_v), _ptr(et),
+                _lib.check(L.cgvp_conv_fwd(d, lay, P, I, layer, _ptr(h), _ptr(e_s), _ptr(e_v), _ptr(et),
                                            _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst),
                                            N, E, 1 if aggr_mean else 0, _ptr(dh), st), "cgvp_conv_fwd")
             if return_stages:
                 stages[f"conv{layer}_dh"] = dh.clone()
             last = layer == num_convs - 1
             if return_stages and last:      # materialise the last hidden state as well
-                _lib.check(L.cgvp_node_update_fwd(d, lay, P, layer, _ptr(h), _ptr(dh), N, 0, _ptr(h2),
+                _lib.check(L.cgvp_node_update_fwd(d, lay, P, I, layer, _ptr(h), _ptr(dh), N, 0, _ptr(h2),
                                                   C.c_void_p(0), st), "cgvp_node_update_fwd")
                 stages[f"conv{layer}"] = h2.clone()
-            _lib.check(L.cgvp_node_update_fwd(d, lay, P, layer, _ptr(h), _ptr(dh), N, 1 if last else 0,
+            _lib.check(L.cgvp_node_update_fwd(d, lay, P, I, layer, _ptr(h), _ptr(dh), N, 1 if last else 0,
                                               _ptr(h2), _ptr(out), st), "cgvp_node_update_fwd")
             if not last:
                 if return_stages:

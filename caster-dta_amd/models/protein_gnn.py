@@ -142,6 +142,7 @@ class VectorProteinGNN_LBAModel(BaseProteinGNN):
                                      activations=(self.gvp_relu, None), vector_gate=True)
         self._arena = None
         self._hip_cfg = None
+        self._image = None          # (key, fragment image) for the MFMA kernels
 
     # ------------------------------------------------------------------ HIP path
     def _hip_config(self):
@@ -191,4 +192,15 @@ class VectorProteinGNN_LBAModel(BaseProteinGNN):
             return autograd_ops.lba_encoder(self, params, layout, dims, x_s, x_v, ntypes, e_s, e_v, etypes,
                                             csr, train_dropout)
         return ops.lba_encoder_forward(params, layout, dims, self.num_convs, x_s, x_v, ntypes, e_s, e_v,
-                                       etypes, csr, aggr_mean=(self.aggr == "mean"))
+                                       etypes, csr, aggr_mean=(self.aggr == "mean"),
+                                       image=self._fragment_image(params, layout, dims))
+
+    def _fragment_image(self, params, layout, dims):
+        """Fragment image of the current weights; rebuilt (one small launch) whenever
+        any parameter was written since the last build."""
+        if ops.VARIANT != "mfma":
+            return None
+        key = (params.data_ptr(), sum(p._version for p in self._arena.params))
+        if self._image is None or self._image[0] != key:
+            self._image = (key, ops.prepare_image(params, layout, dims))
+        return self._image[1]

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 1
+#define CGVP_ABI_VERSION 2
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
@@ -90,11 +90,27 @@ int cgvp_csr_from_coo(const int64_t* edge_index, int64_t num_nodes, int64_t num_
 int cgvp_lba_layout(const cgvp_dims* dims, int32_t num_ntypes, int32_t num_etypes,
                     int32_t num_convs, cgvp_layout* out);
 
+/* FRAGMENT IMAGE.  The MFMA kernels do not read the arena directly: a prep
+ * kernel re-lays every nn.Linear out as pre-permuted v_mfma_f32_16x16x4_f32
+ * A-operand fragments plus bias / LayerNorm / type-column tables, one slice per
+ * kernel (csrc/gvp_quad.h).  Rebuild it after every parameter update (one tiny
+ * launch); inference can keep it.  `cgvp_lba_image_floats` returns its length
+ * (<0 on error), `cgvp_lba_prepare` fills it on `stream`. */
+int64_t cgvp_lba_image_floats(const cgvp_dims* dims, const cgvp_layout* layout);
+int cgvp_lba_prepare(const cgvp_dims* dims, const cgvp_layout* layout, const float* params,
+                     float* image, void* stream);
+
+/* The three forward entry points below take BOTH the arena (`params`) and the
+ * fragment image (`image`).  image != NULL selects the MFMA kernels (16 items per
+ * wave tile, 4 lanes per item, the production path); image == NULL runs the
+ * scalar one-item-per-lane kernels straight from the arena (kept as an
+ * independent second implementation for cross-checks and A/B timing). */
+
 /* gvp_node = Sequential(GVP, LayerNorm) on one-hot(ntypes) ++ x_s, x_v
  * (protein_gnn.py:368-375).  x_s [N][17], x_v [N][3][3], ntypes [N] -> h [N][28]. */
 int cgvp_node_embed_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* params,
-                        const float* x_s, const float* x_v, const int64_t* ntypes,
-                        int64_t num_nodes, float* h, void* stream);
+                        const float* image, const float* x_s, const float* x_v,
+                        const int64_t* ntypes, int64_t num_nodes, float* h, void* stream);
 
 /* GVPConv.forward (gvp_layers.py:291-308) of conv layer `layer` for every edge
  * plus the reduction over target nodes (aggr 'sum'/'add' or 'mean'), with
@@ -104,18 +120,19 @@ int cgvp_node_embed_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
  * tables from cgvp_csr_from_coo.  -> dh [N][28] (every row written, zero for
  * isolated nodes). */
 int cgvp_conv_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* params,
-                  int32_t layer, const float* h, const float* e_s, const float* e_v,
-                  const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,
-                  const int32_t* esrc, const int32_t* edst, int64_t num_nodes, int64_t num_edges,
-                  int32_t aggr_mean, float* dh, void* stream);
+                  const float* image, int32_t layer, const float* h, const float* e_s,
+                  const float* e_v, const int64_t* etypes, const int32_t* rowptr,
+                  const int32_t* eperm, const int32_t* esrc, const int32_t* edst,
+                  int64_t num_nodes, int64_t num_edges, int32_t aggr_mean, float* dh, void* stream);
 
 /* Rest of GVPConvLayer.forward in eval mode (gvp_layers.py:407-410):
  * h_out = LN1(y + FF(y)), y = LN0(h + dh).  When `with_head` != 0 also applies
  * gvp_norm_before_scalar + gvp_to_scalar (protein_gnn.py:385-386) and writes
  * out [N][64]; h_out may then be NULL. */
 int cgvp_node_update_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* params,
-                         int32_t layer, const float* h, const float* dh, int64_t num_nodes,
-                         int32_t with_head, float* h_out, float* out, void* stream);
+                         const float* image, int32_t layer, const float* h, const float* dh,
+                         int64_t num_nodes, int32_t with_head, float* h_out, float* out,
+                         void* stream);
 
 /* One GINEConv + activation of HomoMoleculeGNN_GINE (molecule_gnn.py:254-268,
  * :271-280; PyG GINEConv / MLP restated):

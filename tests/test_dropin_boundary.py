@@ -100,7 +100,7 @@ def test_c_abi_exports_every_declared_symbol():
     handle = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(handle, name), name
-    assert _lib.lib().cgvp_abi_version() == 1
+    assert _lib.lib().cgvp_abi_version() == _lib.ABI_VERSION
 
 
 def test_standalone_module_compositions(gvp_units):

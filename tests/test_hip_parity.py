@@ -15,6 +15,16 @@ TOL = 2e-5
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True, params=["mfma", "simt"])
+def variant(request):
+    """Every test runs on both kernel families: the MFMA tile kernels (production)
+    and the independent one-item-per-lane kernels."""
+    old = ops.VARIANT
+    ops.VARIANT = request.param
+    yield request.param
+    ops.VARIANT = old
+
+
 def _csr_numpy(ei, n):
     dst = ei[1]
     order = np.argsort(dst, kind="stable")
