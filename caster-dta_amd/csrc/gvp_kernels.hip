@@ -68,12 +68,26 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int32_t* __restrict__ cn
   const int64_t chunk = (N + 1023) / 1024;
   const int64_t lo = t * chunk, hi = (lo + chunk < N) ? lo + chunk : N;
   if (in_lds) {
-    for (int64_t i = t; i < N; i += 1024) sbuf[i] = cnt[i];
+    // all global loads in flight at once (9 x int4 per thread covers SCAN_LDS), then LDS
+    constexpr int VPT = SCAN_LDS / 4096;
+    int4 v[VPT];
+    const int64_t n4 = N >> 2;
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+      const int64_t q = t + 1024 * k;
+      v[k] = q < n4 ? reinterpret_cast<const int4*>(cnt)[q] : make_int4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+      const int64_t q = t + 1024 * k;
+      if (q < n4) reinterpret_cast<int4*>(sbuf)[q] = v[k];
+    }
+    if (t < (N & 3)) sbuf[(n4 << 2) + t] = cnt[(n4 << 2) + t];
     __syncthreads();
   }
-  const int32_t* src = in_lds ? sbuf : cnt;
   int32_t sum = 0;
-  for (int64_t i = lo; i < hi; ++i) sum += src[i];
+  if (in_lds) { for (int64_t i = lo; i < hi; ++i) sum += sbuf[i]; }      // two loops: keeps LDS / global
+  else { for (int64_t i = lo; i < hi; ++i) sum += cnt[i]; }              // addressing explicit (no flat)
   part[t] = sum;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {

@@ -87,25 +87,59 @@ __device__ __forceinline__ f4 mfma(float a, float b, f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// acc += sum over this GEMM's k-steps of A-fragment(mt, s) x b[s].  Long chains
-// are split over two accumulators: a dependent f32 MFMA chain issues every 40
-// cycles, two independent ones every 32.
-template <class G>
-__device__ __forceinline__ f4 apply(const float* frag, int mt, const float (&b)[G::NSTEPS], f4 acc, int lane) {
+// acc[j] += sum over this GEMM's k-steps of A-fragment(mt, s) x b[j][s] for TN
+// tiles in lockstep: one LDS fragment read feeds TN independent MFMA chains.
+// With a single tile, long chains are split over two accumulators instead (a
+// dependent f32 MFMA chain issues every 40 cycles, independent ones every 32).
+template <class G, int TN>
+__device__ __forceinline__ void apply(const float* frag, int mt, const float (&b)[TN][G::NSTEPS], f4 (&acc)[TN], int lane) {
   const float* f = frag + mt * G::NSTEPS * 64 + lane;
-  if (G::NSTEPS >= 8) {
+  if (TN == 1 && G::NSTEPS >= 8) {
     f4 acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s + 1 < G::NSTEPS; s += 2) {
-      acc = mfma(f[s * 64], b[s], acc);
-      acc2 = mfma(f[(s + 1) * 64], b[s + 1], acc2);
+      acc[0] = mfma(f[s * 64], b[0][s], acc[0]);
+      acc2 = mfma(f[(s + 1) * 64], b[0][s + 1], acc2);
     }
-    if (G::NSTEPS & 1) acc = mfma(f[(G::NSTEPS - 1) * 64], b[G::NSTEPS - 1], acc);
-    return acc + acc2;
+    if (G::NSTEPS & 1) acc[0] = mfma(f[(G::NSTEPS - 1) * 64], b[0][G::NSTEPS - 1], acc[0]);
+    acc[0] += acc2;
+    return;
   }
 #pragma unroll
-  for (int s = 0; s < G::NSTEPS; ++s) acc = mfma(f[s * 64], b[s], acc);
-  return acc;
+  for (int s = 0; s < G::NSTEPS; ++s) {
+    const float a = f[s * 64];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[j] = mfma(a, b[j][s], acc[j]);
+  }
+}
+
+// Shift within the 16-lane row of a group g (= the 16 items of the tile):
+// lane i receives lane i-K's value, lanes i < K receive `fill`.
+template <int K>
+__device__ __forceinline__ int row_shr_i(int x, int fill) {
+  return __builtin_amdgcn_update_dpp(fill, x, 0x110 | K, 0xf, 0xf, false);
+}
+template <int K>
+__device__ __forceinline__ float row_shr_f(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x110 | K, 0xf, 0xf, false));
+}
+// One Hillis-Steele step of a segmented inclusive scan over the items of a tile;
+// `id` is the (sorted) segment key of each item.
+template <int K, int NVAL>
+__device__ __forceinline__ void seg_scan_step(int id, float (&x)[NVAL]) {
+  const bool same = row_shr_i<K>(id, -2) == id;
+#pragma unroll
+  for (int k = 0; k < NVAL; ++k) {
+    const float y = row_shr_f<K>(x[k]);
+    x[k] += same ? y : 0.f;
+  }
+}
+template <int NVAL>
+__device__ __forceinline__ void seg_scan16(int id, float (&x)[NVAL]) {
+  seg_scan_step<1, NVAL>(id, x);
+  seg_scan_step<2, NVAL>(id, x);
+  seg_scan_step<4, NVAL>(id, x);
+  seg_scan_step<8, NVAL>(id, x);
 }
 
 __device__ __forceinline__ float quad_sum(float x) {   // over the 4 lanes of an item
@@ -167,55 +201,92 @@ struct GvpQ {
     f4 vp[3];                    // wv.vh per plane before gating
     f4 sg;                       // sigmoid(gate) (P2 rows o)
   };
-  static __device__ __forceinline__ void forward(const float* img, int lane, int type,
-                                                 const float (&bs)[SSTEPS], const float (&bv)[3][VSTEPS],
-                                                 f4 (&so)[OT], float (&vo)[3][VOR], Cache& c) {
+  template <int TN>
+  static __device__ __forceinline__ void forward(const float* img, int lane, const int (&type)[TN],
+                                                 const float (&bs)[TN][SSTEPS], const float (&bv)[TN][3][VSTEPS],
+                                                 f4 (&so)[TN][OT], float (&vo)[TN][3][VOR], Cache (&c)[TN]) {
     const int g = lane >> 4;
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int p = 0; p < 3; ++p) c.vh[p] = apply<GWh>(img + F_WH * 64, 0, bv[p], zero, lane);
-    float bfull[SSTEPS + HR];
+    for (int p = 0; p < 3; ++p) {
+      float b[TN][VSTEPS];
+      f4 acc[TN];
 #pragma unroll
-    for (int s = 0; s < SSTEPS; ++s) bfull[s] = bs[s];
+      for (int j = 0; j < TN; ++j) {
+        acc[j] = zero;
 #pragma unroll
-    for (int r = 0; r < HR; ++r) {
-      const float n2 = c.vh[0][r] * c.vh[0][r] + c.vh[1][r] * c.vh[1][r] + c.vh[2][r] * c.vh[2][r];
-      c.vn[r] = gvp::f_sqrt(gvp::f_max(n2, gvp::kNormEps));
-      bfull[SSTEPS + r] = c.vn[r];
+        for (int s = 0; s < VSTEPS; ++s) b[j][s] = bv[j][p][s];
+      }
+      apply<GWh, TN>(img + F_WH * 64, 0, b, acc, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) c[j].vh[p] = acc[j];
     }
+    float bfull[TN][SSTEPS + HR];
 #pragma unroll
-    for (int t = 0; t < OT; ++t) {
-      f4 acc = *reinterpret_cast<const f4*>(img + V_BS + 16 * t + 4 * g);
-      if (NT > 0) acc += *reinterpret_cast<const f4*>(img + V_WT + type * SO + 16 * t + 4 * g);
-      c.sp[t] = apply<GWs>(img + F_WS * 64, t, bfull, acc, lane);
-    }
-    if (VO > 0) {
-      float bh[3][HR], bsp[4 * OT];
+    for (int j = 0; j < TN; ++j) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int s = 0; s < SSTEPS; ++s) bfull[j][s] = bs[j][s];
 #pragma unroll
-        for (int r = 0; r < HR; ++r) bh[p][r] = c.vh[p][r];
-#pragma unroll
-      for (int t = 0; t < OT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bsp[4 * t + r] = c.sp[t][r];
-      f4 gate;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) gate[r] = img[V_BSV + ((4 * r + g) & 15)];
-      gate = apply<GWsv>(img + F_WSV * 64, 0, bsp, gate, lane);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) c.sg[r] = gvp::f_sigmoid(gate[r]);
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        c.vp[p] = apply<GWv>(img + F_WV * 64, 0, bh[p], zero, lane);
-#pragma unroll
-        for (int r = 0; r < VOR; ++r) vo[p][r] = c.vp[p][r] * c.sg[r];
+      for (int r = 0; r < HR; ++r) {
+        const float n2 = c[j].vh[0][r] * c[j].vh[0][r] + c[j].vh[1][r] * c[j].vh[1][r] + c[j].vh[2][r] * c[j].vh[2][r];
+        c[j].vn[r] = gvp::f_sqrt(gvp::f_max(n2, gvp::kNormEps));
+        bfull[j][SSTEPS + r] = c[j].vn[r];
       }
     }
 #pragma unroll
-    for (int t = 0; t < OT; ++t)
+    for (int t = 0; t < OT; ++t) {
+      f4 acc[TN];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) so[t][r] = RELU ? gvp::f_max(c.sp[t][r], 0.f) : c.sp[t][r];
+      for (int j = 0; j < TN; ++j) {
+        acc[j] = *reinterpret_cast<const f4*>(img + V_BS + 16 * t + 4 * g);
+        if (NT > 0) acc[j] += *reinterpret_cast<const f4*>(img + V_WT + type[j] * SO + 16 * t + 4 * g);
+      }
+      apply<GWs, TN>(img + F_WS * 64, t, bfull, acc, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) c[j].sp[t] = acc[j];
+    }
+    if (VO > 0) {
+      float bsp[TN][4 * OT];
+      f4 gate[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int t = 0; t < OT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bsp[j][4 * t + r] = c[j].sp[t][r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gate[j][r] = img[V_BSV + ((4 * r + g) & 15)];
+      }
+      apply<GWsv, TN>(img + F_WSV * 64, 0, bsp, gate, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[j].sg[r] = gvp::f_sigmoid(gate[j][r]);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        float bh[TN][HR];
+        f4 acc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[j] = zero;
+#pragma unroll
+          for (int r = 0; r < HR; ++r) bh[j][r] = c[j].vh[p][r];
+        }
+        apply<GWv, TN>(img + F_WV * 64, 0, bh, acc, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          c[j].vp[p] = acc[j];
+#pragma unroll
+          for (int r = 0; r < VOR; ++r) vo[j][p][r] = acc[j][r] * c[j].sg[r];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) so[j][t][r] = RELU ? gvp::f_max(c[j].sp[t][r], 0.f) : c[j].sp[t][r];
   }
 };
 

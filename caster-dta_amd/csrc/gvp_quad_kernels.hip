@@ -18,16 +18,48 @@ using namespace gq;
 
 namespace {
 
+// Diagnostic build only (-DCGVP_STAMPS): per-wave s_memtime stamps into a debug
+// buffer that nothing else reads; the production library contains none of it.
+#ifdef CGVP_STAMPS
+__device__ unsigned long long* g_stamp_buf = nullptr;
+#define STAMP(slot)                                                                          \
+  do {                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    unsigned long long t_;                                                                   \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    if (g_stamp_buf && (threadIdx.x & 63) == 0)                                              \
+      g_stamp_buf[((size_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * 16 + (slot)] = t_;        \
+  } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
 constexpr int WAVE = 64;
 constexpr int WPB = 4;                 // waves per workgroup
 constexpr int TPB = WAVE * WPB;
 constexpr int TILE = 16;
 
-// Workgroup-cooperative copy of an image slice (multiple of 4 floats) into LDS.
-__device__ __forceinline__ void stage_slice(float* lds, const float* __restrict__ src, int nfloats, int tid) {
+// Workgroup-cooperative copy of an image slice (NFLOATS, multiple of 4) into LDS:
+// every global load is issued before the first LDS store, so the slice costs one
+// memory latency instead of one per iteration.
+template <int NFLOATS>
+__device__ __forceinline__ void stage_slice(float* lds, const float* __restrict__ src, int tid) {
+  static_assert(NFLOATS % 4 == 0, "image slices are whole float4s");
+  constexpr int NF4 = NFLOATS / 4, IT = (NF4 + TPB - 1) / TPB;
   const f4* s = reinterpret_cast<const f4*>(src);
   f4* d = reinterpret_cast<f4*>(lds);
-  for (int i = tid; i < nfloats / 4; i += TPB) d[i] = s[i];
+  f4 v[IT];
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int idx = tid + k * TPB;
+    if (idx < NF4) v[k] = s[idx];
+  }
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int idx = tid + k * TPB;
+    if (idx < NF4) d[idx] = v[k];
+  }
 }
 
 // ------------------------------------------------------------------ prepare
@@ -75,35 +107,35 @@ __global__ __launch_bounds__(TPB) void embed_quad_kernel(EmbedQArgs a) {
   typedef Image<NTN, 0> IM;
   typedef QNode<NTN> Q;
   __shared__ __attribute__((aligned(16))) float lds[IM::EMB_SIZE];
-  stage_slice(lds, a.img, IM::EMB_SIZE, threadIdx.x);
+  stage_slice<IM::EMB_SIZE>(lds, a.img, threadIdx.x);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int64_t n = ((int64_t)blockIdx.x * WPB + w) * TILE + i;
   const bool active = n < a.N;
-  float bs[Q::SSTEPS], bv[3][1];
-  int type = 0;
+  float bs[1][Q::SSTEPS], bv[1][3][1];
+  int type[1] = {0};
 #pragma unroll
   for (int s = 0; s < Q::SSTEPS; ++s) {
     const int c = 4 * s + g;
-    bs[s] = (active && c < NODE_IN_S) ? a.x_s[n * NODE_IN_S + c] : 0.f;
+    bs[0][s] = (active && c < NODE_IN_S) ? a.x_s[n * NODE_IN_S + c] : 0.f;
   }
 #pragma unroll
-  for (int p = 0; p < 3; ++p) bv[p][0] = (active && g < NODE_IN_V) ? a.x_v[n * 3 * NODE_IN_V + 3 * g + p] : 0.f;
+  for (int p = 0; p < 3; ++p) bv[0][p][0] = (active && g < NODE_IN_V) ? a.x_v[n * 3 * NODE_IN_V + 3 * g + p] : 0.f;
   if (NTN > 0 && active) {
-    type = (int)a.ntypes[n];
-    type = type < 0 ? 0 : (type >= NTN ? NTN - 1 : type);
+    type[0] = (int)a.ntypes[n];
+    type[0] = type[0] < 0 ? 0 : (type[0] >= NTN ? NTN - 1 : type[0]);
   }
-  f4 s[1];
-  float v[3][1];
-  typename Q::Cache c;
-  Q::forward(lds + IM::EMB_GVP, lane, type, bs, bv, s, v, c);
-  ln_quad<NS, NV>(lds + IM::EMB_LN, lane, s, v);
+  f4 s[1][1];
+  float v[1][3][1];
+  typename Q::Cache c[1];
+  Q::template forward<1>(lds + IM::EMB_GVP, lane, type, bs, bv, s, v, c);
+  ln_quad<NS, NV>(lds + IM::EMB_LN, lane, s[0], v[0]);
   if (active) {
     float* row = a.h + n * ROW;
-    *reinterpret_cast<f4*>(row + 4 * g) = s[0];
+    *reinterpret_cast<f4*>(row + 4 * g) = s[0][0];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) row[NS + 3 * g + p] = v[p][0];
+    for (int p = 0; p < 3; ++p) row[NS + 3 * g + p] = v[0][p][0];
   }
 }
 
@@ -115,138 +147,193 @@ struct ConvQArgs {
   int64_t N; int npw; int mean; float* dh;
 };
 
+constexpr int CTN = 2;                 // edge tiles processed in lockstep per pass (32 edges)
+
+// Per-lane inputs of CTN tiles of 16 sorted edges (lane = (edge i, group g)).
+struct ConvIn {
+  f4 es0[CTN], es1[CTN], sj[CTN], si[CTN];
+  float ev[CTN][3], vj[CTN][3], vi[CTN][3];
+  int et[CTN];
+  int32_t dst[CTN];
+  bool active[CTN];
+};
+
+// Gather the inputs of the pass starting at sorted-edge position `base`:
+// CSR tables -> raw edge features (original edge order) + source / target rows.
 template <int NTE>
-__device__ __forceinline__ void conv_tile(const float* img, const ConvQArgs& a, int32_t p, bool active, int lane,
-                                          f4& m_s, float (&m_v)[3]) {
-  typedef Image<0, NTE> IM;
-  const int g = lane >> 4;
+__device__ __forceinline__ void conv_gather(const ConvQArgs& a, int32_t base, int32_t e1, int lane, ConvIn& in) {
+  const int i = lane & 15, g = lane >> 4;
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
-  f4 es0 = zero, es1 = zero, sj = zero, si = zero;
-  float ev[3] = {0.f, 0.f, 0.f}, vj[3] = {0.f, 0.f, 0.f}, vi[3] = {0.f, 0.f, 0.f};
-  int et = 0;
-  if (active) {
-    const int32_t eid = a.eperm[p];
-    const float* er = a.e_s + (int64_t)eid * EDGE_IN_S;
-    es0 = *reinterpret_cast<const f4*>(er + 4 * g);
-    es1 = *reinterpret_cast<const f4*>(er + 16 + 4 * g);
-    if (g == 0) {
+  int32_t eid[CTN], src[CTN];
 #pragma unroll
-      for (int d = 0; d < 3; ++d) ev[d] = a.e_v[(int64_t)eid * 3 + d];
+  for (int j = 0; j < CTN; ++j) {                    // hop 1: all index loads in flight together
+    const int32_t p = base + j * TILE + i;
+    in.active[j] = p < e1;
+    in.dst[j] = in.active[j] ? a.edst[p] : -1;
+    eid[j] = in.active[j] ? a.eperm[p] : 0;
+    src[j] = in.active[j] ? a.esrc[p] : 0;
+  }
+#pragma unroll
+  for (int j = 0; j < CTN; ++j) {                    // hop 2: rows
+    in.es0[j] = in.es1[j] = in.sj[j] = in.si[j] = zero;
+    in.et[j] = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) in.ev[j][d] = in.vj[j][d] = in.vi[j][d] = 0.f;
+    if (in.active[j]) {
+      const float* er = a.e_s + (int64_t)eid[j] * EDGE_IN_S;
+      in.es0[j] = *reinterpret_cast<const f4*>(er + 4 * g);
+      in.es1[j] = *reinterpret_cast<const f4*>(er + 16 + 4 * g);
+      if (g == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) in.ev[j][d] = a.e_v[(int64_t)eid[j] * 3 + d];
+      }
+      if (NTE > 0) {
+        in.et[j] = (int)a.etypes[eid[j]];
+        in.et[j] = in.et[j] < 0 ? 0 : (in.et[j] >= NTE ? NTE - 1 : in.et[j]);
+      }
+      const float* hj = a.h + (int64_t)src[j] * ROW;
+      const float* hi = a.h + (int64_t)in.dst[j] * ROW;
+      in.sj[j] = *reinterpret_cast<const f4*>(hj + 4 * g);
+      in.si[j] = *reinterpret_cast<const f4*>(hi + 4 * g);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { in.vj[j][d] = hj[NS + 3 * g + d]; in.vi[j][d] = hi[NS + 3 * g + d]; }
     }
-    if (NTE > 0) {
-      et = (int)a.etypes[eid];
-      et = et < 0 ? 0 : (et >= NTE ? NTE - 1 : et);
-    }
-    const float* hj = a.h + (int64_t)a.esrc[p] * ROW;
-    const float* hi = a.h + (int64_t)a.edst[p] * ROW;
-    sj = *reinterpret_cast<const f4*>(hj + 4 * g);
-    si = *reinterpret_cast<const f4*>(hi + 4 * g);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { vj[d] = hj[NS + 3 * g + d]; vi[d] = hi[NS + 3 * g + d]; }
   }
-  // gvp_edge + LayerNorm, in registers (protein_gnn.py:376)
-  f4 e_s[2];
-  float e_v[3][1];
-  {
-    float bs[8], bv[3][1];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { bs[r] = es0[r]; bs[4 + r] = es1[r]; }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) bv[d][0] = ev[d];
-    typename QEdge<NTE>::Cache c;
-    QEdge<NTE>::forward(img + IM::CV_EDGE, lane, et, bs, bv, e_s, e_v, c);
-    ln_quad<ES, EV>(img + IM::CV_ELN, lane, e_s, e_v);
-  }
-  // message_func.0 on cat((s_j, V_j), edge, (s_i, V_i))   (gvp_layers.py:306)
-  f4 s1[1], s2[1];
-  float v1[3][1], v2[3][1];
-  {
-    float bs[16], bv[3][3];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { bs[r] = sj[r]; bs[4 + r] = e_s[0][r]; bs[8 + r] = e_s[1][r]; bs[12 + r] = si[r]; }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { bv[d][0] = vj[d]; bv[d][1] = vi[d]; bv[d][2] = e_v[d][0]; }
-    QMsg0::Cache c;
-    QMsg0::forward(img + IM::CV_M0, lane, 0, bs, bv, s1, v1, c);
-  }
-  {
-    float bs[4], bv[3][1];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bs[r] = s1[0][r];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) bv[d][0] = v1[d][0];
-    QMsg1::Cache c;
-    QMsg1::forward(img + IM::CV_M1, lane, 0, bs, bv, s2, v2, c);
-  }
-  {
-    float bs[4], bv[3][1];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bs[r] = s2[0][r];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) bv[d][0] = v2[d][0];
-    QMsg2::Cache c;
-    QMsg2::forward(img + IM::CV_M2, lane, 0, bs, bv, s1, v1, c);
-  }
-  m_s = s1[0];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) m_v[d] = v1[d][0];
 }
 
+// Message of CTN tiles: raw edge features -> gvp_edge + LayerNorm (in registers)
+// -> cat with source / target node rows -> 3 message GVPs.
+template <int NTE>
+__device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, int lane,
+                                           f4 (&m_s)[CTN], float (&m_v)[CTN][3]) {
+  typedef Image<0, NTE> IM;
+  const f4 (&es0)[CTN] = in.es0; const f4 (&es1)[CTN] = in.es1; const f4 (&sj)[CTN] = in.sj; const f4 (&si)[CTN] = in.si;
+  const float (&ev)[CTN][3] = in.ev; const float (&vj)[CTN][3] = in.vj; const float (&vi)[CTN][3] = in.vi;
+  const int (&et)[CTN] = in.et;
+  const int zero_t[CTN] = {};
+  // gvp_edge + LayerNorm, in registers (protein_gnn.py:376)
+  f4 e_s[CTN][2];
+  float e_v[CTN][3][1];
+  {
+    float bs[CTN][8], bv[CTN][3][1];
+#pragma unroll
+    for (int j = 0; j < CTN; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { bs[j][r] = es0[j][r]; bs[j][4 + r] = es1[j][r]; }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) bv[j][d][0] = ev[j][d];
+    }
+    typename QEdge<NTE>::Cache c[CTN];
+    QEdge<NTE>::template forward<CTN>(img + IM::CV_EDGE, lane, et, bs, bv, e_s, e_v, c);
+#pragma unroll
+    for (int j = 0; j < CTN; ++j) ln_quad<ES, EV>(img + IM::CV_ELN, lane, e_s[j], e_v[j]);
+  }
+  STAMP(5);
+  // message_func.0 on cat((s_j, V_j), edge, (s_i, V_i))   (gvp_layers.py:306)
+  f4 s1[CTN][1], s2[CTN][1];
+  float v1[CTN][3][1], v2[CTN][3][1];
+  {
+    float bs[CTN][16], bv[CTN][3][3];
+#pragma unroll
+    for (int j = 0; j < CTN; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        bs[j][r] = sj[j][r]; bs[j][4 + r] = e_s[j][0][r]; bs[j][8 + r] = e_s[j][1][r]; bs[j][12 + r] = si[j][r];
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { bv[j][d][0] = vj[j][d]; bv[j][d][1] = vi[j][d]; bv[j][d][2] = e_v[j][d][0]; }
+    }
+    QMsg0::Cache c[CTN];
+    QMsg0::forward<CTN>(img + IM::CV_M0, lane, zero_t, bs, bv, s1, v1, c);
+  }
+  {
+    float bs[CTN][4], bv[CTN][3][1];
+#pragma unroll
+    for (int j = 0; j < CTN; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bs[j][r] = s1[j][0][r];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) bv[j][d][0] = v1[j][d][0];
+    }
+    QMsg1::Cache c[CTN];
+    QMsg1::forward<CTN>(img + IM::CV_M1, lane, zero_t, bs, bv, s2, v2, c);
+  }
+  {
+    float bs[CTN][4], bv[CTN][3][1];
+#pragma unroll
+    for (int j = 0; j < CTN; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bs[j][r] = s2[j][0][r];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) bv[j][d][0] = v2[j][d][0];
+    }
+    QMsg2::Cache c[CTN];
+    QMsg2::forward<CTN>(img + IM::CV_M2, lane, zero_t, bs, bv, s1, v1, c);
+  }
+#pragma unroll
+  for (int j = 0; j < CTN; ++j) {
+    m_s[j] = s1[j][0];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) m_v[j][d] = v1[j][d][0];
+  }
+}
+
+// Waves are independent after the image is staged: each owns `npw` consecutive
+// target nodes, walks their dst-sorted edges 32 at a time, reduces every tile
+// with an in-register segmented scan across the 16 edge lanes (DPP row shifts;
+// no LDS traffic, no barrier) and lets the last lane of each segment add the
+// segment total into the wave's private LDS accumulator.  Ownership makes the
+// result independent of scheduling: no atomics on HBM, bitwise reproducible.
 template <int NTE>
 __global__ __launch_bounds__(TPB) void conv_quad_kernel(ConvQArgs a) {
   typedef Image<0, NTE> IM;
-  constexpr int MSG = TILE * ROW, ACC = WAVE * ROW;
+  constexpr int ACC = WAVE * ROW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* img = lds;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float* msg = lds + IM::CV_SIZE + w * (MSG + ACC + TILE);
-  float* acc = msg + MSG;
-  int* dloc = reinterpret_cast<int*>(acc + ACC);
-  int* s_tiles = reinterpret_cast<int*>(lds + IM::CV_SIZE + WPB * (MSG + ACC + TILE));   // one dynamic LDS object only
-  stage_slice(img, a.img, IM::CV_SIZE, threadIdx.x);
-
-  // this wave's target nodes [n0, n0 + nn) and their (sorted) edges [e0, e1)
+  float* acc = lds + IM::CV_SIZE + w * ACC;
+  STAMP(0);
   const int64_t n0 = ((int64_t)blockIdx.x * WPB + w) * a.npw;
   const int nn = n0 < a.N ? (int)((a.N - n0 < a.npw) ? (a.N - n0) : a.npw) : 0;
   const int32_t e0 = nn > 0 ? a.rowptr[n0] : 0, e1 = nn > 0 ? a.rowptr[n0 + nn] : 0;
-  const int ntiles = (e1 - e0 + TILE - 1) / TILE;
-  if (lane == 0) s_tiles[w] = ntiles;
-  for (int i = lane; i < nn * ROW; i += WAVE) acc[i] = 0.f;
-  __syncthreads();
-  int max_tiles = 0;
-#pragma unroll
-  for (int k = 0; k < WPB; ++k) max_tiles = s_tiles[k] > max_tiles ? s_tiles[k] : max_tiles;
+  // The first pass's gathers (3 dependent hops) are issued BEFORE the image is
+  // staged so that their latency hides behind the staging traffic and barrier.
+  ConvIn in;
+  conv_gather<NTE>(a, e0, e1, lane, in);
+  stage_slice<IM::CV_SIZE>(img, a.img, threadIdx.x);
+  for (int k = lane; k < nn * ROW; k += WAVE) acc[k] = 0.f;
+  STAMP(1);
+  __syncthreads();                                  // image staged, accumulators cleared
+  STAMP(2);
 
   const int i = lane & 15, g = lane >> 4;
-  for (int t = 0; t < max_tiles; ++t) {
-    const bool live = t < ntiles;                 // wave-uniform
-    const int32_t p = e0 + t * TILE + i;
-    const bool active = live && p < e1;
-    f4 m_s = {0.f, 0.f, 0.f, 0.f};
-    float m_v[3] = {0.f, 0.f, 0.f};
-    if (live) conv_tile<NTE>(img, a, p, active, lane, m_s, m_v);
-    __syncthreads();                              // previous tile's reduction has drained msg[]
-    if (live) {
-      *reinterpret_cast<f4*>(msg + i * ROW + 4 * g) = m_s;
+  for (int32_t base = e0; base < e1; base += CTN * TILE) {
+    if (base != e0) conv_gather<NTE>(a, base, e1, lane, in);
+    const int32_t (&dst)[CTN] = in.dst;
+    const bool (&active)[CTN] = in.active;
+    f4 m_s[CTN];
+    float m_v[CTN][3];
+    STAMP(3);
+    conv_tiles<NTE>(img, in, lane, m_s, m_v);
+    STAMP(6);
 #pragma unroll
-      for (int d = 0; d < 3; ++d) msg[i * ROW + NS + 3 * g + d] = m_v[d];
-      if (g == 0) dloc[i] = active ? (a.edst[p] - (int)n0) : -1;
-    }
-    __syncthreads();
-    // segmented sum over the sorted targets: lane c < 28 owns channel c of this wave's rows
-    if (live && lane < ROW) {
-      const int cnt = (e1 - (e0 + t * TILE) < TILE) ? (e1 - (e0 + t * TILE)) : TILE;
-      int cur = dloc[0];
-      float run = 0.f;
-      for (int r = 0; r < cnt; ++r) {
-        const int d = dloc[r];
-        if (d != cur) { acc[cur * ROW + lane] += run; run = 0.f; cur = d; }
-        run += msg[r * ROW + lane];
+    for (int j = 0; j < CTN; ++j) {
+      float x[7] = {m_s[j][0], m_s[j][1], m_s[j][2], m_s[j][3], m_v[j][0], m_v[j][1], m_v[j][2]};
+      seg_scan16<7>(dst[j], x);
+      // lane i closes a segment when its right neighbour has another target (or is past the end)
+      const int nxt = __builtin_amdgcn_update_dpp(-1, dst[j], 0x100 | 1 /* row_shl:1 */, 0xf, 0xf, false);
+      if (active[j] && (i == TILE - 1 || nxt != dst[j])) {
+        float* row = acc + (dst[j] - (int)n0) * ROW;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(row + 4 * g + r, x[r]);     // ds_add_f32, wave-private rows
+#pragma unroll
+        for (int d = 0; d < 3; ++d) atomicAdd(row + NS + 3 * g + d, x[4 + d]);
       }
-      acc[cur * ROW + lane] += run;
     }
   }
+  STAMP(7);
   __syncthreads();
+  STAMP(8);
   if (nn > 0) {
     float* out = a.dh + n0 * ROW;
     for (int k = lane; k < nn * ROW; k += WAVE) {
@@ -259,6 +346,7 @@ __global__ __launch_bounds__(TPB) void conv_quad_kernel(ConvQArgs a) {
       out[k] = v;
     }
   }
+  STAMP(9);
 }
 
 // ------------------------------------------------------------------ node update
@@ -271,49 +359,50 @@ template <bool HEAD>
 __global__ __launch_bounds__(TPB) void node_quad_kernel(NodeQArgs a) {
   typedef Image<0, 0> IM;
   __shared__ __attribute__((aligned(16))) float lds[IM::ND_SIZE + (HEAD ? IM::HD_SIZE : 0)];
-  stage_slice(lds, a.img_node, IM::ND_SIZE, threadIdx.x);
-  if (HEAD) stage_slice(lds + IM::ND_SIZE, a.img_head, IM::HD_SIZE, threadIdx.x);
-  __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int64_t n = ((int64_t)blockIdx.x * WPB + w) * TILE + i;
   const bool active = n < a.N;
   f4 s[1] = {{0.f, 0.f, 0.f, 0.f}};
   float v[3][1] = {{0.f}, {0.f}, {0.f}};
-  if (active) {
+  if (active) {                                  // row loads fly while the image is staged
     const float* hr = a.h + n * ROW;
     const float* dr = a.dh + n * ROW;
     s[0] = *reinterpret_cast<const f4*>(hr + 4 * g) + *reinterpret_cast<const f4*>(dr + 4 * g);
 #pragma unroll
     for (int p = 0; p < 3; ++p) v[p][0] = hr[NS + 3 * g + p] + dr[NS + 3 * g + p];
   }
+  stage_slice<IM::ND_SIZE>(lds, a.img_node, threadIdx.x);
+  if (HEAD) stage_slice<IM::HD_SIZE>(lds + IM::ND_SIZE, a.img_head, threadIdx.x);
+  __syncthreads();
+  const int zt[1] = {0};
   ln_quad<NS, NV>(lds + IM::ND_LN0, lane, s, v);
   {
-    f4 hs[4], s2[1];
-    float hv[3][2], v2[3][1];
+    f4 hs[1][4], s2[1][1];
+    float hv[1][3][2], v2[1][3][1];
     {
-      float bs[4], bv[3][1];
+      float bs[1][4], bv[1][3][1];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bs[r] = s[0][r];
+      for (int r = 0; r < 4; ++r) bs[0][r] = s[0][r];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bv[p][0] = v[p][0];
-      QFf0::Cache c;
-      QFf0::forward(lds + IM::ND_FF0, lane, 0, bs, bv, hs, hv, c);
+      for (int p = 0; p < 3; ++p) bv[0][p][0] = v[p][0];
+      QFf0::Cache c[1];
+      QFf0::forward<1>(lds + IM::ND_FF0, lane, zt, bs, bv, hs, hv, c);
     }
     {
-      float bs[16], bv[3][2];
+      float bs[1][16], bv[1][3][2];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bs[4 * t + r] = hs[t][r];
+        for (int r = 0; r < 4; ++r) bs[0][4 * t + r] = hs[0][t][r];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) { bv[p][0] = hv[p][0]; bv[p][1] = hv[p][1]; }
-      QFf1::Cache c;
-      QFf1::forward(lds + IM::ND_FF1, lane, 0, bs, bv, s2, v2, c);
+      for (int p = 0; p < 3; ++p) { bv[0][p][0] = hv[0][p][0]; bv[0][p][1] = hv[0][p][1]; }
+      QFf1::Cache c[1];
+      QFf1::forward<1>(lds + IM::ND_FF1, lane, zt, bs, bv, s2, v2, c);
     }
-    s[0] += s2[0];
+    s[0] += s2[0][0];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) v[p][0] += v2[p][0];
+    for (int p = 0; p < 3; ++p) v[p][0] += v2[0][p][0];
   }
   ln_quad<NS, NV>(lds + IM::ND_LN1, lane, s, v);
   if (!HEAD) {
@@ -327,18 +416,18 @@ __global__ __launch_bounds__(TPB) void node_quad_kernel(NodeQArgs a) {
   }
   const float* hd = lds + IM::ND_SIZE;
   ln_quad<NS, NV>(hd + IM::HD_LN, lane, s, v);
-  float bs[4], bv[3][1], dummy[3][1];
+  float bs[1][4], bv[1][3][1], dummy[1][3][1];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) bs[r] = s[0][r];
+  for (int r = 0; r < 4; ++r) bs[0][r] = s[0][r];
 #pragma unroll
-  for (int p = 0; p < 3; ++p) bv[p][0] = v[p][0];
-  f4 o[4];
-  QHead::Cache c;
-  QHead::forward(hd + IM::HD_GVP, lane, 0, bs, bv, o, dummy, c);
+  for (int p = 0; p < 3; ++p) bv[0][p][0] = v[p][0];
+  f4 o[1][4];
+  QHead::Cache c[1];
+  QHead::forward<1>(hd + IM::HD_GVP, lane, zt, bs, bv, o, dummy, c);
   if (active) {
     float* row = a.out + n * OUT;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) *reinterpret_cast<f4*>(row + 16 * t + 4 * g) = o[t];
+    for (int t = 0; t < 4; ++t) *reinterpret_cast<f4*>(row + 16 * t + 4 * g) = o[0][t];
   }
 }
 
@@ -368,6 +457,12 @@ void offsets_impl(int num_convs, QuadOffsets* o) {
 }  // namespace
 
 namespace quad {
+
+#ifdef CGVP_STAMPS
+extern "C" int cgvp_debug_set_stamp_buffer(unsigned long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf));
+}
+#endif
 
 int offsets(int nt_node, int nt_edge, int num_convs, QuadOffsets* o) {
 #define CALL(A, B) offsets_impl<A, B>(num_convs, o)
@@ -399,20 +494,20 @@ int node_embed(int nt_node, const float* img, const float* x_s, const float* x_v
 int conv(int nt_edge, const float* img, const float* h, const float* e_s, const float* e_v,
          const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
          const int32_t* edst, int64_t N, int64_t E, int mean, float* dh, hipStream_t st) {
-  // target nodes per wave: fill whole 16-edge MFMA tiles, ~48 edges per wave
+  // target nodes per wave: one pass of CTN lockstep 16-edge tiles (~30 edges) per wave
   int64_t deg = N > 0 ? (E + N - 1) / N : 1;
   if (deg < 1) deg = 1;
-  int npw = (int)(48 / deg);
+  int npw = (int)((CTN * TILE - 2) / deg);
   npw = npw < 1 ? 1 : (npw > WAVE ? WAVE : npw);
   ConvQArgs a{img, h, e_s, e_v, etypes, rowptr, eperm, esrc, edst, N, npw, mean, dh};
   const int64_t groups = (N + npw - 1) / npw;
   const dim3 grid((unsigned)((groups + WPB - 1) / WPB));
-  const size_t per_wave = (size_t)(TILE * ROW + WAVE * ROW + TILE) * sizeof(float);
+  const size_t per_wave = (size_t)(WAVE * ROW) * sizeof(float);
   if (nt_edge == 0) {
-    const size_t lds = Image<0, 0>::CV_SIZE * sizeof(float) + WPB * per_wave + WPB * sizeof(int);
+    const size_t lds = Image<0, 0>::CV_SIZE * sizeof(float) + WPB * per_wave;
     hipLaunchKernelGGL(conv_quad_kernel<0>, grid, dim3(TPB), lds, st, a);
   } else if (nt_edge == 1) {
-    const size_t lds = Image<0, 1>::CV_SIZE * sizeof(float) + WPB * per_wave + WPB * sizeof(int);
+    const size_t lds = Image<0, 1>::CV_SIZE * sizeof(float) + WPB * per_wave;
     hipLaunchKernelGGL(conv_quad_kernel<1>, grid, dim3(TPB), lds, st, a);
   } else {
     return CGVP_ERR_UNSUPPORTED_DIMS;
