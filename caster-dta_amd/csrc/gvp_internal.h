@@ -9,7 +9,10 @@
 // Float offsets of the per-kernel slices inside the fragment image.
 struct QuadOffsets {
   int emb, conv0, node0, layer_stride, head, total;
+  int embT, convT0, nodeT0, layerT_stride, headT;     // transposed slices (backward)
 };
+
+constexpr int kBwdMaxGrid = 256;   // persistent workgroups of the backward kernels = slab rows
 
 namespace quad {
 int offsets(int nt_node, int nt_edge, int num_convs, QuadOffsets* o);
@@ -20,5 +23,22 @@ int conv(int nt_edge, const float* img, const float* h, const float* e_s, const 
          const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
          const int32_t* edst, int64_t N, int64_t E, int mean, float* dh, hipStream_t st);
 int node_update(const float* img_node, const float* img_head, const float* h, const float* dh, int64_t N,
-                int with_head, float* h_out, float* out, hipStream_t st);
+                int with_head, float* h_out, float* out, const float* mask0, const float* mask1, hipStream_t st);
+
+// ---- backward (gvp_quad_bwd_kernels.hip).  Weight gradients are written as one
+// partial block per workgroup into `slab` ([grid][block floats]); `grid` returns
+// the number of rows to reduce.
+int node_update_bwd(const float* img_node, const float* img_head, const float* imgT_node, const float* imgT_head,
+                    const float* h, const float* dh, const float* mask0, const float* mask1, const float* g_out,
+                    const float* g_up0, const float* g_up1, const float* g_up2, int64_t N, int with_head,
+                    float* g_dh, float* g_h, float* slab, int* grid, hipStream_t st);
+int conv_bwd(int nt_edge, const float* img, const float* imgT, const float* h, const float* e_s, const float* e_v,
+             const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
+             const int32_t* edst, int64_t N, int64_t E, int mean, const float* g_dh, float* g_src, float* g_dst,
+             float* slab, int* grid, hipStream_t st);
+int node_embed_bwd(int nt_node, const float* img, const float* imgT, const float* x_s, const float* x_v,
+                   const int64_t* ntypes, int64_t N, const float* g_up0, const float* g_up1, const float* g_up2,
+                   float* g_x_s, float* g_x_v, float* slab, int* grid, hipStream_t st);
+int reduce_slab(const float* slab, int rows, int stride, int col0, int len, float* dst, hipStream_t st);
+int bwd_block_sizes(int nt_node, int nt_edge, int* emb, int* conv_edge, int* conv_total, int* node, int* head);
 }  // namespace quad

@@ -541,13 +541,120 @@ int cgvp_node_update_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const
     QuadOffsets o;
     if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
     if (int rc = quad::node_update(image + o.node0 + layer * o.layer_stride, image + o.head, h, dh, N,
-                                   with_head ? 1 : 0, h_out, out, (hipStream_t)stream)) return rc;
+                                   with_head ? 1 : 0, h_out, out, nullptr, nullptr, (hipStream_t)stream)) return rc;
     return launch_status();
   }
   NodeUpdateArgs a{params, cvt(*layout), layer, h, dh, N, h_out, out};
   dim3 grid((unsigned)((N + WAVE - 1) / WAVE));
   if (with_head) hipLaunchKernelGGL(node_update_kernel<true>, grid, dim3(WAVE), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(node_update_kernel<false>, grid, dim3(WAVE), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+int cgvp_node_update_fwd_train(const cgvp_dims* dims, const cgvp_layout* layout, const float* image,
+                               int32_t layer, const float* h, const float* dh, const float* mask0,
+                               const float* mask1, int64_t N, int32_t with_head, float* h_out, float* out,
+                               void* stream) {
+  if (int rc = check_dims(dims)) return rc;
+  if (N < 0 || !layout || !image) return CGVP_ERR_BAD_ARG;
+  if (layer < 0 || layer >= num_convs_of(*layout)) return CGVP_ERR_BAD_ARG;
+  if (N == 0) return 0;
+  if (!h || !dh || (with_head ? !out : !h_out)) return CGVP_ERR_BAD_ARG;
+  if (((uintptr_t)h & 15) || ((uintptr_t)dh & 15) || ((uintptr_t)h_out & 15) || ((uintptr_t)out & 15) ||
+      ((uintptr_t)mask0 & 15) || ((uintptr_t)mask1 & 15)) return CGVP_ERR_BAD_ARG;
+  QuadOffsets o;
+  if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
+  if (int rc = quad::node_update(image + o.node0 + layer * o.layer_stride, image + o.head, h, dh, N,
+                                 with_head ? 1 : 0, h_out, out, mask0, mask1, (hipStream_t)stream)) return rc;
+  return launch_status();
+}
+
+int64_t cgvp_bwd_workspace_floats(const cgvp_dims* dims, const cgvp_layout* layout) {
+  if (int rc = check_dims(dims)) return rc;
+  if (!layout) return CGVP_ERR_BAD_ARG;
+  int emb, ce, ct, nd, hd;
+  if (int rc = quad::bwd_block_sizes(layout->nt_node, layout->nt_edge, &emb, &ce, &ct, &nd, &hd)) return rc;
+  int mx = emb > ct ? emb : ct;
+  mx = mx > hd ? mx : hd;
+  return (int64_t)kBwdMaxGrid * mx;
+}
+
+int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image, int32_t layer,
+                         const float* h, const float* dh, const float* mask0, const float* mask1,
+                         const float* g_out, const float* g_up0, const float* g_up1, const float* g_up2,
+                         int64_t N, int32_t with_head, float* g_dh, float* g_h, float* grad_params,
+                         float* workspace, void* stream) {
+  if (int rc = check_dims(dims)) return rc;
+  if (N < 0 || !layout || !image || !grad_params || !workspace) return CGVP_ERR_BAD_ARG;
+  const int nc = num_convs_of(*layout);
+  if (layer < 0 || layer >= nc) return CGVP_ERR_BAD_ARG;
+  if (N == 0) return 0;
+  if (!h || !dh || !g_dh || (with_head && !g_out)) return CGVP_ERR_BAD_ARG;
+  const void* al[] = {h, dh, mask0, mask1, g_out, g_up0, g_up1, g_up2, g_dh, g_h};
+  for (const void* q : al) if ((uintptr_t)q & 15) return CGVP_ERR_BAD_ARG;
+  QuadOffsets o;
+  if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, nc, &o)) return rc;
+  int emb, ce, ct, nd, hd, grid = 0;
+  if (int rc = quad::bwd_block_sizes(layout->nt_node, layout->nt_edge, &emb, &ce, &ct, &nd, &hd)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = quad::node_update_bwd(image + o.node0 + layer * o.layer_stride, image + o.head,
+                                     image + o.nodeT0 + layer * o.layerT_stride, image + o.headT, h, dh, mask0,
+                                     mask1, g_out, g_up0, g_up1, g_up2, N, with_head ? 1 : 0, g_dh, g_h,
+                                     workspace, &grid, st)) return rc;
+  const int stride = with_head ? hd : nd;
+  const int node_len = conv_ff1() + LFf1::size(0) - conv_ln0();          // norm.0 .. end of ff_func.1
+  quad::reduce_slab(workspace, grid, stride, 0, node_len, grad_params + layout->conv0 + layer * layout->conv_stride + conv_ln0(), st);
+  if (with_head) quad::reduce_slab(workspace, grid, stride, node_len, layout->total - layout->ln_out, grad_params + layout->ln_out, st);
+  return launch_status();
+}
+
+int cgvp_conv_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image, int32_t layer,
+                  const float* h, const float* e_s, const float* e_v, const int64_t* etypes,
+                  const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc, const int32_t* edst,
+                  int64_t N, int64_t E, int32_t aggr_mean, const float* g_dh, float* g_src, float* g_dst,
+                  float* grad_params, float* workspace, void* stream) {
+  if (int rc = check_dims(dims)) return rc;
+  if (N < 0 || E < 0 || !layout || !image || !grad_params || !workspace) return CGVP_ERR_BAD_ARG;
+  const int nc = num_convs_of(*layout);
+  if (layer < 0 || layer >= nc) return CGVP_ERR_BAD_ARG;
+  if (N == 0) return 0;
+  if (!h || !g_dh || !g_src || !g_dst || !rowptr) return CGVP_ERR_BAD_ARG;
+  if (E > 0 && (!e_s || !e_v || !eperm || !esrc || !edst || (layout->nt_edge > 0 && !etypes))) return CGVP_ERR_BAD_ARG;
+  const void* al[] = {h, e_s, g_dh, g_src, g_dst};
+  for (const void* q : al) if ((uintptr_t)q & 15) return CGVP_ERR_BAD_ARG;
+  QuadOffsets o;
+  if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, nc, &o)) return rc;
+  int emb, ce, ct, nd, hd, grid = 0;
+  if (int rc = quad::bwd_block_sizes(layout->nt_node, layout->nt_edge, &emb, &ce, &ct, &nd, &hd)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t err = hipMemsetAsync(g_src, 0, (size_t)N * ROW * sizeof(float), st);
+  if (err != hipSuccess) return (int)err;
+  if (int rc = quad::conv_bwd(layout->nt_edge, image + o.conv0 + layer * o.layer_stride,
+                              image + o.convT0 + layer * o.layerT_stride, h, e_s, e_v, etypes, rowptr, eperm, esrc,
+                              edst, N, E, aggr_mean ? 1 : 0, g_dh, g_src, g_dst, workspace, &grid, st)) return rc;
+  quad::reduce_slab(workspace, grid, ct, 0, layout->conv0 - layout->edge_gvp, grad_params + layout->edge_gvp, st);
+  quad::reduce_slab(workspace, grid, ct, ce, conv_ln0(), grad_params + layout->conv0 + layer * layout->conv_stride, st);
+  return launch_status();
+}
+
+int cgvp_node_embed_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image, const float* x_s,
+                        const float* x_v, const int64_t* ntypes, int64_t N, const float* g_up0,
+                        const float* g_up1, const float* g_up2, float* g_x_s, float* g_x_v, float* grad_params,
+                        float* workspace, void* stream) {
+  if (int rc = check_dims(dims)) return rc;
+  if (N < 0 || !layout || !image || !grad_params || !workspace) return CGVP_ERR_BAD_ARG;
+  if (N == 0) return 0;
+  if (!x_s || !x_v || (layout->nt_node > 0 && !ntypes) || ((g_x_s == nullptr) != (g_x_v == nullptr))) return CGVP_ERR_BAD_ARG;
+  const void* al[] = {g_up0, g_up1, g_up2};
+  for (const void* q : al) if ((uintptr_t)q & 15) return CGVP_ERR_BAD_ARG;
+  QuadOffsets o;
+  if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
+  int emb, ce, ct, nd, hd, grid = 0;
+  if (int rc = quad::bwd_block_sizes(layout->nt_node, layout->nt_edge, &emb, &ce, &ct, &nd, &hd)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = quad::node_embed_bwd(layout->nt_node, image + o.emb, image + o.embT, x_s, x_v, ntypes, N, g_up0, g_up1,
+                                    g_up2, g_x_s, g_x_v, workspace, &grid, st)) return rc;
+  quad::reduce_slab(workspace, grid, emb, 0, layout->edge_gvp - layout->node_gvp, grad_params + layout->node_gvp, st);
   return launch_status();
 }
 

@@ -49,17 +49,17 @@ GVP_HD wptr cw(const float* p) { return (wptr)p; }
 // ws has nt one-hot type columns FIRST, then SI scalar features, then H norms.
 template <int SI, int VI, int SO, int VO, int H>
 struct GvpLayout {
-  static GVP_HD int ws(int) { return H * VI; }
-  static GVP_HD int bs(int nt) { return H * VI + SO * (nt + SI + H); }
-  static GVP_HD int wv(int nt) { return bs(nt) + SO; }
-  static GVP_HD int wsv(int nt) { return wv(nt) + VO * H; }
-  static GVP_HD int bsv(int nt) { return wsv(nt) + VO * SO; }
-  static GVP_HD int size(int nt) { return bsv(nt) + VO; }
+  static constexpr int ws(int) { return H * VI; }
+  static constexpr int bs(int nt) { return H * VI + SO * (nt + SI + H); }
+  static constexpr int wv(int nt) { return bs(nt) + SO; }
+  static constexpr int wsv(int nt) { return wv(nt) + VO * H; }
+  static constexpr int bsv(int nt) { return wsv(nt) + VO * SO; }
+  static constexpr int size(int nt) { return bsv(nt) + VO; }
 };
 // One tuple-LayerNorm block: scalar_norm.weight [S] | scalar_norm.bias [S].
 template <int S>
 struct LnLayout {
-  static GVP_HD int size() { return 2 * S; }
+  static constexpr int size() { return 2 * S; }
 };
 
 GVP_HD float f_exp(float x) {
@@ -249,12 +249,12 @@ GVP_HD EncLayout make_layout(int nt_node, int nt_edge, int num_convs) {
 }
 // Offsets inside one conv layer block.
 constexpr int CONV_M0 = 0;
-GVP_HD int conv_m1() { return LMsg0::size(0); }
-GVP_HD int conv_m2() { return conv_m1() + LMsg::size(0); }
-GVP_HD int conv_ln0() { return conv_m2() + LMsg::size(0); }
-GVP_HD int conv_ln1() { return conv_ln0() + LnLayout<NS>::size(); }
-GVP_HD int conv_ff0() { return conv_ln1() + LnLayout<NS>::size(); }
-GVP_HD int conv_ff1() { return conv_ff0() + LFf0::size(0); }
+constexpr int conv_m1() { return LMsg0::size(0); }
+constexpr int conv_m2() { return conv_m1() + LMsg::size(0); }
+constexpr int conv_ln0() { return conv_m2() + LMsg::size(0); }
+constexpr int conv_ln1() { return conv_ln0() + LnLayout<NS>::size(); }
+constexpr int conv_ff0() { return conv_ln1() + LnLayout<NS>::size(); }
+constexpr int conv_ff1() { return conv_ff0() + LFf0::size(0); }
 
 // Residue embedding: GVP (17+types, 3)->(16,4) without activations + LayerNorm
 // (protein_gnn.py:325-329, :375).  Output is the merged 28-float node row.

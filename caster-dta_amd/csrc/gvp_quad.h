@@ -83,6 +83,25 @@ struct Gemm {
   }
 };
 
+// The same weight matrix used TRANSPOSED (data gradients): output rows follow a
+// forward k-slot map (so gradients land exactly where the forward operand lived:
+// tile mt, register r <-> forward slot 4 mt + r), k-slots follow the map of the
+// forward OUTPUT rows.  element = W[c_k][c_out].
+template <class RowSegs, class KSegs, int LD>
+struct GemmT {
+  static constexpr int MT = ceil4(RowSegs::steps);
+  static constexpr int NSTEPS = KSegs::steps;
+  static constexpr int NFRAG = MT * NSTEPS;
+  static __host__ __device__ float element(const float* W, int idx) {
+    const int lane = idx & 63, f = idx >> 6;
+    const int mt = f / NSTEPS, s = f - mt * NSTEPS;
+    const int m = lane & 15, slot = 4 * mt + (m & 3);
+    const int c_out = slot < RowSegs::steps ? RowSegs::col(slot, m >> 2) : -1;
+    const int c_k = KSegs::col(s, lane >> 4);
+    return (c_out >= 0 && c_k >= 0) ? W[c_k * LD + c_out] : 0.f;
+  }
+};
+
 __device__ __forceinline__ f4 mfma(float a, float b, f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -146,6 +165,58 @@ __device__ __forceinline__ float quad_sum(float x) {   // over the 4 lanes of an
   x += __shfl_xor(x, 16);
   x += __shfl_xor(x, 32);
   return x;
+}
+
+// Sum over the 16 items of a tile (the 16 lanes of a group row); the total is
+// valid in lane i == 15 of every group.
+__device__ __forceinline__ float row_total(float x) {
+  x += row_shr_f<1>(x);
+  x += row_shr_f<2>(x);
+  x += row_shr_f<4>(x);
+  x += row_shr_f<8>(x);
+  return x;
+}
+
+// LDS row stride (floats) for a [rows][W] operand of the weight-gradient GEMMs:
+// W rounded to 16 and made == 16 (mod 32) so the two 16-lane halves of a
+// ds_read_b32 hit disjoint banks.
+constexpr int wg_stride(int w) { return ((w + 15) / 16) % 2 ? ((w + 15) / 16) * 16 : ((w + 15) / 16) * 16 + 16; }
+
+// Weight-gradient outer product on the matrix cores:
+//   acc[mt][nt] (rows 16mt + 4g + r, cols 16nt + (lane & 15)) += sum_rows A[row][.] (x) B[row][.]
+// A, B are LDS arrays [4*KS rows][stride]; the rows are the items of the tile
+// (KS = 4) or (plane, item) pairs (KS = 12) -- the reduction index of dW.
+template <int MT, int NT, int KS>
+__device__ __forceinline__ void wgrad(const float* A, int sa, const float* B, int sb, f4 (&acc)[MT][NT], int lane) {
+  const int m = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int row = 4 * ks + g;
+    float a[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[mt] = A[row * sa + 16 * mt + m];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float b = B[row * sb + 16 * nt + m];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma(a[mt], b, acc[mt][nt]);
+    }
+  }
+}
+
+// Add a weight-gradient tile grid into a [R][C] row-major LDS/global block.
+template <int MT, int NT>
+__device__ __forceinline__ void wgrad_flush(float* dst, int R, int C, const f4 (&acc)[MT][NT], int lane) {
+  const int m = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * mt + 4 * g + r, col = 16 * nt + m;
+        if (row < R && col < C) atomicAdd(dst + row * C + col, acc[mt][nt][r]);
+      }
 }
 
 // ------------------------------------------------------------------ one GVP
@@ -288,6 +359,224 @@ struct GvpQ {
 #pragma unroll
         for (int r = 0; r < 4; ++r) so[j][t][r] = RELU ? gvp::f_max(c[j].sp[t][r], 0.f) : c[j].sp[t][r];
   }
+
+  // ---------------------------------------------------------------- backward
+  // Transposed image slice: [WsT | WsvT | WvT | WhT] fragments.
+  typedef GemmT<Segs<SSegs, Seg<P2, NT + SI, H>>, Segs<Seg<P1, 0, SO>>, K> TWs;      // d(inputs) = Ws^T dsp
+  typedef GemmT<Segs<Seg<P1, 0, SO>>, Segs<Seg<P2, 0, (VO > 0 ? VO : 1)>>, SO> TWsv;  // dsp += Wsv^T dgate
+  typedef GemmT<Segs<Seg<P2, 0, H>>, Segs<Seg<P2, 0, (VO > 0 ? VO : 1)>>, H> TWv;     // dvh = Wv^T dvp
+  typedef GemmT<VSegs, Segs<Seg<P2, 0, H>>, VI> TWh;                                  // dV = Wh^T dvh
+  static_assert(TWsv::MT == OT && TWv::MT == 1 && TWh::MT == 1, "tile bookkeeping");
+  static constexpr int FT_WS = 0;
+  static constexpr int FT_WSV = FT_WS + TWs::NFRAG;
+  static constexpr int FT_WV = FT_WSV + (VO > 0 ? TWsv::NFRAG : 0);
+  static constexpr int FT_WH = FT_WV + (VO > 0 ? TWv::NFRAG : 0);
+  static constexpr int SIZE_T = (FT_WH + TWh::NFRAG) * 64;
+  static __host__ __device__ float element_t(const float* P, int idx) {
+    if (idx < FT_WSV * 64) return TWs::element(P + A::ws(NT), idx);
+    if (VO > 0 && idx < FT_WV * 64) return TWsv::element(P + A::wsv(NT), idx - FT_WSV * 64);
+    if (VO > 0 && idx < FT_WH * 64) return TWv::element(P + A::wv(NT), idx - FT_WV * 64);
+    return TWh::element(P, idx - FT_WH * 64);
+  }
+
+  struct Grads {          // per-lane gradients the weight-gradient GEMMs consume
+    f4 dsp[OT];           // d(pre-activation scalars), P1
+    f4 dgate;             // d(gate), P2 rows o
+    f4 dvp[3];            // d(wv.vh), P2 rows o
+    f4 dvh[3];            // d(wh.V), P2 rows h
+  };
+
+  // Backward of `forward` for one tile.  d_so / d_vo: gradients of the outputs;
+  // d_bs / d_bv: gradients of the k-slot inputs (same slots as bs / bv).
+  static __device__ __forceinline__ void backward(const float* imgT, int lane, const Cache& c,
+                                                  const f4 (&d_so)[OT], const float (&d_vo)[3][VOR],
+                                                  float (&d_bs)[SSTEPS], float (&d_bv)[3][VSTEPS], Grads& gr) {
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gr.dsp[t][r] = (RELU && c.sp[t][r] <= 0.f) ? 0.f : d_so[t][r];
+    gr.dgate = zero;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) gr.dvp[p] = gr.dvh[p] = zero;
+    if (VO > 0) {
+#pragma unroll
+      for (int r = 0; r < VOR; ++r) {
+        const float sg = c.sg[r];
+        float dsg = 0.f;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { dsg = fmaf(d_vo[p][r], c.vp[p][r], dsg); gr.dvp[p][r] = d_vo[p][r] * sg; }
+        gr.dgate[r] = dsg * sg * (1.0f - sg);
+      }
+      float bg[1][TWsv::NSTEPS];
+#pragma unroll
+      for (int r = 0; r < TWsv::NSTEPS; ++r) bg[0][r] = gr.dgate[r];
+#pragma unroll
+      for (int t = 0; t < OT; ++t) {
+        f4 acc[1] = {gr.dsp[t]};
+        apply<TWsv, 1>(imgT + FT_WSV * 64, t, bg, acc, lane);
+        gr.dsp[t] = acc[0];
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        float b[1][TWv::NSTEPS];
+#pragma unroll
+        for (int r = 0; r < TWv::NSTEPS; ++r) b[0][r] = gr.dvp[p][r];
+        f4 acc[1] = {zero};
+        apply<TWv, 1>(imgT + FT_WV * 64, 0, b, acc, lane);
+        gr.dvh[p] = acc[0];
+      }
+    }
+    float d_vn[HR];
+    {
+      float bd[1][4 * OT];
+#pragma unroll
+      for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bd[0][4 * t + r] = gr.dsp[t][r];
+#pragma unroll
+      for (int mt = 0; mt < TWs::MT; ++mt) {
+        f4 acc[1] = {zero};
+        apply<TWs, 1>(imgT + FT_WS * 64, mt, bd, acc, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int slot = 4 * mt + r;
+          if (slot < SSTEPS) d_bs[slot] = acc[0][r];
+          else if (slot < SSTEPS + HR) d_vn[slot - SSTEPS] = acc[0][r];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < HR; ++r) {      // through vn = sqrt(max(|vh|^2, eps)): no gradient below the clamp
+      const float n2 = c.vh[0][r] * c.vh[0][r] + c.vh[1][r] * c.vh[1][r] + c.vh[2][r] * c.vh[2][r];
+      const float k = n2 > gvp::kNormEps ? d_vn[r] * gvp::f_rcp(c.vn[r]) : 0.f;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) gr.dvh[p][r] = fmaf(k, c.vh[p][r], gr.dvh[p][r]);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      float b[1][TWh::NSTEPS];
+#pragma unroll
+      for (int r = 0; r < TWh::NSTEPS; ++r) b[0][r] = gr.dvh[p][r];
+      f4 acc[1] = {zero};
+      apply<TWh, 1>(imgT + FT_WH * 64, 0, b, acc, lane);
+#pragma unroll
+      for (int s2 = 0; s2 < VSTEPS; ++s2) d_bv[p][s2] = acc[0][s2];
+    }
+  }
+
+  // Weight gradients of this GVP for one tile, added into its arena-layout
+  // gradient block `gblk` (LDS, one per workgroup).  `scr` = this wave's LDS
+  // scratch (>= WG_SCRATCH floats).  type < 0 marks an inactive item.
+  static constexpr int SA1 = wg_stride(SO), SB1 = wg_stride(K), SV = wg_stride(16);
+  static constexpr int WG_SCRATCH_ = 16 * SA1 + 16 * SB1 > 6 * 16 * SV ? 16 * SA1 + 16 * SB1 : 6 * 16 * SV;
+  static constexpr int WG_SCRATCH = WG_SCRATCH_ > 16 * SV + 16 * SA1 ? WG_SCRATCH_ : 16 * SV + 16 * SA1;
+  static __device__ __forceinline__ void weight_grads(float* gblk, float* scr, int lane, int type, bool active,
+                                                      const float (&bs)[SSTEPS], const float (&bv)[3][VSTEPS],
+                                                      const Cache& c, const Grads& gr) {
+    const int i = lane & 15, g = lane >> 4;
+    // ---- dWs = dsp (x) [onehot | s | vn],  dbs = sum dsp
+    float* Abuf = scr;
+    float* Bbuf = scr + 16 * SA1;
+#pragma unroll
+    for (int t = 0; t < OT; ++t) *reinterpret_cast<f4*>(Abuf + i * SA1 + 16 * t + 4 * g) = active ? gr.dsp[t] : f4{0.f, 0.f, 0.f, 0.f};
+    for (int k = g; k < NT; k += 4) Bbuf[i * SB1 + k] = 0.f;
+#pragma unroll
+    for (int s = 0; s < SSTEPS; ++s) { const int col = SSegs::col(s, g); if (col >= 0) Bbuf[i * SB1 + col] = bs[s]; }
+#pragma unroll
+    for (int r = 0; r < HR; ++r) if (4 * r + g < H) Bbuf[i * SB1 + NT + SI + 4 * r + g] = c.vn[r];
+    if (NT > 0 && g == 0 && active) Bbuf[i * SB1 + type] = 1.0f;      // after the zero fill (same wave: in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    {
+      constexpr int NKT = (K + 15) / 16;
+      f4 acc[OT][NKT];
+#pragma unroll
+      for (int a = 0; a < OT; ++a)
+#pragma unroll
+        for (int b = 0; b < NKT; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+      wgrad<OT, NKT, 4>(Abuf, SA1, Bbuf, SB1, acc, lane);
+      wgrad_flush<OT, NKT>(gblk + A::ws(NT), SO, K, acc, lane);
+    }
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float tot = row_total(active ? gr.dsp[t][r] : 0.f);
+        if (i == 15) atomicAdd(gblk + A::bs(NT) + 16 * t + 4 * g + r, tot);
+      }
+    if (VO > 0) {
+      // ---- dWsv = dgate (x) sp, dbsv = sum dgate   (reuses Abuf rows 0..15 as [item][16], Bbuf as [item][SO])
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      float* Ag = scr;                 // [16][SV]: column o = 4r + g
+      float* Bs = scr + 16 * SV;       // [16][SA1]: the pre-activation scalars
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ag[i * SV + ((4 * r + g) & 15)] = active ? gr.dgate[r] : 0.f;
+#pragma unroll
+      for (int t = 0; t < OT; ++t) *reinterpret_cast<f4*>(Bs + i * SA1 + 16 * t + 4 * g) = c.sp[t];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      {
+        f4 acc[1][OT];
+#pragma unroll
+        for (int b = 0; b < OT; ++b) acc[0][b] = f4{0.f, 0.f, 0.f, 0.f};
+        wgrad<1, OT, 4>(Ag, SV, Bs, SA1, acc, lane);
+        wgrad_flush<1, OT>(gblk + A::wsv(NT), VO, SO, acc, lane);
+      }
+#pragma unroll
+      for (int r = 0; r < VOR; ++r) {
+        const float tot = row_total(active ? gr.dgate[r] : 0.f);
+        if (i == 15 && 4 * r + g < VO) atomicAdd(gblk + A::bsv(NT) + 4 * r + g, tot);
+      }
+    }
+    // ---- dWv = sum_planes dvp (x) vh ;  dWh = sum_planes dvh (x) V_in      ([plane][item][16] operands)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    float* Avp = scr;                    // dvp  [3][16][SV]
+    float* Bvh = scr + 3 * 16 * SV;      // vh   [3][16][SV]
+    if (VO > 0) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          Avp[(p * 16 + i) * SV + ((4 * r + g) & 15)] = active ? gr.dvp[p][r] : 0.f;
+          Bvh[(p * 16 + i) * SV + ((4 * r + g) & 15)] = c.vh[p][r];
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      f4 acc[1][1] = {{f4{0.f, 0.f, 0.f, 0.f}}};
+      wgrad<1, 1, 12>(Avp, SV, Bvh, SV, acc, lane);
+      wgrad_flush<1, 1>(gblk + A::wv(NT), VO, H, acc, lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+    {
+      float* Avh = scr;                  // dvh  [3][16][SV]
+      float* Bin = scr + 3 * 16 * SV;    // V_in [3][16][SV] in wh column order
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Avh[(p * 16 + i) * SV + ((4 * r + g) & 15)] = active ? gr.dvh[p][r] : 0.f;
+        for (int k = g; k < 16; k += 4) Bin[(p * 16 + i) * SV + k] = 0.f;
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int s = 0; s < VSTEPS; ++s) { const int col = VSegs::col(s, g); if (col >= 0) Bin[(p * 16 + i) * SV + col] = bv[p][s]; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      f4 acc[1][1] = {{f4{0.f, 0.f, 0.f, 0.f}}};
+      wgrad<1, 1, 12>(Avh, SV, Bin, SV, acc, lane);
+      wgrad_flush<1, 1>(gblk, H, VI, acc, lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
 };
 
 // Tuple LayerNorm on a tile (gvp_layers.py:231-242): S scalars in P1 (S/16
@@ -323,6 +612,66 @@ __device__ __forceinline__ void ln_quad(const float* ln, int lane, f4 (&s)[S / 1
   for (int p = 0; p < 3; ++p)
 #pragma unroll
     for (int r = 0; r < ceil4(NV); ++r) v[p][r] *= rvn;
+}
+
+// Backward of ln_quad.  x / v: the tuple BEFORE normalisation; ds / dv: in =
+// gradient of the normalised tuple, out = gradient of x / v.  The per-lane
+// contributions to d(gamma), d(beta) are returned for a row reduction.
+template <int S, int NV>
+__device__ __forceinline__ void ln_quad_bwd(const float* ln, int lane, const f4 (&x)[S / 16],
+                                            const float (&v)[3][ceil4(NV)], f4 (&ds)[S / 16],
+                                            float (&dv)[3][ceil4(NV)], f4 (&dgamma)[S / 16], f4 (&dbeta)[S / 16]) {
+  const int g = lane >> 4;
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < S / 16; ++t) sum += x[t][0] + x[t][1] + x[t][2] + x[t][3];
+  const float mean = quad_sum(sum) * (1.0f / S);
+  float var = 0.f;
+#pragma unroll
+  for (int t = 0; t < S / 16; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float d = x[t][r] - mean; var = fmaf(d, d, var); }
+  const float rstd = gvp::f_rsqrt(quad_sum(var) * (1.0f / S) + gvp::kLnEps);
+  f4 xh[S / 16], dxh[S / 16];
+  float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < S / 16; ++t) {
+    const f4 ga = *reinterpret_cast<const f4*>(ln + 16 * t + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xh[t][r] = (x[t][r] - mean) * rstd;
+      dgamma[t][r] = ds[t][r] * xh[t][r];
+      dbeta[t][r] = ds[t][r];
+      dxh[t][r] = ds[t][r] * ga[r];
+      m1 += dxh[t][r];
+      m2 = fmaf(dxh[t][r], xh[t][r], m2);
+    }
+  }
+  m1 = quad_sum(m1) * (1.0f / S);
+  m2 = quad_sum(m2) * (1.0f / S);
+#pragma unroll
+  for (int t = 0; t < S / 16; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ds[t][r] = rstd * (dxh[t][r] - m1 - xh[t][r] * m2);
+  // vectors: v' = v * rvn, rvn = (mean_c max(|v_c|^2, eps))^-1/2
+  float n2s = 0.f, dot = 0.f;
+  bool free_[ceil4(NV)];
+#pragma unroll
+  for (int r = 0; r < ceil4(NV); ++r) {
+    free_[r] = false;
+    if (4 * r + g < NV) {
+      const float n2 = v[0][r] * v[0][r] + v[1][r] * v[1][r] + v[2][r] * v[2][r];
+      free_[r] = n2 > gvp::kNormEps;
+      n2s += gvp::f_max(n2, gvp::kNormEps);
+      dot += dv[0][r] * v[0][r] + dv[1][r] * v[1][r] + dv[2][r] * v[2][r];
+    }
+  }
+  const float rvn = gvp::f_rsqrt(quad_sum(n2s) * (1.0f / NV));
+  const float k = quad_sum(dot) * rvn * rvn * rvn * (1.0f / NV);
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int r = 0; r < ceil4(NV); ++r) dv[p][r] = rvn * dv[p][r] - (free_[r] ? k * v[p][r] : 0.f);
 }
 
 // ------------------------------------------------------------- the LBA encoder
@@ -361,7 +710,19 @@ struct Image {
   static __host__ __device__ int conv(int l) { return EMB_SIZE + l * (CV_SIZE + ND_SIZE); }
   static __host__ __device__ int node(int l) { return conv(l) + CV_SIZE; }
   static __host__ __device__ int head(int num_convs) { return conv(num_convs); }
-  static __host__ __device__ int total(int num_convs) { return head(num_convs) + HD_SIZE; }
+  static __host__ __device__ int fwd_total(int num_convs) { return head(num_convs) + HD_SIZE; }
+  // transposed-fragment slices for the backward kernels, appended after the forward image:
+  //   embT | per layer [convT = edgeT msg0T msg1T msg2T | nodeT = ff0T ff1T] | headT
+  static constexpr int TE_SIZE = QNode<NTN>::SIZE_T;
+  static constexpr int TC_EDGE = 0, TC_M0 = QEdge<NTE>::SIZE_T, TC_M1 = TC_M0 + QMsg0::SIZE_T,
+                       TC_M2 = TC_M1 + QMsg1::SIZE_T, TC_SIZE = TC_M2 + QMsg2::SIZE_T;
+  static constexpr int TN_FF0 = 0, TN_FF1 = QFf0::SIZE_T, TN_SIZE = TN_FF1 + QFf1::SIZE_T;
+  static constexpr int TH_SIZE = QHead::SIZE_T;
+  static __host__ __device__ int embT(int nc) { return fwd_total(nc); }
+  static __host__ __device__ int convT(int nc, int l) { return embT(nc) + TE_SIZE + l * (TC_SIZE + TN_SIZE); }
+  static __host__ __device__ int nodeT(int nc, int l) { return convT(nc, l) + TC_SIZE; }
+  static __host__ __device__ int headT(int nc) { return convT(nc, nc); }
+  static __host__ __device__ int total(int nc) { return headT(nc) + TH_SIZE; }
 };
 
 }  // namespace gq

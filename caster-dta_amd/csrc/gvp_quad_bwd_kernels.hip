@@ -1,0 +1,628 @@
+// gvp_quad_bwd_kernels.hip -- backward of the LBA protein encoder on the same
+// MFMA quad-layout blocks as the forward (gvp_quad.h).
+//
+// Every kernel recomputes its stage's forward for a tile of 16 items from the
+// saved stage inputs (h_l, dh_l, raw features) instead of reading saved
+// activations, then back-propagates:
+//   * data gradients   : transposed weight fragments, chained in registers like
+//                        the forward (tile mt, register r <-> forward k-slot);
+//   * weight gradients : dW = sum_items dY (x) X as MFMA outer products whose
+//                        operands are transposed through a per-wave LDS scratch;
+//                        each workgroup accumulates one arena-layout block in LDS
+//                        and writes it to its row of a slab that a small reduce
+//                        kernel sums (deterministic, no float atomics on HBM);
+//   * d h[dst]         : in-register segmented scan over the sorted edges (owned
+//                        rows, plain stores);  d h[src]: float atomics (the only
+//                        ones in the library; sources are unsorted).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gvp_internal.h"
+#include "gvp_quad.h"
+
+using namespace gq;
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int WPB = 4;
+constexpr int TPB = WAVE * WPB;
+constexpr int TILE = 16;
+constexpr int MAX_GRID = kBwdMaxGrid;  // persistent workgroups (one slab row each)
+
+template <int NFLOATS>
+__device__ __forceinline__ void stage_slice(float* lds, const float* __restrict__ src, int tid) {
+  static_assert(NFLOATS % 4 == 0, "image slices are whole float4s");
+  constexpr int NF4 = NFLOATS / 4, IT = (NF4 + TPB - 1) / TPB;
+  const f4* s = reinterpret_cast<const f4*>(src);
+  f4* d = reinterpret_cast<f4*>(lds);
+  f4 v[IT];
+#pragma unroll
+  for (int k = 0; k < IT; ++k) { const int idx = tid + k * TPB; if (idx < NF4) v[k] = s[idx]; }
+#pragma unroll
+  for (int k = 0; k < IT; ++k) { const int idx = tid + k * TPB; if (idx < NF4) d[idx] = v[k]; }
+}
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int pad4(int x) { return (x + 3) / 4 * 4; }
+
+// LayerNorm parameter gradients of a tile -> [gamma | beta] block in LDS.
+template <int S>
+__device__ __forceinline__ void ln_param_grads(float* blk, int lane, bool active, const f4 (&dgamma)[S / 16],
+                                               const f4 (&dbeta)[S / 16]) {
+  const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < S / 16; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float tg = row_total(active ? dgamma[t][r] : 0.f);
+      const float tb = row_total(active ? dbeta[t][r] : 0.f);
+      if (i == 15) {
+        atomicAdd(blk + 16 * t + 4 * g + r, tg);
+        atomicAdd(blk + S + 16 * t + 4 * g + r, tb);
+      }
+    }
+}
+
+// ===================================================================== node update
+// Arena-layout gradient block of the node side of a conv layer:
+//   [norm.0 (32) | norm.1 (32) | ff_func.0 | ff_func.1]   (+ [gvp_norm_before_scalar (32) | gvp_to_scalar])
+constexpr int NB_LN0 = 0, NB_LN1 = 2 * NS, NB_FF0 = 4 * NS, NB_FF1 = NB_FF0 + LFf0::size(0),
+              NODE_BLK = NB_FF1 + LFf1::size(0);
+constexpr int HB_LN = 0, HB_GVP = 2 * NS, HEAD_BLK = HB_GVP + LHead::size(0);
+constexpr int NODE_SCR = cmax(cmax(QFf0::WG_SCRATCH, QFf1::WG_SCRATCH), QHead::WG_SCRATCH);
+
+constexpr int MROW = NS + NV;          // dropout mask row: 16 scalar + 4 vector-channel factors
+struct NodeBArgs {
+  const float* img_node; const float* img_head; const float* imgT_node; const float* imgT_head;
+  const float* h; const float* dh; const float* mask0; const float* mask1;
+  const float* g_out; const float* g_up0; const float* g_up1; const float* g_up2;
+  int64_t N; float* g_dh; float* g_h; float* slab;
+};
+
+template <bool HEAD>
+__global__ __launch_bounds__(TPB) void node_bwd_kernel(NodeBArgs a) {
+  typedef Image<0, 0> IM;
+  constexpr int GB = pad4(NODE_BLK + (HEAD ? HEAD_BLK : 0));
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* f_node = lds;
+  float* f_head = f_node + IM::ND_SIZE;
+  float* t_node = f_head + (HEAD ? IM::HD_SIZE : 0);
+  float* t_head = t_node + IM::TN_SIZE;
+  float* gblk = t_head + (HEAD ? IM::TH_SIZE : 0);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* scr = gblk + GB + w * NODE_SCR;
+  stage_slice<IM::ND_SIZE>(f_node, a.img_node, threadIdx.x);
+  stage_slice<IM::TN_SIZE>(t_node, a.imgT_node, threadIdx.x);
+  if (HEAD) {
+    stage_slice<IM::HD_SIZE>(f_head, a.img_head, threadIdx.x);
+    stage_slice<IM::TH_SIZE>(t_head, a.imgT_head, threadIdx.x);
+  }
+  for (int k = threadIdx.x; k < GB; k += TPB) gblk[k] = 0.f;
+  __syncthreads();
+
+  const int i = lane & 15, g = lane >> 4;
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  const int zt[1] = {0};
+  const int64_t ntiles = (a.N + TILE - 1) / TILE;
+  for (int64_t tile = (int64_t)blockIdx.x * WPB + w; tile < ntiles; tile += (int64_t)gridDim.x * WPB) {
+    const int64_t n = tile * TILE + i;
+    const bool active = n < a.N;
+    // ---- recompute the forward of this tile
+    f4 x0[1] = {zero};
+    float xv0[3][1] = {{0.f}, {0.f}, {0.f}};
+    f4 m0s = {1.f, 1.f, 1.f, 1.f}, m1s = {1.f, 1.f, 1.f, 1.f};
+    float m0v = 1.f, m1v = 1.f;
+    if (active) {
+      const float* hr = a.h + n * ROW;
+      const float* dr = a.dh + n * ROW;
+      if (a.mask0) { m0s = *reinterpret_cast<const f4*>(a.mask0 + n * MROW + 4 * g); m0v = a.mask0[n * MROW + NS + g]; }
+      if (a.mask1) { m1s = *reinterpret_cast<const f4*>(a.mask1 + n * MROW + 4 * g); m1v = a.mask1[n * MROW + NS + g]; }
+      x0[0] = *reinterpret_cast<const f4*>(hr + 4 * g) + *reinterpret_cast<const f4*>(dr + 4 * g) * m0s;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) xv0[p][0] = hr[NS + 3 * g + p] + dr[NS + 3 * g + p] * m0v;
+    }
+    f4 y[1] = {x0[0]};
+    float yv[3][1] = {{xv0[0][0]}, {xv0[1][0]}, {xv0[2][0]}};
+    ln_quad<NS, NV>(f_node + IM::ND_LN0, lane, y, yv);
+    f4 hs[1][4], s2[1][1];
+    float hv[1][3][2], v2[1][3][1];
+    float bs0[1][4], bv0[1][3][1], bs1[1][16], bv1[1][3][2];
+    QFf0::Cache c0[1];
+    QFf1::Cache c1[1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bs0[0][r] = y[0][r];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) bv0[0][p][0] = yv[p][0];
+    QFf0::forward<1>(f_node + IM::ND_FF0, lane, zt, bs0, bv0, hs, hv, c0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bs1[0][4 * t + r] = hs[0][t][r];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { bv1[0][p][0] = hv[0][p][0]; bv1[0][p][1] = hv[0][p][1]; }
+    QFf1::forward<1>(f_node + IM::ND_FF1, lane, zt, bs1, bv1, s2, v2, c1);
+    f4 z[1] = {y[0] + s2[0][0] * m1s};
+    float zv[3][1];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) zv[p][0] = yv[p][0] + v2[0][p][0] * m1v;
+
+    // ---- upstream gradient of this stage's output
+    f4 gs[1] = {zero};
+    float gv[3][1] = {{0.f}, {0.f}, {0.f}};
+    if (HEAD) {
+      f4 o1[1] = {z[0]};
+      float ov1[3][1] = {{zv[0][0]}, {zv[1][0]}, {zv[2][0]}};
+      ln_quad<NS, NV>(f_node + IM::ND_LN1, lane, o1, ov1);        // output of norm.1 (input of the head)
+      f4 wsn[1] = {o1[0]};
+      float wvn[3][1] = {{ov1[0][0]}, {ov1[1][0]}, {ov1[2][0]}};
+      ln_quad<NS, NV>(f_head + IM::HD_LN, lane, wsn, wvn);
+      float bsh[1][4], bvh[1][3][1], dummy[1][3][1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bsh[0][r] = wsn[0][r];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bvh[0][p][0] = wvn[p][0];
+      f4 o[1][4];
+      QHead::Cache ch[1];
+      QHead::forward<1>(f_head + IM::HD_GVP, lane, zt, bsh, bvh, o, dummy, ch);
+      f4 d_o[4] = {zero, zero, zero, zero};
+      if (active) {
+        const float* gr_ = a.g_out + n * OUT;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) d_o[t] = *reinterpret_cast<const f4*>(gr_ + 16 * t + 4 * g);
+      }
+      float d_vo[3][1] = {{0.f}, {0.f}, {0.f}}, d_bs[4], d_bv[3][1];
+      QHead::Grads grh;
+      QHead::backward(t_head, lane, ch[0], d_o, d_vo, d_bs, d_bv, grh);
+      QHead::weight_grads(gblk + NODE_BLK + HB_GVP, scr, lane, 0, active, bsh[0], bvh[0], ch[0], grh);
+      f4 dws[1] = {f4{d_bs[0], d_bs[1], d_bs[2], d_bs[3]}};
+      float dwv[3][1] = {{d_bv[0][0]}, {d_bv[1][0]}, {d_bv[2][0]}};
+      f4 dga[1], dbe[1];
+      ln_quad_bwd<NS, NV>(f_head + IM::HD_LN, lane, o1, ov1, dws, dwv, dga, dbe);
+      ln_param_grads<NS>(gblk + NODE_BLK + HB_LN, lane, active, dga, dbe);
+      gs[0] = dws[0];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) gv[p][0] = dwv[p][0];
+    } else if (active) {
+      const float* ups[3] = {a.g_up0, a.g_up1, a.g_up2};
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (ups[u]) {
+          const float* r_ = ups[u] + n * ROW;
+          gs[0] += *reinterpret_cast<const f4*>(r_ + 4 * g);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) gv[p][0] += r_[NS + 3 * g + p];
+        }
+    }
+
+    // ---- norm.1, feed-forward, residual, norm.0
+    {
+      f4 dga[1], dbe[1];
+      ln_quad_bwd<NS, NV>(f_node + IM::ND_LN1, lane, z, zv, gs, gv, dga, dbe);      // gs/gv := d z
+      ln_param_grads<NS>(gblk + NB_LN1, lane, active, dga, dbe);
+    }
+    float d_hs[16], d_hv[3][2];
+    {
+      f4 d_so[1] = {gs[0] * m1s};
+      float d_vo[3][1] = {{gv[0][0] * m1v}, {gv[1][0] * m1v}, {gv[2][0] * m1v}};
+      QFf1::Grads gr1;
+      QFf1::backward(t_node + IM::TN_FF1, lane, c1[0], d_so, d_vo, d_hs, d_hv, gr1);
+      QFf1::weight_grads(gblk + NB_FF1, scr, lane, 0, active, bs1[0], bv1[0], c1[0], gr1);
+    }
+    {
+      f4 d_so[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) d_so[t] = f4{d_hs[4 * t], d_hs[4 * t + 1], d_hs[4 * t + 2], d_hs[4 * t + 3]};
+      float d_ys[4], d_yv[3][1];
+      QFf0::Grads gr0;
+      QFf0::backward(t_node + IM::TN_FF0, lane, c0[0], d_so, d_hv, d_ys, d_yv, gr0);
+      QFf0::weight_grads(gblk + NB_FF0, scr, lane, 0, active, bs0[0], bv0[0], c0[0], gr0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gs[0][r] += d_ys[r];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) gv[p][0] += d_yv[p][0];
+    }
+    {
+      f4 dga[1], dbe[1];
+      ln_quad_bwd<NS, NV>(f_node + IM::ND_LN0, lane, x0, xv0, gs, gv, dga, dbe);    // gs/gv := d (h + dh)
+      ln_param_grads<NS>(gblk + NB_LN0, lane, active, dga, dbe);
+    }
+    if (active) {               // d h (residual path) and d dh = mask0 * d h (equal without dropout)
+      if (a.g_h) {
+        float* row = a.g_h + n * ROW;
+        *reinterpret_cast<f4*>(row + 4 * g) = gs[0];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) row[NS + 3 * g + p] = gv[p][0];
+      }
+      float* row = a.g_dh + n * ROW;
+      *reinterpret_cast<f4*>(row + 4 * g) = gs[0] * m0s;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) row[NS + 3 * g + p] = gv[p][0] * m0v;
+    }
+  }
+  __syncthreads();
+  float* out = a.slab + (size_t)blockIdx.x * GB;
+  for (int k = threadIdx.x; k < GB; k += TPB) out[k] = gblk[k];
+}
+
+// ===================================================================== conv
+// Gradient block: [gvp_edge.0 | gvp_edge.1 (64)] then [message_func.0 | .1 | .2].
+template <int NTE>
+struct ConvBlk {
+  static constexpr int E_GVP = 0, E_LN = LEdgeGvp::size(NTE), E_SIZE = pad4(E_LN + 2 * ES);
+  static constexpr int M0 = E_SIZE, M1 = M0 + LMsg0::size(0), M2 = M1 + LMsg::size(0), SIZE = pad4(M2 + LMsg::size(0));
+};
+template <int NTE>
+constexpr int conv_scr() {
+  return cmax(cmax(QEdge<NTE>::WG_SCRATCH, QMsg0::WG_SCRATCH), cmax(QMsg1::WG_SCRATCH, QMsg2::WG_SCRATCH));
+}
+
+struct ConvBArgs {
+  const float* img; const float* imgT;
+  const float* h; const float* e_s; const float* e_v; const int64_t* etypes;
+  const int32_t* rowptr; const int32_t* eperm; const int32_t* esrc; const int32_t* edst;
+  int64_t N; int npw; int mean; const float* g_dh; float* g_src; float* g_dst; float* slab;
+};
+
+template <int NTE>
+__global__ __launch_bounds__(TPB) void conv_bwd_kernel(ConvBArgs a) {
+  typedef Image<0, NTE> IM;
+  typedef ConvBlk<NTE> B;
+  constexpr int ACC = WAVE * ROW, SCR = conv_scr<NTE>();
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* img = lds;
+  float* imgT = img + IM::CV_SIZE;
+  float* gblk = imgT + IM::TC_SIZE;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* acc = gblk + B::SIZE + w * (ACC + SCR);
+  float* scr = acc + ACC;
+  stage_slice<IM::CV_SIZE>(img, a.img, threadIdx.x);
+  stage_slice<IM::TC_SIZE>(imgT, a.imgT, threadIdx.x);
+  for (int k = threadIdx.x; k < B::SIZE; k += TPB) gblk[k] = 0.f;
+  for (int k = lane; k < ACC; k += WAVE) acc[k] = 0.f;
+  __syncthreads();
+
+  const int i = lane & 15, g = lane >> 4;
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  const int zt[1] = {0};
+  const int64_t ngroups = (a.N + a.npw - 1) / a.npw;
+  for (int64_t grp = (int64_t)blockIdx.x * WPB + w; grp < ngroups; grp += (int64_t)gridDim.x * WPB) {
+    const int64_t n0 = grp * a.npw;
+    const int nn = (int)((a.N - n0 < a.npw) ? (a.N - n0) : a.npw);
+    const int32_t e0 = a.rowptr[n0], e1 = a.rowptr[n0 + nn];
+    for (int32_t base = e0; base < e1; base += TILE) {
+      const int32_t p = base + i;
+      const bool active = p < e1;
+      // ---- gather (as the forward)
+      f4 es0 = zero, es1 = zero, sj = zero, si = zero, d_ms = zero;
+      float ev[3] = {0.f, 0.f, 0.f}, vj[3] = {0.f, 0.f, 0.f}, vi[3] = {0.f, 0.f, 0.f}, d_mv[3] = {0.f, 0.f, 0.f};
+      int et[1] = {0};
+      int32_t src = 0, dst = -1;
+      if (active) {
+        const int32_t eid = a.eperm[p];
+        src = a.esrc[p];
+        dst = a.edst[p];
+        const float* er = a.e_s + (int64_t)eid * EDGE_IN_S;
+        es0 = *reinterpret_cast<const f4*>(er + 4 * g);
+        es1 = *reinterpret_cast<const f4*>(er + 16 + 4 * g);
+        if (g == 0) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) ev[d] = a.e_v[(int64_t)eid * 3 + d];
+        }
+        if (NTE > 0) {
+          et[0] = (int)a.etypes[eid];
+          et[0] = et[0] < 0 ? 0 : (et[0] >= NTE ? NTE - 1 : et[0]);
+        }
+        const float* hj = a.h + (int64_t)src * ROW;
+        const float* hi = a.h + (int64_t)dst * ROW;
+        const float* gd = a.g_dh + (int64_t)dst * ROW;       // d(aggregated message) of the target
+        sj = *reinterpret_cast<const f4*>(hj + 4 * g);
+        si = *reinterpret_cast<const f4*>(hi + 4 * g);
+        d_ms = *reinterpret_cast<const f4*>(gd + 4 * g);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { vj[d] = hj[NS + 3 * g + d]; vi[d] = hi[NS + 3 * g + d]; d_mv[d] = gd[NS + 3 * g + d]; }
+        if (a.mean) {
+          const int deg = a.rowptr[dst + 1] - a.rowptr[dst];
+          const float sc = 1.0f / (float)(deg > 1 ? deg : 1);
+          d_ms *= sc;
+#pragma unroll
+          for (int d = 0; d < 3; ++d) d_mv[d] *= sc;
+        }
+      }
+      // ---- recompute the forward of the tile, keeping every GVP's cache
+      float bse[1][8], bve[1][3][1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { bse[0][r] = es0[r]; bse[0][4 + r] = es1[r]; }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) bve[0][d][0] = ev[d];
+      f4 e_pre[1][2];
+      float ev_pre[1][3][1];
+      typename QEdge<NTE>::Cache ce[1];
+      QEdge<NTE>::template forward<1>(img + IM::CV_EDGE, lane, et, bse, bve, e_pre, ev_pre, ce);
+      f4 e_s[2] = {e_pre[0][0], e_pre[0][1]};
+      float e_v[3][1] = {{ev_pre[0][0][0]}, {ev_pre[0][1][0]}, {ev_pre[0][2][0]}};
+      ln_quad<ES, EV>(img + IM::CV_ELN, lane, e_s, e_v);
+      float b0[1][16], bv0[1][3][3], b1[1][4], bv1[1][3][1], b2[1][4], bv2[1][3][1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { b0[0][r] = sj[r]; b0[0][4 + r] = e_s[0][r]; b0[0][8 + r] = e_s[1][r]; b0[0][12 + r] = si[r]; }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { bv0[0][d][0] = vj[d]; bv0[0][d][1] = vi[d]; bv0[0][d][2] = e_v[d][0]; }
+      f4 s1[1][1], s2[1][1], s3[1][1];
+      float v1[1][3][1], v2[1][3][1], v3[1][3][1];
+      QMsg0::Cache c0[1];
+      QMsg1::Cache c1[1];
+      QMsg2::Cache c2[1];
+      QMsg0::forward<1>(img + IM::CV_M0, lane, zt, b0, bv0, s1, v1, c0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b1[0][r] = s1[0][0][r];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) bv1[0][d][0] = v1[0][d][0];
+      QMsg1::forward<1>(img + IM::CV_M1, lane, zt, b1, bv1, s2, v2, c1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b2[0][r] = s2[0][0][r];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) bv2[0][d][0] = v2[0][d][0];
+      QMsg2::forward<1>(img + IM::CV_M2, lane, zt, b2, bv2, s3, v3, c2);
+
+      // ---- backward through the three message GVPs
+      float d_b[4], d_bv[3][1];
+      {
+        f4 d_so[1] = {d_ms};
+        float d_vo[3][1] = {{d_mv[0]}, {d_mv[1]}, {d_mv[2]}};
+        QMsg2::Grads gr;
+        QMsg2::backward(imgT + IM::TC_M2, lane, c2[0], d_so, d_vo, d_b, d_bv, gr);
+        QMsg2::weight_grads(gblk + B::M2, scr, lane, 0, active, b2[0], bv2[0], c2[0], gr);
+      }
+      {
+        f4 d_so[1] = {f4{d_b[0], d_b[1], d_b[2], d_b[3]}};
+        float d_vo[3][1] = {{d_bv[0][0]}, {d_bv[1][0]}, {d_bv[2][0]}};
+        QMsg1::Grads gr;
+        QMsg1::backward(imgT + IM::TC_M1, lane, c1[0], d_so, d_vo, d_b, d_bv, gr);
+        QMsg1::weight_grads(gblk + B::M1, scr, lane, 0, active, b1[0], bv1[0], c1[0], gr);
+      }
+      float d_b0[16], d_bv0[3][3];
+      {
+        f4 d_so[1] = {f4{d_b[0], d_b[1], d_b[2], d_b[3]}};
+        float d_vo[3][1] = {{d_bv[0][0]}, {d_bv[1][0]}, {d_bv[2][0]}};
+        QMsg0::Grads gr;
+        QMsg0::backward(imgT + IM::TC_M0, lane, c0[0], d_so, d_vo, d_b0, d_bv0, gr);
+        QMsg0::weight_grads(gblk + B::M0, scr, lane, 0, active, b0[0], bv0[0], c0[0], gr);
+      }
+      // ---- edge embedding: LayerNorm and GVP (weight gradients only; raw edge features get none)
+      {
+        f4 d_es[2] = {f4{d_b0[4], d_b0[5], d_b0[6], d_b0[7]}, f4{d_b0[8], d_b0[9], d_b0[10], d_b0[11]}};
+        float d_ev[3][1] = {{d_bv0[0][2]}, {d_bv0[1][2]}, {d_bv0[2][2]}};
+        f4 dga[2], dbe[2];
+        ln_quad_bwd<ES, EV>(img + IM::CV_ELN, lane, e_pre[0], ev_pre[0], d_es, d_ev, dga, dbe);
+        ln_param_grads<ES>(gblk + B::E_LN, lane, active, dga, dbe);
+        float d_in[8], d_inv[3][1];
+        typename QEdge<NTE>::Grads gr;
+        QEdge<NTE>::backward(imgT + IM::TC_EDGE, lane, ce[0], d_es, d_ev, d_in, d_inv, gr);
+        QEdge<NTE>::weight_grads(gblk + B::E_GVP, scr, lane, et[0], active, bse[0], bve[0], ce[0], gr);
+      }
+      // ---- d h[src]: unsorted sources -> float atomics on the zero-initialised g_src
+      if (active) {
+        float* rj = a.g_src + (int64_t)src * ROW;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(rj + 4 * g + r, d_b0[r]);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) atomicAdd(rj + NS + 3 * g + d, d_bv0[d][0]);
+      }
+      // ---- d h[dst]: segmented scan over the sorted targets, owned rows
+      {
+        float x[7] = {d_b0[12], d_b0[13], d_b0[14], d_b0[15], d_bv0[0][1], d_bv0[1][1], d_bv0[2][1]};
+        seg_scan16<7>(dst, x);
+        const int nxt = __builtin_amdgcn_update_dpp(-1, dst, 0x100 | 1, 0xf, 0xf, false);
+        if (active && (i == TILE - 1 || nxt != dst)) {
+          float* row = acc + (dst - (int)n0) * ROW;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(row + 4 * g + r, x[r]);
+#pragma unroll
+          for (int d = 0; d < 3; ++d) atomicAdd(row + NS + 3 * g + d, x[4 + d]);
+        }
+      }
+    }
+    // flush this group's owned rows and clear the accumulator for the next group
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float* out = a.g_dst + n0 * ROW;
+    for (int k = lane; k < nn * ROW; k += WAVE) { out[k] = acc[k]; acc[k] = 0.f; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  float* out = a.slab + (size_t)blockIdx.x * B::SIZE;
+  for (int k = threadIdx.x; k < B::SIZE; k += TPB) out[k] = gblk[k];
+}
+
+// ===================================================================== node embed
+template <int NTN>
+struct EmbBlk {
+  static constexpr int GVP = 0, LN = LNodeGvp::size(NTN), SIZE = pad4(LN + 2 * NS);
+};
+
+struct EmbBArgs {
+  const float* img; const float* imgT; const float* x_s; const float* x_v; const int64_t* ntypes; int64_t N;
+  const float* g_up0; const float* g_up1; const float* g_up2; float* g_x_s; float* g_x_v; float* slab;
+};
+
+template <int NTN>
+__global__ __launch_bounds__(TPB) void embed_bwd_kernel(EmbBArgs a) {
+  typedef Image<NTN, 0> IM;
+  typedef QNode<NTN> Q;
+  typedef EmbBlk<NTN> B;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* img = lds;
+  float* imgT = img + IM::EMB_SIZE;
+  float* gblk = imgT + IM::TE_SIZE;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* scr = gblk + B::SIZE + w * Q::WG_SCRATCH;
+  stage_slice<IM::EMB_SIZE>(img, a.img, threadIdx.x);
+  stage_slice<IM::TE_SIZE>(imgT, a.imgT, threadIdx.x);
+  for (int k = threadIdx.x; k < B::SIZE; k += TPB) gblk[k] = 0.f;
+  __syncthreads();
+  const int i = lane & 15, g = lane >> 4;
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  const int64_t ntiles = (a.N + TILE - 1) / TILE;
+  for (int64_t tile = (int64_t)blockIdx.x * WPB + w; tile < ntiles; tile += (int64_t)gridDim.x * WPB) {
+    const int64_t n = tile * TILE + i;
+    const bool active = n < a.N;
+    float bs[1][Q::SSTEPS], bv[1][3][1];
+    int type[1] = {0};
+#pragma unroll
+    for (int s = 0; s < Q::SSTEPS; ++s) {
+      const int c = 4 * s + g;
+      bs[0][s] = (active && c < NODE_IN_S) ? a.x_s[n * NODE_IN_S + c] : 0.f;
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) bv[0][p][0] = (active && g < NODE_IN_V) ? a.x_v[n * 3 * NODE_IN_V + 3 * g + p] : 0.f;
+    if (NTN > 0 && active) {
+      type[0] = (int)a.ntypes[n];
+      type[0] = type[0] < 0 ? 0 : (type[0] >= NTN ? NTN - 1 : type[0]);
+    }
+    f4 s_pre[1][1];
+    float v_pre[1][3][1];
+    typename Q::Cache c[1];
+    Q::template forward<1>(img + IM::EMB_GVP, lane, type, bs, bv, s_pre, v_pre, c);
+    f4 gs[1] = {zero};
+    float gv[3][1] = {{0.f}, {0.f}, {0.f}};
+    if (active) {
+      const float* ups[3] = {a.g_up0, a.g_up1, a.g_up2};
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (ups[u]) {
+          const float* r_ = ups[u] + n * ROW;
+          gs[0] += *reinterpret_cast<const f4*>(r_ + 4 * g);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) gv[p][0] += r_[NS + 3 * g + p];
+        }
+    }
+    f4 dga[1], dbe[1];
+    ln_quad_bwd<NS, NV>(img + IM::EMB_LN, lane, s_pre[0], v_pre[0], gs, gv, dga, dbe);
+    ln_param_grads<NS>(gblk + B::LN, lane, active, dga, dbe);
+    float d_bs[Q::SSTEPS], d_bv[3][1];
+    typename Q::Grads gr;
+    Q::backward(imgT, lane, c[0], gs, gv, d_bs, d_bv, gr);
+    Q::weight_grads(gblk + B::GVP, scr, lane, type[0], active, bs[0], bv[0], c[0], gr);
+    if (active && a.g_x_s) {
+#pragma unroll
+      for (int s = 0; s < Q::SSTEPS; ++s) {
+        const int cc = 4 * s + g;
+        if (cc < NODE_IN_S) a.g_x_s[n * NODE_IN_S + cc] = d_bs[s];
+      }
+      if (g < NODE_IN_V) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a.g_x_v[n * 3 * NODE_IN_V + 3 * g + p] = d_bv[p][0];
+      }
+    }
+  }
+  __syncthreads();
+  float* out = a.slab + (size_t)blockIdx.x * B::SIZE;
+  for (int k = threadIdx.x; k < B::SIZE; k += TPB) out[k] = gblk[k];
+}
+
+// dst[j] += sum_r slab[r][col0 + j], j < len   (fixed order: deterministic)
+__global__ void reduce_slab_kernel(const float* __restrict__ slab, int rows, int stride, int col0, int len,
+                                   float* __restrict__ dst) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= len) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += slab[(size_t)r * stride + col0 + j];
+  dst[j] += s;
+}
+
+inline int grid_for(int64_t units) {
+  int64_t wgs = (units + WPB - 1) / WPB;
+  return (int)(wgs < 1 ? 1 : (wgs > MAX_GRID ? MAX_GRID : wgs));
+}
+
+}  // namespace
+
+namespace quad {
+
+int bwd_block_sizes(int nt_node, int nt_edge, int* emb, int* conv_edge, int* conv_total, int* node, int* head) {
+  if (nt_node == 0) *emb = EmbBlk<0>::SIZE; else if (nt_node == 20) *emb = EmbBlk<20>::SIZE;
+  else if (nt_node == 21) *emb = EmbBlk<21>::SIZE; else return CGVP_ERR_UNSUPPORTED_DIMS;
+  if (nt_edge == 0) { *conv_edge = ConvBlk<0>::E_SIZE; *conv_total = ConvBlk<0>::SIZE; }
+  else if (nt_edge == 1) { *conv_edge = ConvBlk<1>::E_SIZE; *conv_total = ConvBlk<1>::SIZE; }
+  else return CGVP_ERR_UNSUPPORTED_DIMS;
+  *node = pad4(NODE_BLK);
+  *head = pad4(NODE_BLK + HEAD_BLK);
+  return 0;
+}
+
+int reduce_slab(const float* slab, int rows, int stride, int col0, int len, float* dst, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_slab_kernel, dim3((len + 255) / 256), dim3(256), 0, st, slab, rows, stride, col0, len, dst);
+  return 0;
+}
+
+int node_update_bwd(const float* img_node, const float* img_head, const float* imgT_node, const float* imgT_head,
+                    const float* h, const float* dh, const float* mask0, const float* mask1, const float* g_out,
+                    const float* g_up0, const float* g_up1, const float* g_up2, int64_t N, int with_head,
+                    float* g_dh, float* g_h, float* slab, int* grid, hipStream_t st) {
+  typedef Image<0, 0> IM;
+  NodeBArgs a{img_node, img_head, imgT_node, imgT_head, h, dh, mask0, mask1, g_out, g_up0, g_up1, g_up2, N, g_dh, g_h, slab};
+  const int G = grid_for((N + TILE - 1) / TILE);
+  *grid = G;
+  if (with_head) {
+    const size_t lds = (size_t)(IM::ND_SIZE + IM::HD_SIZE + IM::TN_SIZE + IM::TH_SIZE + pad4(NODE_BLK + HEAD_BLK) +
+                                WPB * NODE_SCR) * sizeof(float);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(node_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(node_bwd_kernel<true>, dim3(G), dim3(TPB), lds, st, a);
+  } else {
+    const size_t lds = (size_t)(IM::ND_SIZE + IM::TN_SIZE + pad4(NODE_BLK) + WPB * NODE_SCR) * sizeof(float);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(node_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(node_bwd_kernel<false>, dim3(G), dim3(TPB), lds, st, a);
+  }
+  return 0;
+}
+
+template <int NTE>
+int conv_bwd_impl(ConvBArgs& a, int* grid, hipStream_t st) {
+  typedef Image<0, NTE> IM;
+  const int64_t groups = (a.N + a.npw - 1) / a.npw;
+  const int G = grid_for(groups);
+  *grid = G;
+  const size_t lds = (size_t)(IM::CV_SIZE + IM::TC_SIZE + ConvBlk<NTE>::SIZE + WPB * (WAVE * ROW + conv_scr<NTE>())) * sizeof(float);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_kernel<NTE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(conv_bwd_kernel<NTE>, dim3(G), dim3(TPB), lds, st, a);
+  return 0;
+}
+
+int conv_bwd(int nt_edge, const float* img, const float* imgT, const float* h, const float* e_s, const float* e_v,
+             const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
+             const int32_t* edst, int64_t N, int64_t E, int mean, const float* g_dh, float* g_src, float* g_dst,
+             float* slab, int* grid, hipStream_t st) {
+  int64_t deg = N > 0 ? (E + N - 1) / N : 1;
+  if (deg < 1) deg = 1;
+  int npw = (int)((2 * TILE - 2) / deg);
+  npw = npw < 1 ? 1 : (npw > WAVE ? WAVE : npw);
+  ConvBArgs a{img, imgT, h, e_s, e_v, etypes, rowptr, eperm, esrc, edst, N, npw, mean, g_dh, g_src, g_dst, slab};
+  if (nt_edge == 0) return conv_bwd_impl<0>(a, grid, st);
+  if (nt_edge == 1) return conv_bwd_impl<1>(a, grid, st);
+  return CGVP_ERR_UNSUPPORTED_DIMS;
+}
+
+template <int NTN>
+int embed_bwd_impl(EmbBArgs& a, int* grid, hipStream_t st) {
+  typedef Image<NTN, 0> IM;
+  const int G = grid_for((a.N + TILE - 1) / TILE);
+  *grid = G;
+  const size_t lds = (size_t)(IM::EMB_SIZE + IM::TE_SIZE + EmbBlk<NTN>::SIZE + WPB * QNode<NTN>::WG_SCRATCH) * sizeof(float);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel<NTN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(embed_bwd_kernel<NTN>, dim3(G), dim3(TPB), lds, st, a);
+  return 0;
+}
+
+int node_embed_bwd(int nt_node, const float* img, const float* imgT, const float* x_s, const float* x_v,
+                   const int64_t* ntypes, int64_t N, const float* g_up0, const float* g_up1, const float* g_up2,
+                   float* g_x_s, float* g_x_v, float* slab, int* grid, hipStream_t st) {
+  EmbBArgs a{img, imgT, x_s, x_v, ntypes, N, g_up0, g_up1, g_up2, g_x_s, g_x_v, slab};
+  if (nt_node == 0) return embed_bwd_impl<0>(a, grid, st);
+  if (nt_node == 20) return embed_bwd_impl<20>(a, grid, st);
+  if (nt_node == 21) return embed_bwd_impl<21>(a, grid, st);
+  return CGVP_ERR_UNSUPPORTED_DIMS;
+}
+
+}  // namespace quad

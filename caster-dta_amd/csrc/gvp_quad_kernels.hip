@@ -89,9 +89,24 @@ __global__ void lba_prepare_kernel(const float* __restrict__ P, EncLayout L, int
         else if (k < IM::ND_LN1) v = QFf1::element(C + conv_ff1(), k - IM::ND_FF1);
         else v = C[conv_ln1() + (k - IM::ND_LN1)];
       }
-    } else {
+    } else if (idx < IM::fwd_total(num_convs)) {
       const int k = idx - IM::head(num_convs);
       v = k < IM::HD_GVP ? P[L.ln_out + k] : QHead::element(P + L.head, k - IM::HD_GVP);
+    } else if (idx < IM::convT(num_convs, 0)) {
+      v = QNode<NTN>::element_t(P + L.node_gvp, idx - IM::embT(num_convs));
+    } else if (idx < IM::headT(num_convs)) {
+      const int j = idx - IM::convT(num_convs, 0);
+      const int l = j / (IM::TC_SIZE + IM::TN_SIZE);
+      int k = j - l * (IM::TC_SIZE + IM::TN_SIZE);
+      const float* C = P + L.conv0 + l * L.conv_stride;
+      if (k < IM::TC_M0) v = QEdge<NTE>::element_t(P + L.edge_gvp, k);
+      else if (k < IM::TC_M1) v = QMsg0::element_t(C + CONV_M0, k - IM::TC_M0);
+      else if (k < IM::TC_M2) v = QMsg1::element_t(C + conv_m1(), k - IM::TC_M1);
+      else if (k < IM::TC_SIZE) v = QMsg2::element_t(C + conv_m2(), k - IM::TC_M2);
+      else if (k < IM::TC_SIZE + IM::TN_FF1) v = QFf0::element_t(C + conv_ff0(), k - IM::TC_SIZE);
+      else v = QFf1::element_t(C + conv_ff1(), k - IM::TC_SIZE - IM::TN_FF1);
+    } else {
+      v = QHead::element_t(P + L.head, idx - IM::headT(num_convs));
     }
     img[idx] = v;
   }
@@ -350,10 +365,15 @@ __global__ __launch_bounds__(TPB) void conv_quad_kernel(ConvQArgs a) {
 }
 
 // ------------------------------------------------------------------ node update
+// mask0 / mask1: optional dropout masks [N][20] = 16 scalar-channel + 4 vector-channel
+// factors (0 or 1/(1-p); a vector channel's xyz share one factor, gvp_layers.py:187-198),
+// applied to dh before the first residual and to the feed-forward output before the second.
 struct NodeQArgs {
   const float* img_node; const float* img_head;
   const float* h; const float* dh; int64_t N; float* h_out; float* out;
+  const float* mask0; const float* mask1;
 };
+constexpr int MROW = NS + NV;
 
 template <bool HEAD>
 __global__ __launch_bounds__(TPB) void node_quad_kernel(NodeQArgs a) {
@@ -365,12 +385,23 @@ __global__ __launch_bounds__(TPB) void node_quad_kernel(NodeQArgs a) {
   const bool active = n < a.N;
   f4 s[1] = {{0.f, 0.f, 0.f, 0.f}};
   float v[3][1] = {{0.f}, {0.f}, {0.f}};
+  f4 m1s = {1.f, 1.f, 1.f, 1.f};
+  float m1v = 1.f;
   if (active) {                                  // row loads fly while the image is staged
     const float* hr = a.h + n * ROW;
     const float* dr = a.dh + n * ROW;
-    s[0] = *reinterpret_cast<const f4*>(hr + 4 * g) + *reinterpret_cast<const f4*>(dr + 4 * g);
+    f4 ds = *reinterpret_cast<const f4*>(dr + 4 * g);
+    float dv[3] = {dr[NS + 3 * g], dr[NS + 3 * g + 1], dr[NS + 3 * g + 2]};
+    if (a.mask0) {
+      ds *= *reinterpret_cast<const f4*>(a.mask0 + n * MROW + 4 * g);
+      const float mv = a.mask0[n * MROW + NS + g];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) v[p][0] = hr[NS + 3 * g + p] + dr[NS + 3 * g + p];
+      for (int p = 0; p < 3; ++p) dv[p] *= mv;
+    }
+    if (a.mask1) { m1s = *reinterpret_cast<const f4*>(a.mask1 + n * MROW + 4 * g); m1v = a.mask1[n * MROW + NS + g]; }
+    s[0] = *reinterpret_cast<const f4*>(hr + 4 * g) + ds;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) v[p][0] = hr[NS + 3 * g + p] + dv[p];
   }
   stage_slice<IM::ND_SIZE>(lds, a.img_node, threadIdx.x);
   if (HEAD) stage_slice<IM::HD_SIZE>(lds + IM::ND_SIZE, a.img_head, threadIdx.x);
@@ -400,9 +431,9 @@ __global__ __launch_bounds__(TPB) void node_quad_kernel(NodeQArgs a) {
       QFf1::Cache c[1];
       QFf1::forward<1>(lds + IM::ND_FF1, lane, zt, bs, bv, s2, v2, c);
     }
-    s[0] += s2[0][0];
+    s[0] += s2[0][0] * m1s;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) v[p][0] += v2[0][p][0];
+    for (int p = 0; p < 3; ++p) v[p][0] += v2[0][p][0] * m1v;
   }
   ln_quad<NS, NV>(lds + IM::ND_LN1, lane, s, v);
   if (!HEAD) {
@@ -444,6 +475,8 @@ void offsets_impl(int num_convs, QuadOffsets* o) {
   typedef Image<NTN, NTE> IM;
   o->emb = IM::emb(); o->conv0 = IM::conv(0); o->node0 = IM::node(0); o->layer_stride = IM::CV_SIZE + IM::ND_SIZE;
   o->head = IM::head(num_convs); o->total = IM::total(num_convs);
+  o->embT = IM::embT(num_convs); o->convT0 = IM::convT(num_convs, 0); o->nodeT0 = IM::nodeT(num_convs, 0);
+  o->layerT_stride = IM::TC_SIZE + IM::TN_SIZE; o->headT = IM::headT(num_convs);
 }
 
 #define DISPATCH_NT(NTN_, NTE_, CALL)                       \
@@ -516,8 +549,8 @@ int conv(int nt_edge, const float* img, const float* h, const float* e_s, const 
 }
 
 int node_update(const float* img_node, const float* img_head, const float* h, const float* dh, int64_t N,
-                int with_head, float* h_out, float* out, hipStream_t st) {
-  NodeQArgs a{img_node, img_head, h, dh, N, h_out, out};
+                int with_head, float* h_out, float* out, const float* mask0, const float* mask1, hipStream_t st) {
+  NodeQArgs a{img_node, img_head, h, dh, N, h_out, out, mask0, mask1};
   const dim3 grid((unsigned)((N + WPB * TILE - 1) / (WPB * TILE)));
   if (with_head) hipLaunchKernelGGL(node_quad_kernel<true>, grid, dim3(TPB), 0, st, a);
   else hipLaunchKernelGGL(node_quad_kernel<false>, grid, dim3(TPB), 0, st, a);

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 2
+#define CGVP_ABI_VERSION 3
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
@@ -133,6 +133,59 @@ int cgvp_node_update_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const
                          const float* image, int32_t layer, const float* h, const float* dh,
                          int64_t num_nodes, int32_t with_head, float* h_out, float* out,
                          void* stream);
+
+/* Training-mode variant of cgvp_node_update_fwd (MFMA kernels only): `mask0` /
+ * `mask1` are the dropout masks of gvp_layers.Dropout (gvp_layers.py:187-219) for
+ * dropout[0] (on dh) and dropout[1] (on the feed-forward output), one row
+ * [16 scalar factors | 4 vector-channel factors] per node, each 0 or 1/(1-p);
+ * either may be NULL (= no dropout). */
+int cgvp_node_update_fwd_train(const cgvp_dims* dims, const cgvp_layout* layout, const float* image,
+                               int32_t layer, const float* h, const float* dh, const float* mask0,
+                               const float* mask1, int64_t num_nodes, int32_t with_head, float* h_out,
+                               float* out, void* stream);
+
+/* ---------------------------------------------------------------- BACKWARD
+ * Autograd of the three forward stages (what torch.autograd derives from
+ * gvp_layers.py / protein_gnn.py in the reference).  Each call recomputes its
+ * stage from the saved stage INPUTS (h_l, dh_l, raw features) and
+ *   - writes data gradients to the given buffers,
+ *   - ADDS weight gradients into `grad_params`, an arena of the parameter layout
+ *     (zero it once per backward pass).  `workspace` is scratch of
+ *     cgvp_bwd_workspace_floats() floats (per-workgroup partial blocks, summed in a
+ *     fixed order by a reduce kernel: weight gradients are run-to-run reproducible).
+ * MFMA kernels only (image required). */
+int64_t cgvp_bwd_workspace_floats(const cgvp_dims* dims, const cgvp_layout* layout);
+
+/* d/d(h, dh, weights) of cgvp_node_update_fwd[_train].  Upstream gradient: with
+ * the head, g_out [N][64]; otherwise the SUM of up to three [N][28] buffers
+ * g_up0..2 (NULL entries skipped).  Writes g_dh [N][28] (= mask0 * d h) and, when
+ * g_h != NULL, g_h [N][28] (the residual path; equals g_dh without dropout). */
+int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image,
+                         int32_t layer, const float* h, const float* dh, const float* mask0,
+                         const float* mask1, const float* g_out, const float* g_up0,
+                         const float* g_up1, const float* g_up2, int64_t num_nodes,
+                         int32_t with_head, float* g_dh, float* g_h, float* grad_params,
+                         float* workspace, void* stream);
+
+/* d/d(h, weights) of cgvp_conv_fwd given g_dh = d(loss)/d(dh).  Gradients w.r.t.
+ * the node rows arrive in two buffers that the consumer sums: g_src [N][28]
+ * (scatter over the unsorted sources; float atomics; zeroed by this call) and
+ * g_dst [N][28] (segmented sums over the sorted targets; every row written).
+ * Raw edge features receive no gradient. */
+int cgvp_conv_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image, int32_t layer,
+                  const float* h, const float* e_s, const float* e_v, const int64_t* etypes,
+                  const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
+                  const int32_t* edst, int64_t num_nodes, int64_t num_edges, int32_t aggr_mean,
+                  const float* g_dh, float* g_src, float* g_dst, float* grad_params,
+                  float* workspace, void* stream);
+
+/* d/d(x_s, x_v, weights) of cgvp_node_embed_fwd; upstream = sum of g_up0..2.
+ * g_x_s [N][17] / g_x_v [N][3][3] may both be NULL (inputs without gradient). */
+int cgvp_node_embed_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image,
+                        const float* x_s, const float* x_v, const int64_t* ntypes,
+                        int64_t num_nodes, const float* g_up0, const float* g_up1,
+                        const float* g_up2, float* g_x_s, float* g_x_v, float* grad_params,
+                        float* workspace, void* stream);
 
 /* One GINEConv + activation of HomoMoleculeGNN_GINE (molecule_gnn.py:254-268,
  * :271-280; PyG GINEConv / MLP restated):

@@ -128,12 +128,23 @@ def gvp_conv(P, pfx, x, edge_index, edge_attr, n_layers=3, aggr="mean",
 
 
 # --------------------------------------------------------------------------- a7
+def _apply_mask(t, mask):
+    """gvp_layers.Dropout with a GIVEN mask row [s factors | v-channel factors]
+    (gvp_layers.py:187-219: a vector channel's xyz share one factor)."""
+    if mask is None:
+        return t
+    ns = t[0].shape[1]
+    return t[0] * mask[:, :ns], t[1] * mask[:, ns:].unsqueeze(-1)
+
+
 def gvp_conv_layer(P, pfx, x, edge_index, edge_attr, n_message=3, n_feedforward=2,
-                   aggr="mean", activations=("relu", "sigmoid"), vector_gate=False):
-    """gvp_layers.py:366-415, eval mode (dropout = identity, :192-193),
-    without the autoregressive / node_mask branches."""
+                   aggr="mean", activations=("relu", "sigmoid"), vector_gate=False, masks=(None, None)):
+    """gvp_layers.py:366-415 without the autoregressive / node_mask branches.
+    Eval mode by default (dropout = identity, :192-193); `masks` supplies the two
+    dropout masks explicitly to check the training kernels."""
     nv = x[1].shape[1]
     dh = gvp_conv(P, pfx + "conv.", x, edge_index, edge_attr, n_message, aggr, activations, vector_gate)
+    dh = _apply_mask(dh, masks[0])
     x = gvp_layernorm(P, pfx + "norm.0.", (x[0] + dh[0], x[1] + dh[1]), nv)     # :407
     h = x
     hv = nv
@@ -145,12 +156,13 @@ def gvp_conv_layer(P, pfx, x, edge_index, edge_attr, n_message=3, n_feedforward=
             vo = nv
         h = gvp(P, f"{pfx}ff_func.{l}.", h, hv, vo, sa, va, vector_gate)
         hv = vo
+    h = _apply_mask(h, masks[1])
     return gvp_layernorm(P, pfx + "norm.1.", (x[0] + h[0], x[1] + h[1]), nv)    # :410
 
 
 # --------------------------------------------------------------------------- a8/a9
 def protein_lba_forward(P, x, edge_index, ntypes, etypes, eattr, num_ntypes=20, num_etypes=1,
-                        num_convs=2, aggr="sum", pfx="", return_stages=False):
+                        num_convs=2, aggr="sum", pfx="", return_stages=False, masks=None):
     """protein_gnn.py:361-388 (VectorProteinGNN_LBAModel.forward), eval mode.
 
     One-hot node / edge types are concatenated IN FRONT of the scalar features
@@ -173,7 +185,8 @@ def protein_lba_forward(P, x, edge_index, ntypes, etypes, eattr, num_ntypes=20, 
     stages["node_embed"] = h
     stages["edge_embed"] = e
     for l in range(num_convs):                                                  # :379-380
-        h = gvp_conv_layer(P, f"{pfx}conv_list.{l}.", h, edge_index, e, 3, 2, aggr, ("relu", None), True)
+        h = gvp_conv_layer(P, f"{pfx}conv_list.{l}.", h, edge_index, e, 3, 2, aggr, ("relu", None), True,
+                           masks[l] if masks is not None else (None, None))
         stages[f"conv{l}"] = h
     h = gvp_layernorm(P, pfx + "gvp_norm_before_scalar.", h, hv)                # :385
     out = gvp(P, pfx + "gvp_to_scalar.", h, hv, 0, "relu", None, True)          # :386

@@ -1,0 +1,150 @@
+"""GPU parity of the hand-written BACKWARD kernels (through the nn.Module
+boundary and torch.autograd): reference golden gradients, oracle autograd on
+other shapes / aggregation / depth, dropout with pinned masks."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import davis_synth as ds
+from conftest import GOLDEN, rel_err
+from gvp_hip import arena
+from oracle import gvp_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = torch.from_numpy
+
+
+def _to(d, dev=DEV):
+    return {k: (tuple(t.to(dev) for t in v) if isinstance(v, tuple) else v.to(dev)) for k, v in d.items()}
+
+
+def _encoder(state=None, num_convs=2, aggr="sum", dropout=0.2, seed=None):
+    from models.protein_gnn import SelectableProteinModelWrapper
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))["protein_gnn_kwargs"]
+    kw = dict(kw, num_convs=num_convs, aggr=aggr, dropout_rate=dropout)
+    for k in ("in_channels", "edge_dim", "hidden_channels", "edge_hidden_channels"):
+        kw[k] = tuple(kw[k])
+    if seed is not None:
+        torch.manual_seed(seed)
+    m = SelectableProteinModelWrapper(**kw)
+    if state is not None:
+        m.load_state_dict({"gnn_model." + k: v for k, v in state.items()}, strict=False)
+    return m.to(DEV)
+
+
+def _check_grads(model, ref_grads, tol=2e-4):
+    """max-abs error of every weight gradient relative to the largest gradient of
+    its own tensor, with a floor tied to the global gradient scale (gradients that
+    are analytically zero are pure rounding noise)."""
+    scale = max(float(v.abs().max()) for v in ref_grads.values())
+    checked = 0
+    for name, p in model.gnn_model.named_parameters():
+        if not p.numel():
+            continue
+        ref = ref_grads[name]
+        err = float((p.grad.cpu() - ref).abs().max())
+        assert err <= tol * float(ref.abs().max()) + 2e-6 * scale, (name, err, float(ref.abs().max()))
+        checked += 1
+    return checked
+
+
+def test_backward_golden(lba_small, protein_params):
+    """Gradients produced by the reference's own autograd (pretrained weights)."""
+    g = lba_small
+    model = _encoder(protein_params).eval()
+    xs, xv = T(g["x_s"]).to(DEV).requires_grad_(), T(g["x_v"]).to(DEV).requires_grad_()
+    out = model((xs, xv), T(g["edge_index"]).to(DEV), T(g["ntypes"]).to(DEV), T(g["etypes"]).to(DEV),
+                eattr=(T(g["e_s"]).to(DEV), T(g["e_v"]).to(DEV)), batch=T(g["batch"]).to(DEV))
+    assert rel_err(out, g["out"]) < 2e-5
+    (out * T(g["r"]).to(DEV)).sum().backward()
+    ref = {k[2:]: T(v) for k, v in g.items() if k.startswith("g_")}
+    assert _check_grads(model, ref) >= 60
+    assert rel_err(xs.grad, g["gin_x_s"]) < 2e-4
+    assert rel_err(xv.grad, g["gin_x_v"]) < 2e-4
+
+
+@pytest.mark.parametrize("case", ["c1_davis16_sum", "knn_mean", "depth4_ragged"])
+def test_backward_vs_oracle_autograd(protein_params, case):
+    if case == "c1_davis16_sum":
+        gb, nc, aggr, state = ds.protein_batch(16, 1), 2, "sum", protein_params
+    elif case == "knn_mean":
+        gb, nc, aggr, state = ds.protein_batch(2, 2, length=150, thresh=20, thresh_type="num"), 2, "mean", protein_params
+    else:
+        gb, nc, aggr, state = ds.protein_batch(4, 3, lengths=[1, 17, 64, 33], thresh=7.0), 4, "sum", None
+    model = _encoder(state, nc, aggr, seed=5).eval()
+    d = ds.to_torch(gb)
+    P = {k: v.detach().cpu().clone().requires_grad_(v.numel() > 0) for k, v in model.gnn_model.state_dict().items()}
+    xs, xv = d["x"][0].clone().requires_grad_(), d["x"][1].clone().requires_grad_()
+    ref_out = O.protein_lba_forward(P, (xs, xv), d["edge_index"], d["ntypes"], d["etypes"], d["eattr"],
+                                    num_convs=nc, aggr=aggr)
+    r = torch.randn(ref_out.shape, generator=torch.Generator().manual_seed(3))
+    (ref_out * r).sum().backward()
+    dd = _to(d)
+    gxs, gxv = dd["x"][0].clone().requires_grad_(), dd["x"][1].clone().requires_grad_()
+    out = model((gxs, gxv), dd["edge_index"], dd["ntypes"], dd["etypes"], eattr=dd["eattr"])
+    assert rel_err(out, ref_out) < 2e-5
+    (out * r.to(DEV)).sum().backward()
+    _check_grads(model, {k: v.grad for k, v in P.items() if v.numel()})
+    assert rel_err(gxs.grad, xs.grad) < 2e-4 and rel_err(gxv.grad, xv.grad) < 2e-4
+
+
+def test_weights_only_and_accumulation(protein_params):
+    """No input gradients requested; .grad accumulates over two backward passes."""
+    model = _encoder(protein_params).eval()
+    d = _to(ds.to_torch(ds.protein_batch(3, 8, length=60)))
+    for _ in range(2):
+        model(d["x"], d["edge_index"], d["ntypes"], d["etypes"], eattr=d["eattr"]).square().mean().backward()
+    g2 = {n: p.grad.clone() for n, p in model.gnn_model.named_parameters() if p.numel()}
+    model.zero_grad()
+    model(d["x"], d["edge_index"], d["ntypes"], d["etypes"], eattr=d["eattr"]).square().mean().backward()
+    for n, p in model.gnn_model.named_parameters():
+        if p.numel():
+            assert rel_err(g2[n], 2 * p.grad) < 1e-5, n
+
+
+def test_training_dropout_with_pinned_masks(protein_params, monkeypatch):
+    """Training mode: the kernels apply the dropout masks they are given (drawn by
+    torch) exactly like gvp_layers.Dropout; forward and gradients match the oracle
+    run with the same masks."""
+    from gvp_hip import autograd_ops
+    gb = ds.protein_batch(4, 11, length=50)
+    N = gb.num_nodes
+    gen = torch.Generator().manual_seed(0)
+    pinned = [((torch.rand(N, 20, generator=gen) < 0.8).float() / 0.8) for _ in range(4)]
+    it = iter(pinned)
+    monkeypatch.setattr(autograd_ops, "_dropout_mask", lambda n, p, dev: next(it).to(dev))
+    model = _encoder(protein_params).train()
+    d = ds.to_torch(gb)
+    dd = _to(d)
+    out = model(dd["x"], dd["edge_index"], dd["ntypes"], dd["etypes"], eattr=dd["eattr"])
+    r = torch.randn(out.shape, generator=torch.Generator().manual_seed(4))
+    (out * r.to(DEV)).sum().backward()
+    P = {k: v.detach().cpu().clone().requires_grad_(v.numel() > 0) for k, v in model.gnn_model.state_dict().items()}
+    ref = O.protein_lba_forward(P, d["x"], d["edge_index"], d["ntypes"], d["etypes"], d["eattr"],
+                                masks=[(pinned[0], pinned[1]), (pinned[2], pinned[3])])
+    assert rel_err(out, ref) < 2e-5
+    (ref * r).sum().backward()
+    _check_grads(model, {k: v.grad for k, v in P.items() if v.numel()})
+    # and the masks torch draws have the right statistics (per node x channel, scale 1/(1-p))
+    monkeypatch.undo()
+    m = autograd_ops._dropout_mask(20000, 0.2, DEV)
+    assert set(np.unique(m.cpu().numpy()).round(4)) == {0.0, 1.25}
+    assert abs(float((m == 0).float().mean()) - 0.2) < 0.01
+
+
+def test_adam_step_moves_the_arena(protein_params):
+    """An optimizer step through the ordinary nn.Module API changes what the kernels compute."""
+    model = _encoder(protein_params).eval()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    d = _to(ds.protein_batch(2, 2, length=40) and ds.to_torch(ds.protein_batch(2, 2, length=40)))
+    before = model(d["x"], d["edge_index"], d["ntypes"], d["etypes"], eattr=d["eattr"]).detach().clone()
+    loss = model(d["x"], d["edge_index"], d["ntypes"], d["etypes"], eattr=d["eattr"]).square().mean()
+    loss.backward()
+    opt.step()
+    after = model(d["x"], d["edge_index"], d["ntypes"], d["etypes"], eattr=d["eattr"]).detach()
+    assert float((after - before).abs().max()) > 1e-4
+    assert float(after.square().mean()) < float(before.square().mean())
