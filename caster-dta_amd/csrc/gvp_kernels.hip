@@ -348,6 +348,7 @@ struct GineArgs {
   int64_t N; int cin; int chid; int cout;
   const float* eps; const float* we; const float* be; const float* w0; const float* b0;
   const float* w1; const float* b1; float slope; float* out;
+  const float* mask;     // optional [N][cout] dropout factors applied after the activation
 };
 
 constexpr int GINE_APB = 4;   // atoms (waves) per block
@@ -409,8 +410,187 @@ __global__ __launch_bounds__(WAVE * GINE_APB) void gine_conv_kernel(GineArgs a) 
     const float* wr = a.w1 + lane * a.chid;
     for (int k = 0; k < a.chid; ++k) y = fmaf(wr[k], tbuf[w][k], y);
     y = y > 0.f ? y : y * a.slope;
+    if (a.mask) y *= a.mask[i * a.cout + lane];
     a.out[i * a.cout + lane] = y;
   }
+}
+
+// ------------------------------------------------------------- GINE backward
+// One wave per target atom (persistent waves loop over atoms), one lane per
+// channel, forward recomputed.  Weight gradients accumulate in REGISTERS (lane o
+// owns row o of nn.lins.1, lane k row k of nn.lins.0, lane c row c of lin) over all
+// the atoms of the wave and are written once, in the layer's state_dict order
+//   eps | nn.lins.0.weight | nn.lins.0.bias | nn.lins.1.weight | nn.lins.1.bias | lin.weight | lin.bias
+// to the wave's slab row (summed by reduce_slab_kernel in a fixed order).
+struct GineBArgs {
+  const float* x; const int64_t* ntypes; const float* eattr; const int64_t* etypes;
+  const int32_t* rowptr; const int32_t* eperm; const int32_t* esrc; int64_t N;
+  const float* eps; const float* we; const float* be; const float* w0; const float* b0;
+  const float* w1; const float* b1; float slope;
+  const float* mask; const float* g_out; float* g_x; float* slab;
+};
+
+template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
+struct GineLay {
+  static constexpr int KE = NET + ED;
+  static constexpr int EPS = 0, W0 = 1, B0 = W0 + CHID * CIN, W1 = B0 + CHID, B1 = W1 + COUT * CHID,
+                       WE = B1 + COUT, BE = WE + CIN * KE, SIZE = BE + CIN;
+};
+
+template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
+__global__ __launch_bounds__(WAVE * GINE_APB) void gine_bwd_kernel(GineBArgs a) {
+  typedef GineLay<CIN, CHID, COUT, NT, NET, ED> LY;
+  constexpr int KE = NET + ED, XW = CIN - NT;
+  __shared__ float hbuf[GINE_APB][WAVE], tbuf[GINE_APB][WAVE], dybuf[GINE_APB][WAVE], dtbuf[GINE_APB][WAVE];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int w = threadIdx.x >> 6;
+  const int wave = blockIdx.x * GINE_APB + w, nwaves = gridDim.x * GINE_APB;
+  float acc_w1[CHID], acc_w0[CIN], acc_wa[ED > 0 ? ED : 1], acc_wt[NET > 0 ? NET : 1];
+  float acc_b1 = 0.f, acc_b0 = 0.f, acc_be = 0.f, acc_eps = 0.f;
+#pragma unroll
+  for (int k = 0; k < CHID; ++k) acc_w1[k] = 0.f;
+#pragma unroll
+  for (int c = 0; c < CIN; ++c) acc_w0[c] = 0.f;
+#pragma unroll
+  for (int k = 0; k < ED; ++k) acc_wa[k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < NET; ++k) acc_wt[k] = 0.f;
+  float wa[ED > 0 ? ED : 1];
+#pragma unroll
+  for (int k = 0; k < ED; ++k) wa[k] = lane < CIN ? a.we[lane * KE + NET + k] : 0.f;
+  const float bias_e = lane < CIN ? a.be[lane] : 0.f;
+  const float eps1 = 1.0f + a.eps[0];
+  auto xcat = [&](int64_t n) -> float {
+    if (lane < NT) return ((int)a.ntypes[n] == lane) ? 1.f : 0.f;
+    return a.x[n * XW + (lane - NT)];
+  };
+  // all waves run the same trip count so the workgroup barriers below line up
+  const int64_t iters = (a.N + nwaves - 1) / nwaves;
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t i = wave + it * nwaves;
+    const bool valid = i < a.N;
+    float xi = 0.f, hval = 0.f;
+    int32_t p0 = 0, p1 = 0;
+    if (valid && lane < CIN) {
+      xi = xcat(i);
+      p0 = a.rowptr[i]; p1 = a.rowptr[i + 1];
+      float agg = 0.f;
+      for (int32_t p = p0; p < p1; ++p) {
+        const int32_t eid = a.eperm[p];
+        float e = bias_e;
+        if (NET > 0) {
+          int et = (int)a.etypes[eid];
+          et = et < 0 ? 0 : (et >= NET ? NET - 1 : et);
+          e += a.we[lane * KE + et];
+        }
+        const float* ea = a.eattr + (int64_t)eid * ED;
+#pragma unroll
+        for (int k = 0; k < ED; ++k) e = fmaf(wa[k], ea[k], e);
+        const float mj = xcat(a.esrc[p]) + e;
+        agg += mj > 0.f ? mj : 0.f;
+      }
+      hval = fmaf(eps1, xi, agg);
+    }
+    hbuf[w][lane] = hval;
+    __syncthreads();
+    float tpre = 0.f;
+    if (valid && lane < CHID) {
+      tpre = a.b0[lane];
+      const float* wr = a.w0 + lane * CIN;
+#pragma unroll 4
+      for (int k = 0; k < CIN; ++k) tpre = fmaf(wr[k], hbuf[w][k], tpre);
+    }
+    tbuf[w][lane] = tpre > 0.f ? tpre : tpre * a.slope;
+    __syncthreads();
+    float dy = 0.f;
+    if (valid && lane < COUT) {
+      float ypre = a.b1[lane];
+      const float* wr = a.w1 + lane * CHID;
+#pragma unroll 4
+      for (int k = 0; k < CHID; ++k) ypre = fmaf(wr[k], tbuf[w][k], ypre);
+      dy = a.g_out[i * COUT + lane] * (ypre > 0.f ? 1.f : a.slope);
+      if (a.mask) dy *= a.mask[i * COUT + lane];
+      acc_b1 += dy;
+#pragma unroll
+      for (int k = 0; k < CHID; ++k) acc_w1[k] = fmaf(dy, tbuf[w][k], acc_w1[k]);
+    }
+    dybuf[w][lane] = dy;
+    __syncthreads();
+    float dtp = 0.f;
+    if (valid && lane < CHID) {
+      float dt = 0.f;
+#pragma unroll 4
+      for (int o = 0; o < COUT; ++o) dt = fmaf(a.w1[o * CHID + lane], dybuf[w][o], dt);
+      dtp = dt * (tpre > 0.f ? 1.f : a.slope);
+      acc_b0 += dtp;
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) acc_w0[c] = fmaf(dtp, hbuf[w][c], acc_w0[c]);
+    }
+    dtbuf[w][lane] = dtp;
+    __syncthreads();
+    if (valid && lane < CIN) {
+      float dh = 0.f;
+#pragma unroll 4
+      for (int k = 0; k < CHID; ++k) dh = fmaf(a.w0[k * CIN + lane], dtbuf[w][k], dh);
+      acc_eps = fmaf(dh, xi, acc_eps);
+      if (a.g_x && lane >= NT) atomicAdd(a.g_x + i * XW + (lane - NT), eps1 * dh);
+      for (int32_t p = p0; p < p1; ++p) {
+        const int32_t eid = a.eperm[p];
+        const int32_t j = a.esrc[p];
+        float e = bias_e;
+        int et = 0;
+        if (NET > 0) {
+          et = (int)a.etypes[eid];
+          et = et < 0 ? 0 : (et >= NET ? NET - 1 : et);
+          e += a.we[lane * KE + et];
+        }
+        const float* ea = a.eattr + (int64_t)eid * ED;
+#pragma unroll
+        for (int k = 0; k < ED; ++k) e = fmaf(wa[k], ea[k], e);
+        const float mj = xcat(j) + e;
+        const float dm = mj > 0.f ? dh : 0.f;
+        acc_be += dm;
+#pragma unroll
+        for (int k = 0; k < NET; ++k) acc_wt[k] += (k == et) ? dm : 0.f;
+#pragma unroll
+        for (int k = 0; k < ED; ++k) acc_wa[k] = fmaf(dm, ea[k], acc_wa[k]);
+        if (a.g_x && lane >= NT) atomicAdd(a.g_x + (int64_t)j * XW + (lane - NT), dm);
+      }
+    }
+    __syncthreads();
+  }
+  float* row = a.slab + (size_t)wave * LY::SIZE;
+  // eps: sum over the lanes of the wave
+  float e = acc_eps;
+  for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off);
+  if (lane == 0) row[LY::EPS] = e;
+  if (lane < CHID) {
+    row[LY::B0 + lane] = acc_b0;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) row[LY::W0 + lane * CIN + c] = acc_w0[c];
+  }
+  if (lane < COUT) {
+    row[LY::B1 + lane] = acc_b1;
+#pragma unroll
+    for (int k = 0; k < CHID; ++k) row[LY::W1 + lane * CHID + k] = acc_w1[k];
+  }
+  if (lane < CIN) {
+    row[LY::BE + lane] = acc_be;
+#pragma unroll
+    for (int k = 0; k < NET; ++k) row[LY::WE + lane * KE + k] = acc_wt[k];
+#pragma unroll
+    for (int k = 0; k < ED; ++k) row[LY::WE + lane * KE + NET + k] = acc_wa[k];
+  }
+}
+
+template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
+int gine_bwd_launch(GineBArgs& a, float* grad_layer, hipStream_t st) {
+  typedef GineLay<CIN, CHID, COUT, NT, NET, ED> LY;
+  int64_t wgs = (a.N + GINE_APB - 1) / GINE_APB;
+  const int G = (int)(wgs < 1 ? 1 : (wgs > 64 ? 64 : wgs));          // <= 256 waves = slab rows
+  hipLaunchKernelGGL((gine_bwd_kernel<CIN, CHID, COUT, NT, NET, ED>), dim3(G), dim3(WAVE * GINE_APB), 0, st, a);
+  quad::reduce_slab(a.slab, G * GINE_APB, LY::SIZE, 0, LY::SIZE, grad_layer, st);
+  return 0;
 }
 
 }  // namespace
@@ -662,7 +842,7 @@ int cgvp_gine_conv_fwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
                        const int64_t* etypes, int32_t num_etypes, int32_t edge_dim,
                        const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc, int64_t N,
                        int64_t E, int32_t cin, int32_t chid, int32_t cout, const cgvp_gine_w* w,
-                       float act_slope, float* out, void* stream) {
+                       float act_slope, const float* mask, float* out, void* stream) {
   if (N < 0 || E < 0 || !w) return CGVP_ERR_BAD_ARG;
   if (num_ntypes < 0 || num_etypes < 0 || edge_dim < 0 || cin <= num_ntypes) return CGVP_ERR_BAD_ARG;
   if (cin > WAVE || chid > WAVE || cout > WAVE || chid < 1 || cout < 1 || num_etypes + edge_dim > GINE_MAXKE)
@@ -671,9 +851,38 @@ int cgvp_gine_conv_fwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
   if (!x || !out || !rowptr || (num_ntypes > 0 && !ntypes)) return CGVP_ERR_BAD_ARG;
   if (E > 0 && (!eperm || !esrc || (edge_dim > 0 && !eattr) || (num_etypes > 0 && !etypes))) return CGVP_ERR_BAD_ARG;
   GineArgs a{x, ntypes, num_ntypes, eattr, etypes, num_etypes, edge_dim, rowptr, eperm, esrc, N, cin,
-             chid, cout, w->eps, w->we, w->be, w->w0, w->b0, w->w1, w->b1, act_slope, out};
+             chid, cout, w->eps, w->we, w->be, w->w0, w->b0, w->w1, w->b1, act_slope, out, mask};
   hipLaunchKernelGGL(gine_conv_kernel, dim3((unsigned)((N + GINE_APB - 1) / GINE_APB)),
                      dim3(WAVE * GINE_APB), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+int64_t cgvp_gine_bwd_workspace_floats(void) { return (int64_t)256 * GineLay<16, 64, 64, 0, 5, 9>::SIZE; }
+
+int cgvp_gine_conv_bwd(const float* x, const int64_t* ntypes, int32_t num_ntypes, const float* eattr,
+                       const int64_t* etypes, int32_t num_etypes, int32_t edge_dim, const int32_t* rowptr,
+                       const int32_t* eperm, const int32_t* esrc, int64_t N, int64_t E, int32_t cin,
+                       int32_t chid, int32_t cout, const cgvp_gine_w* w, float act_slope, const float* mask,
+                       const float* g_out, float* g_x, float* grad_layer, float* workspace, void* stream) {
+  if (N < 0 || E < 0 || !w || !grad_layer || !workspace) return CGVP_ERR_BAD_ARG;
+  if (N == 0) return 0;
+  if (!x || !g_out || !rowptr || (num_ntypes > 0 && !ntypes)) return CGVP_ERR_BAD_ARG;
+  if (E > 0 && (!eperm || !esrc || (edge_dim > 0 && !eattr) || (num_etypes > 0 && !etypes))) return CGVP_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (g_x) {
+    hipError_t err = hipMemsetAsync(g_x, 0, (size_t)N * (cin - num_ntypes) * sizeof(float), st);
+    if (err != hipSuccess) return (int)err;
+  }
+  GineBArgs a{x, ntypes, eattr, etypes, rowptr, eperm, esrc, N, w->eps, w->we, w->be, w->w0, w->b0, w->w1, w->b1,
+              act_slope, mask, g_out, g_x, workspace};
+  // compiled for the two layer shapes of HomoMoleculeGNN_GINE in CASTER-DTA (molecule_gnn.py:240-250)
+  if (cin == 52 && chid == 16 && cout == 16 && num_ntypes == 11 && num_etypes == 5 && edge_dim == 9)
+    gine_bwd_launch<52, 16, 16, 11, 5, 9>(a, grad_layer, st);
+  else if (cin == 16 && chid == 64 && cout == 64 && num_ntypes == 0 && num_etypes == 5 && edge_dim == 9)
+    gine_bwd_launch<16, 64, 64, 0, 5, 9>(a, grad_layer, st);
+  else if (cin == 16 && chid == 16 && cout == 16 && num_ntypes == 0 && num_etypes == 5 && edge_dim == 9)
+    gine_bwd_launch<16, 16, 16, 0, 5, 9>(a, grad_layer, st);       // middle layers of deeper stacks
+  else return CGVP_ERR_UNSUPPORTED_DIMS;
   return launch_status();
 }
 

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcaster_gvp.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class HipLibraryError(RuntimeError):
@@ -63,7 +63,10 @@ _SIGNATURES = {
     "cgvp_node_embed_bwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P,
                                       _P, _P, _P]),
     "cgvp_gine_conv_fwd": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _I64, _I64, _I32, _I32,
-                                     _I32, C.POINTER(GineW), C.c_float, _P, _P]),
+                                     _I32, C.POINTER(GineW), C.c_float, _P, _P, _P]),
+    "cgvp_gine_bwd_workspace_floats": (C.c_int64, []),
+    "cgvp_gine_conv_bwd": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _I64, _I64, _I32, _I32, _I32,
+                                     C.POINTER(GineW), C.c_float, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

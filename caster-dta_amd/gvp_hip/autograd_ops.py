@@ -115,5 +115,79 @@ def lba_encoder(model, params, layout, dims, x_s, x_v, ntypes, e_s, e_v, etypes,
     return _LbaEncoderFn.apply(meta, x_s, x_v, e_s, e_v, *model._arena.params)
 
 
+_GINE_KEYS = ("eps", "w0", "b0", "w1", "b1", "we", "be")     # slab / state_dict order of one GINEConv
+
+
+class _GineEncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, meta, x, eattr, *params):
+        m = meta
+        widths, nl = m["widths"], len(m["widths"]) - 1
+        x, eattr = _f32(x, "x"), _f32(eattr, "eattr")
+        N = int(x.shape[0])
+        ws = [dict(zip(_GINE_KEYS, params[7 * l:7 * l + 7])) for l in range(nl)]
+        hs, masks = [x], []
+        for l in range(nl):
+            mask = None
+            if m["dropout"] > 0 and l < nl - 1:
+                keep = 1.0 - m["dropout"]
+                mask = (torch.rand(N, widths[l + 1], device=x.device) < keep).to(torch.float32).div_(keep)
+            masks.append(mask)
+            first = l == 0
+            hs.append(ops.gine_conv_forward(hs[l], m["ntypes"] if first else None, m["num_ntypes"] if first else 0,
+                                            eattr, m["etypes"], m["num_etypes"], m["csr"], ws[l], widths[l],
+                                            widths[l + 1], widths[l + 1], m["slope"], mask=mask))
+        ctx.meta, ctx.saved = m, (hs, masks, eattr, ws)
+        return hs[-1]
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        m = ctx.meta
+        hs, masks, eattr, ws = ctx.saved
+        widths, nl = m["widths"], len(m["widths"]) - 1
+        csr = m["csr"]
+        N, dev = int(hs[0].shape[0]), hs[0].device
+        f32 = dict(dtype=torch.float32, device=dev)
+        nt = _i64(m["ntypes"], "ntypes")
+        et = _i64(m["etypes"], "etypes")
+        g = _f32(g, "grad_output")
+        wsp = torch.empty(int(L.cgvp_gine_bwd_workspace_floats()), **f32)
+        grads = [None] * (7 * nl)
+        edge_dim = int(eattr.shape[1])
+        with torch.cuda.device(dev):
+            for l in reversed(range(nl)):
+                first = l == 0
+                cin, cout = widths[l], widths[l + 1]
+                w = {k: _f32(v, k) for k, v in ws[l].items()}
+                sizes = [w[k].numel() for k in _GINE_KEYS]
+                glayer = torch.zeros(sum(sizes), **f32)
+                need_x = (not first) or ctx.needs_input_grad[1]
+                g_x = torch.empty(N, cin - (m["num_ntypes"] if first else 0), **f32) if need_x else None
+                gw = _lib.GineW(**{k: v.data_ptr() for k, v in w.items()})
+                rc = L.cgvp_gine_conv_bwd(_ptr(hs[l]), _ptr(nt if first else None), m["num_ntypes"] if first else 0,
+                                          _ptr(eattr), _ptr(et), m["num_etypes"], edge_dim, _ptr(csr.rowptr),
+                                          _ptr(csr.eperm), _ptr(csr.esrc), N, csr.num_edges, cin, cout, cout,
+                                          C.byref(gw), float(m["slope"]), _ptr(masks[l]), _ptr(g), _ptr(g_x),
+                                          _ptr(glayer), _ptr(wsp), _stream())
+                _lib.check(rc, "cgvp_gine_conv_bwd")
+                off = 0
+                for j, k in enumerate(_GINE_KEYS):
+                    grads[7 * l + j] = glayer[off:off + sizes[j]].view(ws[l][k].shape)
+                    off += sizes[j]
+                g = g_x
+        return (None, g if ctx.needs_input_grad[1] else None, None) + tuple(grads)
+
+
 def gine_encoder(model, x, ntypes, eattr, etypes, csr, slope, train_dropout):
-    raise NotImplementedError("GINE backward kernels are not wired up yet")
+    """HomoMoleculeGNN_GINE.forward with autograd (and inter-layer dropout when training)."""
+    if eattr.requires_grad:
+        raise NotImplementedError("gradients w.r.t. bond features are not produced by the backward kernels")
+    params = []
+    for conv in model.conv_list:
+        kw = conv.kernel_weights()
+        params += [kw[k] for k in _GINE_KEYS]
+    meta = dict(widths=model._widths, ntypes=ntypes, etypes=etypes, num_ntypes=model.num_ntypes,
+                num_etypes=model.num_etypes, csr=csr, slope=slope,
+                dropout=float(model.dropout_rate) if train_dropout else 0.0)
+    return _GineEncoderFn.apply(meta, x, eattr, *params)

@@ -204,7 +204,7 @@ def lba_encoder_forward(params, layout, dims, num_convs, x_s, x_v, ntypes, e_s, 
     return (out, stages) if return_stages else out
 
 
-def gine_conv_forward(x, ntypes, num_ntypes, eattr, etypes, num_etypes, csr, w, cin, chid, cout, slope):
+def gine_conv_forward(x, ntypes, num_ntypes, eattr, etypes, num_etypes, csr, w, cin, chid, cout, slope, mask=None):
     """One GINEConv + activation (molecule_gnn.py:260-266).  `w` maps the
     cgvp_gine_w field names to contiguous fp32 CUDA tensors."""
     L = _lib.lib()
@@ -222,6 +222,6 @@ def gine_conv_forward(x, ntypes, num_ntypes, eattr, etypes, num_etypes, csr, w, 
     with torch.cuda.device(x.device):
         rc = L.cgvp_gine_conv_fwd(_ptr(x), _ptr(nt), num_ntypes, _ptr(eattr), _ptr(et), num_etypes, edge_dim,
                                   _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), N, csr.num_edges,
-                                  cin, chid, cout, C.byref(gw), float(slope), _ptr(out), _stream())
+                                  cin, chid, cout, C.byref(gw), float(slope), _ptr(mask), _ptr(out), _stream())
     _lib.check(rc, "cgvp_gine_conv_fwd")
     return out

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 3
+#define CGVP_ABI_VERSION 4
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
@@ -210,7 +210,23 @@ int cgvp_gine_conv_fwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
                        int32_t edge_dim, const int32_t* rowptr, const int32_t* eperm,
                        const int32_t* esrc, int64_t num_nodes, int64_t num_edges, int32_t cin,
                        int32_t chid, int32_t cout, const cgvp_gine_w* w, float act_slope,
-                       float* out, void* stream);
+                       const float* mask, float* out, void* stream);
+
+/* Backward of cgvp_gine_conv_fwd.  `mask` (optional, [N][cout]) is the dropout
+ * mask molecule_gnn.py:262 applies to the layer output during training (also an
+ * optional argument of the forward).  g_out [N][cout] -> g_x [N][cin - num_ntypes]
+ * (NULL to skip; zeroed here, filled with float atomics) and the layer's weight
+ * gradients ADDED into `grad_layer` in state_dict order
+ *   eps | nn.lins.0.weight | nn.lins.0.bias | nn.lins.1.weight | nn.lins.1.bias | lin.weight | lin.bias.
+ * Compiled for the CASTER-DTA layer shapes (52,16,16), (16,64,64), (16,16,16)
+ * with 11 / 0 atom types, 5 bond types, 9 bond features. */
+int64_t cgvp_gine_bwd_workspace_floats(void);
+int cgvp_gine_conv_bwd(const float* x, const int64_t* ntypes, int32_t num_ntypes, const float* eattr,
+                       const int64_t* etypes, int32_t num_etypes, int32_t edge_dim,
+                       const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
+                       int64_t num_nodes, int64_t num_edges, int32_t cin, int32_t chid, int32_t cout,
+                       const cgvp_gine_w* w, float act_slope, const float* mask, const float* g_out,
+                       float* g_x, float* grad_layer, float* workspace, void* stream);
 
 /* Library self-description (checked by the loader and the CPU test-suite). */
 int cgvp_abi_version(void);
