@@ -39,7 +39,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="davis_b64", choices=sorted(WORKLOADS))
-    ap.add_argument("--mode", default="fwd", choices=["fwd"])
+    ap.add_argument("--mode", default="fwdbwd", choices=["fwd", "fwdbwd"],
+                    help="fwdbwd (default, BASELINE config 2): forward + backward of both encoders incl. all "
+                         "weight gradients; fwd: inference forward only")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--cache-csr", action="store_true", help="reuse the CSR tables across steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -74,6 +76,14 @@ def main():
     ops.CSR_CACHE_ENABLED = bool(args.cache_csr)
     side = torch.cuda.Stream(device=dev)
 
+    train = args.mode == "fwdbwd"
+    enc_params = [p for p in list(model.protein_gnn.parameters()) + list(model.molecule_gnn.parameters()) if p.numel()]
+    for p in model.parameters():
+        p.requires_grad_(train)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    g_res = torch.randn(pb.num_nodes, 64, device=dev, generator=gen)     # upstream gradients of the embeddings
+    g_atm = torch.randn(mb.num_nodes, 64, device=dev, generator=gen)
+
     def step():
         main_s = torch.cuda.current_stream()
         side.wait_stream(main_s)
@@ -81,9 +91,12 @@ def main():
             atoms = model.molecule_gnn(**mdata)
         residues = model.protein_gnn(**pdata)
         main_s.wait_stream(side)
-        return residues, atoms
+        if not train:
+            return residues, atoms
+        # backward of both encoders: every weight gradient (22,507 parameters) is produced
+        return torch.autograd.grad([residues, atoms], enc_params, [g_res, g_atm])
 
-    with torch.no_grad():
+    with torch.set_grad_enabled(train):
         out = step()
         torch.cuda.synchronize()
         graph = None
@@ -122,20 +135,28 @@ def main():
         if rank == 0:
             ops.KERNEL_EVENTS = []
             for _ in range(min(args.steps, 50)):
-                model.protein_gnn(**pdata)
+                step()
             torch.cuda.synchronize()
-            times = [a.elapsed_time(b) * 1e-3 for (_, a, b) in ops.KERNEL_EVENTS]
+            by = {}
+            for (name, a, b) in ops.KERNEL_EVENTS:
+                by.setdefault(name, []).append(a.elapsed_time(b) * 1e-3)
             ops.KERNEL_EVENTS = None
             N, E = pb.num_nodes, pb.num_edges
-            conv_bytes = 224 * N + 156 * E            # per conv launch
-            times.sort()
+            conv_bytes = 224 * N + 156 * E            # algorithmic bytes of one conv launch
+            # dominant kernel = the conv kernel with the largest share of the step (backward when training);
+            # backward counted as 2x the forward bytes (fwd + bwd = 3x forward)
+            name = max(by, key=lambda k: sum(by[k]))
+            times = sorted(by[name])
+            nbytes = conv_bytes * (2 if name == "conv_bwd" else 1)
             avg = sum(times) / len(times)
             peak = 8000.0
-            roof = dict(bound="hbm", achieved=round(conv_bytes / avg / 1e9, 1), peak=peak, unit="GB/s",
-                        frac=round(conv_bytes / avg / 1e9 / peak, 4), traffic=None,
-                        kernel="conv_quad_kernel" if ops.VARIANT == "mfma" else "conv_fwd_kernel",
+            kname = {"conv_fwd": "conv_quad_kernel" if ops.VARIANT == "mfma" else "conv_fwd_kernel",
+                     "conv_bwd": "conv_bwd_kernel (+ its 2 slab reductions and g_src memset)"}[name]
+            roof = dict(bound="hbm", achieved=round(nbytes / avg / 1e9, 1), peak=peak, unit="GB/s",
+                        frac=round(nbytes / avg / 1e9 / peak, 4), traffic=None, kernel=kname,
                         avg_us=round(avg * 1e6, 2), median_us=round(times[len(times) // 2] * 1e6, 2),
-                        bytes_per_launch=conv_bytes, launches=len(times))
+                        bytes_per_launch=nbytes, launches=len(times),
+                        other={k: round(sum(v) / len(v) * 1e6, 2) for k, v in by.items() if k != name})
 
     pairs_per_step = wl["pairs"] * world
     value = pairs_per_step * args.steps / dt
@@ -164,7 +185,7 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "graph-pairs/sec (Davis-shaped protein+drug), encoders forward",
+            "metric": "graph-pairs/sec (Davis-shaped protein+drug), encoders " + ("fwd+bwd" if train else "forward"),
             "value": round(value, 1), "unit": "graph-pairs/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",

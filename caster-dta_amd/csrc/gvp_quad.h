@@ -177,46 +177,61 @@ __device__ __forceinline__ float row_total(float x) {
   return x;
 }
 
-// LDS row stride (floats) for a [rows][W] operand of the weight-gradient GEMMs:
-// W rounded to 16 and made == 16 (mod 32) so the two 16-lane halves of a
-// ds_read_b32 hit disjoint banks.
-constexpr int wg_stride(int w) { return ((w + 15) / 16) % 2 ? ((w + 15) / 16) * 16 : ((w + 15) / 16) * 16 + 16; }
+// ---- weight gradients on the matrix cores, without leaving registers --------
+// dW[row][col] = sum_items dY[row][item] * X[col][item] reduces over ITEMS, but
+// everything above keeps the item on lane & 15 ("item-on-lane").  An MFMA against
+// a 0/1 selection fragment transposes a group of 4 k-steps (16 slots) exactly:
+//     T[item][n] = sum_g V[item][slot (4T + r, g)] * [n == 4r + g]
+// whose D tile holds, in lane (n, g') register rr, the value of slot
+// (s = 4T + n/4, g = n%4) for item 4g' + rr: "slot-on-lane".  Two such tiles are
+// directly the A and B operands of the item-reduction GEMM (k-step rr <-> items
+// 4g' + rr).  Rows / columns of the result are in slot order and are mapped back
+// to nn.Linear rows / columns by the segment maps when the tile is flushed.
+__device__ __forceinline__ float sel_val(int lane, int r) { return ((lane & 15) == 4 * r + (lane >> 4)) ? 1.f : 0.f; }
 
-// Weight-gradient outer product on the matrix cores:
-//   acc[mt][nt] (rows 16mt + 4g + r, cols 16nt + (lane & 15)) += sum_rows A[row][.] (x) B[row][.]
-// A, B are LDS arrays [4*KS rows][stride]; the rows are the items of the tile
-// (KS = 4) or (plane, item) pairs (KS = 12) -- the reduction index of dW.
-template <int MT, int NT, int KS>
-__device__ __forceinline__ void wgrad(const float* A, int sa, const float* B, int sb, f4 (&acc)[MT][NT], int lane) {
-  const int m = lane & 15, g = lane >> 4;
+template <int NSTEPS>
+__device__ __forceinline__ void transpose_slots(const float (&v)[NSTEPS], f4 (&out)[ceil4(NSTEPS)], int lane) {
+  const float sel[4] = {sel_val(lane, 0), sel_val(lane, 1), sel_val(lane, 2), sel_val(lane, 3)};
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const int row = 4 * ks + g;
-    float a[MT];
+  for (int T = 0; T < ceil4(NSTEPS); ++T) {
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = A[row * sa + 16 * mt + m];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const float b = B[row * sb + 16 * nt + m];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma(a[mt], b, acc[mt][nt]);
-    }
+    for (int r = 0; r < 4; ++r)
+      if (4 * T + r < NSTEPS) acc = mfma(v[4 * T + r], sel[r], acc);
+    out[T] = acc;
   }
 }
 
-// Add a weight-gradient tile grid into a [R][C] row-major LDS/global block.
-template <int MT, int NT>
-__device__ __forceinline__ void wgrad_flush(float* dst, int R, int C, const f4 (&acc)[MT][NT], int lane) {
-  const int m = lane & 15, g = lane >> 4;
+// acc[mt][nt] = sum over the 16 items of the tile of A_T[mt] (x) B_T[nt]
+template <int MT, int NT_>
+__device__ __forceinline__ void outer_items(const f4 (&A)[MT], const f4 (&B)[NT_], f4 (&acc)[MT][NT_]) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+  for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT_; ++nt) acc[mt][nt] = mfma(A[mt][rr], B[nt][rr], acc[mt][nt]);
+}
+
+// Add a slot-ordered weight-gradient tile grid into W-layout block `dst` ([.][LD]).
+// (Padding slots are skipped with a branch: redirecting them to a shared dummy
+// word was measured 2.6x slower -- every lane of every wave serialises on it.)
+template <class RowSegs, class ColSegs, int MT, int NT_>
+__device__ __forceinline__ void flush_slots(float* dst, float* trash, int LD, const f4 (&acc)[MT][NT_], int lane) {
+  const int n = lane & 15, gq_ = lane >> 4;
+#pragma unroll
+  for (int nt = 0; nt < NT_; ++nt) {
+    const int cs = 4 * nt + (n >> 2);
+    const int col = cs < ColSegs::steps ? ColSegs::col(cs, n & 3) : -1;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = 16 * mt + 4 * g + r, col = 16 * nt + m;
-        if (row < R && col < C) atomicAdd(dst + row * C + col, acc[mt][nt][r]);
+        const int m = 4 * gq_ + r, rs = 4 * mt + (m >> 2);
+        const int row = rs < RowSegs::steps ? RowSegs::col(rs, m & 3) : -1;
+        if (row >= 0 && col >= 0) atomicAdd(dst + row * LD + col, acc[mt][nt][r]);
       }
+  }
 }
 
 // ------------------------------------------------------------------ one GVP
@@ -466,38 +481,41 @@ struct GvpQ {
   }
 
   // Weight gradients of this GVP for one tile, added into its arena-layout
-  // gradient block `gblk` (LDS, one per workgroup).  `scr` = this wave's LDS
-  // scratch (>= WG_SCRATCH floats).  type < 0 marks an inactive item.
-  static constexpr int SA1 = wg_stride(SO), SB1 = wg_stride(K), SV = wg_stride(16);
-  static constexpr int WG_SCRATCH_ = 16 * SA1 + 16 * SB1 > 6 * 16 * SV ? 16 * SA1 + 16 * SB1 : 6 * 16 * SV;
-  static constexpr int WG_SCRATCH = WG_SCRATCH_ > 16 * SV + 16 * SA1 ? WG_SCRATCH_ : 16 * SV + 16 * SA1;
-  static __device__ __forceinline__ void weight_grads(float* gblk, float* scr, int lane, int type, bool active,
+  // gradient block `gblk` (LDS, one per workgroup).  Registers and MFMAs only.
+  static constexpr int WG_SCRATCH = 0;
+  static constexpr int NTS = ceil4(NT);                 // k-steps of the one-hot type columns
+  typedef Segs<Seg<P2, 0, (NT > 0 ? NT : 1)>, SSegs, Seg<P2, NT + SI, H>> WsCols;   // [types | scalars | norms]
+  static __device__ __forceinline__ void weight_grads(float* gblk, float* trash, int lane, int type, bool active,
                                                       const float (&bs)[SSTEPS], const float (&bv)[3][VSTEPS],
                                                       const Cache& c, const Grads& gr) {
     const int i = lane & 15, g = lane >> 4;
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
     // ---- dWs = dsp (x) [onehot | s | vn],  dbs = sum dsp
-    float* Abuf = scr;
-    float* Bbuf = scr + 16 * SA1;
-#pragma unroll
-    for (int t = 0; t < OT; ++t) *reinterpret_cast<f4*>(Abuf + i * SA1 + 16 * t + 4 * g) = active ? gr.dsp[t] : f4{0.f, 0.f, 0.f, 0.f};
-    for (int k = g; k < NT; k += 4) Bbuf[i * SB1 + k] = 0.f;
-#pragma unroll
-    for (int s = 0; s < SSTEPS; ++s) { const int col = SSegs::col(s, g); if (col >= 0) Bbuf[i * SB1 + col] = bs[s]; }
-#pragma unroll
-    for (int r = 0; r < HR; ++r) if (4 * r + g < H) Bbuf[i * SB1 + NT + SI + 4 * r + g] = c.vn[r];
-    if (NT > 0 && g == 0 && active) Bbuf[i * SB1 + type] = 1.0f;      // after the zero fill (same wave: in order)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     {
-      constexpr int NKT = (K + 15) / 16;
-      f4 acc[OT][NKT];
+      float a[4 * OT];
 #pragma unroll
-      for (int a = 0; a < OT; ++a)
+      for (int t = 0; t < OT; ++t)
 #pragma unroll
-        for (int b = 0; b < NKT; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
-      wgrad<OT, NKT, 4>(Abuf, SA1, Bbuf, SB1, acc, lane);
-      wgrad_flush<OT, NKT>(gblk + A::ws(NT), SO, K, acc, lane);
+        for (int r = 0; r < 4; ++r) a[4 * t + r] = active ? gr.dsp[t][r] : 0.f;
+      f4 AT[OT];
+      transpose_slots<4 * OT>(a, AT, lane);
+      constexpr int NB = (NT > 0 ? NTS : 1) + SSTEPS + HR;
+      float b[NB];
+#pragma unroll
+      for (int s = 0; s < (NT > 0 ? NTS : 1); ++s) b[s] = (NT > 0 && 4 * s + g == type) ? 1.f : 0.f;
+#pragma unroll
+      for (int s = 0; s < SSTEPS; ++s) b[(NT > 0 ? NTS : 1) + s] = bs[s];
+#pragma unroll
+      for (int r = 0; r < HR; ++r) b[(NT > 0 ? NTS : 1) + SSTEPS + r] = c.vn[r];
+      f4 BT[ceil4(NB)];
+      transpose_slots<NB>(b, BT, lane);
+      f4 acc[OT][ceil4(NB)];
+#pragma unroll
+      for (int x = 0; x < OT; ++x)
+#pragma unroll
+        for (int y = 0; y < ceil4(NB); ++y) acc[x][y] = zero;
+      outer_items<OT, ceil4(NB)>(AT, BT, acc);
+      flush_slots<Segs<Seg<P1, 0, SO>>, WsCols, OT, ceil4(NB)>(gblk + A::ws(NT), trash, K, acc, lane);
     }
 #pragma unroll
     for (int t = 0; t < OT; ++t)
@@ -507,74 +525,59 @@ struct GvpQ {
         if (i == 15) atomicAdd(gblk + A::bs(NT) + 16 * t + 4 * g + r, tot);
       }
     if (VO > 0) {
-      // ---- dWsv = dgate (x) sp, dbsv = sum dgate   (reuses Abuf rows 0..15 as [item][16], Bbuf as [item][SO])
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      float* Ag = scr;                 // [16][SV]: column o = 4r + g
-      float* Bs = scr + 16 * SV;       // [16][SA1]: the pre-activation scalars
+      // ---- dWsv = dgate (x) sp, dbsv = sum dgate
+      float a[VOR], b[4 * OT];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Ag[i * SV + ((4 * r + g) & 15)] = active ? gr.dgate[r] : 0.f;
+      for (int r = 0; r < VOR; ++r) a[r] = active ? gr.dgate[r] : 0.f;
 #pragma unroll
-      for (int t = 0; t < OT; ++t) *reinterpret_cast<f4*>(Bs + i * SA1 + 16 * t + 4 * g) = c.sp[t];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      {
-        f4 acc[1][OT];
+      for (int t = 0; t < OT; ++t)
 #pragma unroll
-        for (int b = 0; b < OT; ++b) acc[0][b] = f4{0.f, 0.f, 0.f, 0.f};
-        wgrad<1, OT, 4>(Ag, SV, Bs, SA1, acc, lane);
-        wgrad_flush<1, OT>(gblk + A::wsv(NT), VO, SO, acc, lane);
-      }
+        for (int r = 0; r < 4; ++r) b[4 * t + r] = c.sp[t][r];
+      f4 AT[1], BT[OT], acc[1][OT];
+      transpose_slots<VOR>(a, AT, lane);
+      transpose_slots<4 * OT>(b, BT, lane);
+#pragma unroll
+      for (int y = 0; y < OT; ++y) acc[0][y] = zero;
+      outer_items<1, OT>(AT, BT, acc);
+      flush_slots<Segs<Seg<P2, 0, (VO > 0 ? VO : 1)>>, Segs<Seg<P1, 0, SO>>, 1, OT>(gblk + A::wsv(NT), trash, SO, acc, lane);
 #pragma unroll
       for (int r = 0; r < VOR; ++r) {
         const float tot = row_total(active ? gr.dgate[r] : 0.f);
         if (i == 15 && 4 * r + g < VO) atomicAdd(gblk + A::bsv(NT) + 4 * r + g, tot);
       }
-    }
-    // ---- dWv = sum_planes dvp (x) vh ;  dWh = sum_planes dvh (x) V_in      ([plane][item][16] operands)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    float* Avp = scr;                    // dvp  [3][16][SV]
-    float* Bvh = scr + 3 * 16 * SV;      // vh   [3][16][SV]
-    if (VO > 0) {
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          Avp[(p * 16 + i) * SV + ((4 * r + g) & 15)] = active ? gr.dvp[p][r] : 0.f;
-          Bvh[(p * 16 + i) * SV + ((4 * r + g) & 15)] = c.vh[p][r];
-        }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      f4 acc[1][1] = {{f4{0.f, 0.f, 0.f, 0.f}}};
-      wgrad<1, 1, 12>(Avp, SV, Bvh, SV, acc, lane);
-      wgrad_flush<1, 1>(gblk + A::wv(NT), VO, H, acc, lane);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-    }
-    {
-      float* Avh = scr;                  // dvh  [3][16][SV]
-      float* Bin = scr + 3 * 16 * SV;    // V_in [3][16][SV] in wh column order
+      // ---- dWv = sum_planes dvp (x) vh
+      f4 accv[1][1] = {{zero}};
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
+        float av[VOR], bh[HR];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Avh[(p * 16 + i) * SV + ((4 * r + g) & 15)] = active ? gr.dvh[p][r] : 0.f;
-        for (int k = g; k < 16; k += 4) Bin[(p * 16 + i) * SV + k] = 0.f;
+        for (int r = 0; r < VOR; ++r) av[r] = active ? gr.dvp[p][r] : 0.f;
+#pragma unroll
+        for (int r = 0; r < HR; ++r) bh[r] = c.vh[p][r];
+        f4 AV[1], BH[1];
+        transpose_slots<VOR>(av, AV, lane);
+        transpose_slots<HR>(bh, BH, lane);
+        outer_items<1, 1>(AV, BH, accv);
       }
+      flush_slots<Segs<Seg<P2, 0, (VO > 0 ? VO : 1)>>, Segs<Seg<P2, 0, H>>, 1, 1>(gblk + A::wv(NT), trash, H, accv, lane);
+    }
+    // ---- dWh = sum_planes dvh (x) V_in
+    {
+      f4 acch[1][1] = {{zero}};
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < 3; ++p) {
+        float ah[HR], bin[VSTEPS];
 #pragma unroll
-        for (int s = 0; s < VSTEPS; ++s) { const int col = VSegs::col(s, g); if (col >= 0) Bin[(p * 16 + i) * SV + col] = bv[p][s]; }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      f4 acc[1][1] = {{f4{0.f, 0.f, 0.f, 0.f}}};
-      wgrad<1, 1, 12>(Avh, SV, Bin, SV, acc, lane);
-      wgrad_flush<1, 1>(gblk, H, VI, acc, lane);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < HR; ++r) ah[r] = active ? gr.dvh[p][r] : 0.f;
+#pragma unroll
+        for (int s = 0; s < VSTEPS; ++s) bin[s] = bv[p][s];
+        f4 AH[1], BI[1];
+        static_assert(VSTEPS <= 4 && HR <= 4, "vector operands fit one slot tile");
+        transpose_slots<HR>(ah, AH, lane);
+        transpose_slots<VSTEPS>(bin, BI, lane);
+        outer_items<1, 1>(AH, BI, acch);
+      }
+      flush_slots<Segs<Seg<P2, 0, H>>, VSegs, 1, 1>(gblk, trash, VI, acch, lane);
     }
   }
 };

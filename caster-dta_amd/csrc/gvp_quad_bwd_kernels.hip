@@ -22,13 +22,35 @@
 
 using namespace gq;
 
+#ifdef CGVP_STAMPS
+__device__ unsigned long long* g_stamp_buf_bwd = nullptr;
+extern "C" int cgvp_debug_set_stamp_buffer_bwd(unsigned long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf_bwd), &buf, sizeof(buf));
+}
+#endif
+
 namespace {
 
 constexpr int WAVE = 64;
 constexpr int WPB = 4;
 constexpr int TPB = WAVE * WPB;
 constexpr int TILE = 16;
+
+#ifdef CGVP_STAMPS     // diagnostic build only, see gvp_quad_kernels.hip
+#define STAMP(slot)                                                                          \
+  do {                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    unsigned long long t_;                                                                   \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    if (g_stamp_buf_bwd && (threadIdx.x & 63) == 0)                                          \
+      g_stamp_buf_bwd[((size_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * 16 + (slot)] = t_;    \
+  } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
 constexpr int MAX_GRID = kBwdMaxGrid;  // persistent workgroups (one slab row each)
+constexpr int ACC_ROWS = 32;           // target nodes a wave owns at most (conv backward accumulator)
 
 template <int NFLOATS>
 __device__ __forceinline__ void stage_slice(float* lds, const float* __restrict__ src, int tid) {
@@ -48,8 +70,8 @@ constexpr int pad4(int x) { return (x + 3) / 4 * 4; }
 
 // LayerNorm parameter gradients of a tile -> [gamma | beta] block in LDS.
 template <int S>
-__device__ __forceinline__ void ln_param_grads(float* blk, int lane, bool active, const f4 (&dgamma)[S / 16],
-                                               const f4 (&dbeta)[S / 16]) {
+__device__ __forceinline__ void ln_param_grads(float* blk, float* trash, int lane, bool active,
+                                               const f4 (&dgamma)[S / 16], const f4 (&dbeta)[S / 16]) {
   const int i = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int t = 0; t < S / 16; ++t)
@@ -81,9 +103,9 @@ struct NodeBArgs {
 };
 
 template <bool HEAD>
-__global__ __launch_bounds__(TPB) void node_bwd_kernel(NodeBArgs a) {
+__global__ __launch_bounds__(TPB, 2) void node_bwd_kernel(NodeBArgs a) {
   typedef Image<0, 0> IM;
-  constexpr int GB = pad4(NODE_BLK + (HEAD ? HEAD_BLK : 0));
+  constexpr int GB = pad4(NODE_BLK + (HEAD ? HEAD_BLK : 0));       // slab row; LDS block has 4 extra floats (trash word)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* f_node = lds;
   float* f_head = f_node + IM::ND_SIZE;
@@ -91,7 +113,8 @@ __global__ __launch_bounds__(TPB) void node_bwd_kernel(NodeBArgs a) {
   float* t_head = t_node + IM::TN_SIZE;
   float* gblk = t_head + (HEAD ? IM::TH_SIZE : 0);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float* scr = gblk + GB + w * NODE_SCR;
+  float* trash = gblk + GB;
+  float* scr = trash;
   stage_slice<IM::ND_SIZE>(f_node, a.img_node, threadIdx.x);
   stage_slice<IM::TN_SIZE>(t_node, a.imgT_node, threadIdx.x);
   if (HEAD) {
@@ -174,12 +197,12 @@ __global__ __launch_bounds__(TPB) void node_bwd_kernel(NodeBArgs a) {
       float d_vo[3][1] = {{0.f}, {0.f}, {0.f}}, d_bs[4], d_bv[3][1];
       QHead::Grads grh;
       QHead::backward(t_head, lane, ch[0], d_o, d_vo, d_bs, d_bv, grh);
-      QHead::weight_grads(gblk + NODE_BLK + HB_GVP, scr, lane, 0, active, bsh[0], bvh[0], ch[0], grh);
+      QHead::weight_grads(gblk + NODE_BLK + HB_GVP, trash, lane, 0, active, bsh[0], bvh[0], ch[0], grh);
       f4 dws[1] = {f4{d_bs[0], d_bs[1], d_bs[2], d_bs[3]}};
       float dwv[3][1] = {{d_bv[0][0]}, {d_bv[1][0]}, {d_bv[2][0]}};
       f4 dga[1], dbe[1];
       ln_quad_bwd<NS, NV>(f_head + IM::HD_LN, lane, o1, ov1, dws, dwv, dga, dbe);
-      ln_param_grads<NS>(gblk + NODE_BLK + HB_LN, lane, active, dga, dbe);
+      ln_param_grads<NS>(gblk + NODE_BLK + HB_LN, trash, lane, active, dga, dbe);
       gs[0] = dws[0];
 #pragma unroll
       for (int p = 0; p < 3; ++p) gv[p][0] = dwv[p][0];
@@ -199,7 +222,7 @@ __global__ __launch_bounds__(TPB) void node_bwd_kernel(NodeBArgs a) {
     {
       f4 dga[1], dbe[1];
       ln_quad_bwd<NS, NV>(f_node + IM::ND_LN1, lane, z, zv, gs, gv, dga, dbe);      // gs/gv := d z
-      ln_param_grads<NS>(gblk + NB_LN1, lane, active, dga, dbe);
+      ln_param_grads<NS>(gblk + NB_LN1, trash, lane, active, dga, dbe);
     }
     float d_hs[16], d_hv[3][2];
     {
@@ -207,7 +230,7 @@ __global__ __launch_bounds__(TPB) void node_bwd_kernel(NodeBArgs a) {
       float d_vo[3][1] = {{gv[0][0] * m1v}, {gv[1][0] * m1v}, {gv[2][0] * m1v}};
       QFf1::Grads gr1;
       QFf1::backward(t_node + IM::TN_FF1, lane, c1[0], d_so, d_vo, d_hs, d_hv, gr1);
-      QFf1::weight_grads(gblk + NB_FF1, scr, lane, 0, active, bs1[0], bv1[0], c1[0], gr1);
+      QFf1::weight_grads(gblk + NB_FF1, trash, lane, 0, active, bs1[0], bv1[0], c1[0], gr1);
     }
     {
       f4 d_so[4];
@@ -216,7 +239,7 @@ __global__ __launch_bounds__(TPB) void node_bwd_kernel(NodeBArgs a) {
       float d_ys[4], d_yv[3][1];
       QFf0::Grads gr0;
       QFf0::backward(t_node + IM::TN_FF0, lane, c0[0], d_so, d_hv, d_ys, d_yv, gr0);
-      QFf0::weight_grads(gblk + NB_FF0, scr, lane, 0, active, bs0[0], bv0[0], c0[0], gr0);
+      QFf0::weight_grads(gblk + NB_FF0, trash, lane, 0, active, bs0[0], bv0[0], c0[0], gr0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) gs[0][r] += d_ys[r];
 #pragma unroll
@@ -225,7 +248,7 @@ __global__ __launch_bounds__(TPB) void node_bwd_kernel(NodeBArgs a) {
     {
       f4 dga[1], dbe[1];
       ln_quad_bwd<NS, NV>(f_node + IM::ND_LN0, lane, x0, xv0, gs, gv, dga, dbe);    // gs/gv := d (h + dh)
-      ln_param_grads<NS>(gblk + NB_LN0, lane, active, dga, dbe);
+      ln_param_grads<NS>(gblk + NB_LN0, trash, lane, active, dga, dbe);
     }
     if (active) {               // d h (residual path) and d dh = mask0 * d h (equal without dropout)
       if (a.g_h) {
@@ -253,9 +276,7 @@ struct ConvBlk {
   static constexpr int M0 = E_SIZE, M1 = M0 + LMsg0::size(0), M2 = M1 + LMsg::size(0), SIZE = pad4(M2 + LMsg::size(0));
 };
 template <int NTE>
-constexpr int conv_scr() {
-  return cmax(cmax(QEdge<NTE>::WG_SCRATCH, QMsg0::WG_SCRATCH), cmax(QMsg1::WG_SCRATCH, QMsg2::WG_SCRATCH));
-}
+constexpr int conv_scr() { return 512; }   // per-wave LDS scratch: [16][28] gradient rows + 16 source ids (g_src transpose)
 
 struct ConvBArgs {
   const float* img; const float* imgT;
@@ -265,22 +286,25 @@ struct ConvBArgs {
 };
 
 template <int NTE>
-__global__ __launch_bounds__(TPB) void conv_bwd_kernel(ConvBArgs a) {
+__global__ __launch_bounds__(TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
   typedef Image<0, NTE> IM;
   typedef ConvBlk<NTE> B;
-  constexpr int ACC = WAVE * ROW, SCR = conv_scr<NTE>();
+  constexpr int ACC = ACC_ROWS * ROW, SCR = conv_scr<NTE>();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* img = lds;
   float* imgT = img + IM::CV_SIZE;
   float* gblk = imgT + IM::TC_SIZE;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float* acc = gblk + B::SIZE + w * (ACC + SCR);
+  float* trash = gblk + B::SIZE;
+  float* acc = trash + 4 + w * (ACC + SCR);
   float* scr = acc + ACC;
   stage_slice<IM::CV_SIZE>(img, a.img, threadIdx.x);
   stage_slice<IM::TC_SIZE>(imgT, a.imgT, threadIdx.x);
   for (int k = threadIdx.x; k < B::SIZE; k += TPB) gblk[k] = 0.f;
   for (int k = lane; k < ACC; k += WAVE) acc[k] = 0.f;
+  STAMP(0);
   __syncthreads();
+  STAMP(1);
 
   const int i = lane & 15, g = lane >> 4;
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -329,6 +353,7 @@ __global__ __launch_bounds__(TPB) void conv_bwd_kernel(ConvBArgs a) {
           for (int d = 0; d < 3; ++d) d_mv[d] *= sc;
         }
       }
+      STAMP(2);
       // ---- recompute the forward of the tile, keeping every GVP's cache
       float bse[1][8], bve[1][3][1];
 #pragma unroll
@@ -364,6 +389,7 @@ __global__ __launch_bounds__(TPB) void conv_bwd_kernel(ConvBArgs a) {
       for (int d = 0; d < 3; ++d) bv2[0][d][0] = v2[0][d][0];
       QMsg2::forward<1>(img + IM::CV_M2, lane, zt, b2, bv2, s3, v3, c2);
 
+      STAMP(3);
       // ---- backward through the three message GVPs
       float d_b[4], d_bv[3][1];
       {
@@ -371,14 +397,14 @@ __global__ __launch_bounds__(TPB) void conv_bwd_kernel(ConvBArgs a) {
         float d_vo[3][1] = {{d_mv[0]}, {d_mv[1]}, {d_mv[2]}};
         QMsg2::Grads gr;
         QMsg2::backward(imgT + IM::TC_M2, lane, c2[0], d_so, d_vo, d_b, d_bv, gr);
-        QMsg2::weight_grads(gblk + B::M2, scr, lane, 0, active, b2[0], bv2[0], c2[0], gr);
+        QMsg2::weight_grads(gblk + B::M2, trash, lane, 0, active, b2[0], bv2[0], c2[0], gr);
       }
       {
         f4 d_so[1] = {f4{d_b[0], d_b[1], d_b[2], d_b[3]}};
         float d_vo[3][1] = {{d_bv[0][0]}, {d_bv[1][0]}, {d_bv[2][0]}};
         QMsg1::Grads gr;
         QMsg1::backward(imgT + IM::TC_M1, lane, c1[0], d_so, d_vo, d_b, d_bv, gr);
-        QMsg1::weight_grads(gblk + B::M1, scr, lane, 0, active, b1[0], bv1[0], c1[0], gr);
+        QMsg1::weight_grads(gblk + B::M1, trash, lane, 0, active, b1[0], bv1[0], c1[0], gr);
       }
       float d_b0[16], d_bv0[3][3];
       {
@@ -386,28 +412,48 @@ __global__ __launch_bounds__(TPB) void conv_bwd_kernel(ConvBArgs a) {
         float d_vo[3][1] = {{d_bv[0][0]}, {d_bv[1][0]}, {d_bv[2][0]}};
         QMsg0::Grads gr;
         QMsg0::backward(imgT + IM::TC_M0, lane, c0[0], d_so, d_vo, d_b0, d_bv0, gr);
-        QMsg0::weight_grads(gblk + B::M0, scr, lane, 0, active, b0[0], bv0[0], c0[0], gr);
+        QMsg0::weight_grads(gblk + B::M0, trash, lane, 0, active, b0[0], bv0[0], c0[0], gr);
       }
+      STAMP(4);
       // ---- edge embedding: LayerNorm and GVP (weight gradients only; raw edge features get none)
       {
         f4 d_es[2] = {f4{d_b0[4], d_b0[5], d_b0[6], d_b0[7]}, f4{d_b0[8], d_b0[9], d_b0[10], d_b0[11]}};
         float d_ev[3][1] = {{d_bv0[0][2]}, {d_bv0[1][2]}, {d_bv0[2][2]}};
         f4 dga[2], dbe[2];
         ln_quad_bwd<ES, EV>(img + IM::CV_ELN, lane, e_pre[0], ev_pre[0], d_es, d_ev, dga, dbe);
-        ln_param_grads<ES>(gblk + B::E_LN, lane, active, dga, dbe);
+        ln_param_grads<ES>(gblk + B::E_LN, trash, lane, active, dga, dbe);
         float d_in[8], d_inv[3][1];
         typename QEdge<NTE>::Grads gr;
         QEdge<NTE>::backward(imgT + IM::TC_EDGE, lane, ce[0], d_es, d_ev, d_in, d_inv, gr);
-        QEdge<NTE>::weight_grads(gblk + B::E_GVP, scr, lane, et[0], active, bse[0], bve[0], ce[0], gr);
+        QEdge<NTE>::weight_grads(gblk + B::E_GVP, trash, lane, et[0], active, bse[0], bve[0], ce[0], gr);
       }
-      // ---- d h[src]: unsorted sources -> float atomics on the zero-initialised g_src
-      if (active) {
-        float* rj = a.g_src + (int64_t)src * ROW;
+      STAMP(5);
+      // ---- d h[src]: unsorted sources -> float atomics on the zero-initialised g_src.  The rows
+      // are transposed through LDS so that one wave-instruction adds two whole 112-B rows
+      // (lane-per-row atomics run an order of magnitude slower).
+      {
+        float* trow = scr;                          // [16][28]
+        int* tsrc = reinterpret_cast<int*>(scr + TILE * ROW);
+        *reinterpret_cast<f4*>(trow + i * ROW + 4 * g) = f4{d_b0[0], d_b0[1], d_b0[2], d_b0[3]};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(rj + 4 * g + r, d_b0[r]);
+        for (int d = 0; d < 3; ++d) trow[i * ROW + NS + 3 * g + d] = d_bv0[d][0];
+        if (g == 0) tsrc[i] = active ? src : -1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int half = lane / ROW, col = lane - half * ROW;      // lanes 0..27 -> row 2k, 28..55 -> row 2k+1
+        if (half < 2) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) atomicAdd(rj + NS + 3 * g + d, d_bv0[d][0]);
+          for (int k = 0; k < TILE / 2; ++k) {
+            const int r = 2 * k + half;
+            const int sr = tsrc[r];
+            if (sr >= 0) atomicAdd(a.g_src + (int64_t)sr * ROW + col, trow[r * ROW + col]);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
       }
+      STAMP(6);
       // ---- d h[dst]: segmented scan over the sorted targets, owned rows
       {
         float x[7] = {d_b0[12], d_b0[13], d_b0[14], d_b0[15], d_bv0[0][1], d_bv0[1][1], d_bv0[2][1]};
@@ -422,6 +468,7 @@ __global__ __launch_bounds__(TPB) void conv_bwd_kernel(ConvBArgs a) {
         }
       }
     }
+    STAMP(7);
     // flush this group's owned rows and clear the accumulator for the next group
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -431,9 +478,11 @@ __global__ __launch_bounds__(TPB) void conv_bwd_kernel(ConvBArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
   }
+  STAMP(8);
   __syncthreads();
   float* out = a.slab + (size_t)blockIdx.x * B::SIZE;
   for (int k = threadIdx.x; k < B::SIZE; k += TPB) out[k] = gblk[k];
+  STAMP(9);
 }
 
 // ===================================================================== node embed
@@ -457,7 +506,8 @@ __global__ __launch_bounds__(TPB) void embed_bwd_kernel(EmbBArgs a) {
   float* imgT = img + IM::EMB_SIZE;
   float* gblk = imgT + IM::TE_SIZE;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float* scr = gblk + B::SIZE + w * Q::WG_SCRATCH;
+  float* trash = gblk + B::SIZE;
+  float* scr = trash;
   stage_slice<IM::EMB_SIZE>(img, a.img, threadIdx.x);
   stage_slice<IM::TE_SIZE>(imgT, a.imgT, threadIdx.x);
   for (int k = threadIdx.x; k < B::SIZE; k += TPB) gblk[k] = 0.f;
@@ -500,11 +550,11 @@ __global__ __launch_bounds__(TPB) void embed_bwd_kernel(EmbBArgs a) {
     }
     f4 dga[1], dbe[1];
     ln_quad_bwd<NS, NV>(img + IM::EMB_LN, lane, s_pre[0], v_pre[0], gs, gv, dga, dbe);
-    ln_param_grads<NS>(gblk + B::LN, lane, active, dga, dbe);
+    ln_param_grads<NS>(gblk + B::LN, trash, lane, active, dga, dbe);
     float d_bs[Q::SSTEPS], d_bv[3][1];
     typename Q::Grads gr;
     Q::backward(imgT, lane, c[0], gs, gv, d_bs, d_bv, gr);
-    Q::weight_grads(gblk + B::GVP, scr, lane, type[0], active, bs[0], bv[0], c[0], gr);
+    Q::weight_grads(gblk + B::GVP, trash, lane, type[0], active, bs[0], bv[0], c[0], gr);
     if (active && a.g_x_s) {
 #pragma unroll
       for (int s = 0; s < Q::SSTEPS; ++s) {
@@ -517,19 +567,35 @@ __global__ __launch_bounds__(TPB) void embed_bwd_kernel(EmbBArgs a) {
       }
     }
   }
+  STAMP(8);
   __syncthreads();
   float* out = a.slab + (size_t)blockIdx.x * B::SIZE;
   for (int k = threadIdx.x; k < B::SIZE; k += TPB) out[k] = gblk[k];
+  STAMP(9);
 }
 
-// dst[j] += sum_r slab[r][col0 + j], j < len   (fixed order: deterministic)
-__global__ void reduce_slab_kernel(const float* __restrict__ slab, int rows, int stride, int col0, int len,
-                                   float* __restrict__ dst) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= len) return;
+// dst[j] += sum_r slab[r][col0 + j], j < len.  A block owns 64 columns; its 16
+// row groups each sum rows rg, rg+16, ... (coalesced 256-B reads) and the 16
+// partials are added in a fixed order: deterministic, and ~16 dependent loads per
+// thread instead of `rows`.
+constexpr int RED_COLS = 64, RED_RG = 16;
+__global__ __launch_bounds__(RED_COLS * RED_RG) void reduce_slab_kernel(const float* __restrict__ slab, int rows,
+                                                                        int stride, int col0, int len,
+                                                                        float* __restrict__ dst) {
+  __shared__ float part[RED_RG][RED_COLS];
+  const int c = threadIdx.x & (RED_COLS - 1), rg = threadIdx.x / RED_COLS;
+  const int j = blockIdx.x * RED_COLS + c;
   float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += slab[(size_t)r * stride + col0 + j];
-  dst[j] += s;
+  if (j < len)
+    for (int r = rg; r < rows; r += RED_RG) s += slab[(size_t)r * stride + col0 + j];
+  part[rg][c] = s;
+  __syncthreads();
+  if (rg == 0 && j < len) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < RED_RG; ++k) t += part[k][c];
+    dst[j] += t;
+  }
 }
 
 inline int grid_for(int64_t units) {
@@ -553,7 +619,7 @@ int bwd_block_sizes(int nt_node, int nt_edge, int* emb, int* conv_edge, int* con
 }
 
 int reduce_slab(const float* slab, int rows, int stride, int col0, int len, float* dst, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_slab_kernel, dim3((len + 255) / 256), dim3(256), 0, st, slab, rows, stride, col0, len, dst);
+  hipLaunchKernelGGL(reduce_slab_kernel, dim3((len + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_RG), 0, st, slab, rows, stride, col0, len, dst);
   return 0;
 }
 
@@ -566,12 +632,12 @@ int node_update_bwd(const float* img_node, const float* img_head, const float* i
   const int G = grid_for((N + TILE - 1) / TILE);
   *grid = G;
   if (with_head) {
-    const size_t lds = (size_t)(IM::ND_SIZE + IM::HD_SIZE + IM::TN_SIZE + IM::TH_SIZE + pad4(NODE_BLK + HEAD_BLK) +
+    const size_t lds = (size_t)(IM::ND_SIZE + IM::HD_SIZE + IM::TN_SIZE + IM::TH_SIZE + pad4(NODE_BLK + HEAD_BLK) + 4 +
                                 WPB * NODE_SCR) * sizeof(float);
     hipFuncSetAttribute(reinterpret_cast<const void*>(node_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(node_bwd_kernel<true>, dim3(G), dim3(TPB), lds, st, a);
   } else {
-    const size_t lds = (size_t)(IM::ND_SIZE + IM::TN_SIZE + pad4(NODE_BLK) + WPB * NODE_SCR) * sizeof(float);
+    const size_t lds = (size_t)(IM::ND_SIZE + IM::TN_SIZE + pad4(NODE_BLK) + 4 + WPB * NODE_SCR) * sizeof(float);
     hipFuncSetAttribute(reinterpret_cast<const void*>(node_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(node_bwd_kernel<false>, dim3(G), dim3(TPB), lds, st, a);
   }
@@ -584,7 +650,7 @@ int conv_bwd_impl(ConvBArgs& a, int* grid, hipStream_t st) {
   const int64_t groups = (a.N + a.npw - 1) / a.npw;
   const int G = grid_for(groups);
   *grid = G;
-  const size_t lds = (size_t)(IM::CV_SIZE + IM::TC_SIZE + ConvBlk<NTE>::SIZE + WPB * (WAVE * ROW + conv_scr<NTE>())) * sizeof(float);
+  const size_t lds = (size_t)(IM::CV_SIZE + IM::TC_SIZE + ConvBlk<NTE>::SIZE + 4 + WPB * (ACC_ROWS * ROW + conv_scr<NTE>())) * sizeof(float);
   hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_kernel<NTE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(conv_bwd_kernel<NTE>, dim3(G), dim3(TPB), lds, st, a);
   return 0;
@@ -597,7 +663,7 @@ int conv_bwd(int nt_edge, const float* img, const float* imgT, const float* h, c
   int64_t deg = N > 0 ? (E + N - 1) / N : 1;
   if (deg < 1) deg = 1;
   int npw = (int)((2 * TILE - 2) / deg);
-  npw = npw < 1 ? 1 : (npw > WAVE ? WAVE : npw);
+  npw = npw < 1 ? 1 : (npw > ACC_ROWS ? ACC_ROWS : npw);
   ConvBArgs a{img, imgT, h, e_s, e_v, etypes, rowptr, eperm, esrc, edst, N, npw, mean, g_dh, g_src, g_dst, slab};
   if (nt_edge == 0) return conv_bwd_impl<0>(a, grid, st);
   if (nt_edge == 1) return conv_bwd_impl<1>(a, grid, st);
@@ -609,7 +675,7 @@ int embed_bwd_impl(EmbBArgs& a, int* grid, hipStream_t st) {
   typedef Image<NTN, 0> IM;
   const int G = grid_for((a.N + TILE - 1) / TILE);
   *grid = G;
-  const size_t lds = (size_t)(IM::EMB_SIZE + IM::TE_SIZE + EmbBlk<NTN>::SIZE + WPB * QNode<NTN>::WG_SCRATCH) * sizeof(float);
+  const size_t lds = (size_t)(IM::EMB_SIZE + IM::TE_SIZE + EmbBlk<NTN>::SIZE + 4 + WPB * QNode<NTN>::WG_SCRATCH) * sizeof(float);
   hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel<NTN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(embed_bwd_kernel<NTN>, dim3(G), dim3(TPB), lds, st, a);
   return 0;

@@ -48,9 +48,10 @@ class _LbaEncoderFn(torch.autograd.Function):
             _lib.check(L.cgvp_node_embed_fwd(d, lay, P, I, _ptr(x_s), _ptr(x_v), _ptr(nt), N, _ptr(hs[0]), st),
                        "cgvp_node_embed_fwd")
             for l in range(nc):
-                _lib.check(L.cgvp_conv_fwd(d, lay, P, I, l, _ptr(hs[l]), _ptr(e_s), _ptr(e_v), _ptr(et),
-                                           _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst),
-                                           N, E, 1 if m["mean"] else 0, _ptr(dhs[l]), st), "cgvp_conv_fwd")
+                with ops._timed("conv_fwd"):
+                    _lib.check(L.cgvp_conv_fwd(d, lay, P, I, l, _ptr(hs[l]), _ptr(e_s), _ptr(e_v), _ptr(et),
+                                               _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst),
+                                               N, E, 1 if m["mean"] else 0, _ptr(dhs[l]), st), "cgvp_conv_fwd")
                 last = l == nc - 1
                 _lib.check(L.cgvp_node_update_fwd_train(d, lay, I, l, _ptr(hs[l]), _ptr(dhs[l]), _ptr(masks[l][0]),
                                                         _ptr(masks[l][1]), N, 1 if last else 0,
@@ -91,10 +92,11 @@ class _LbaEncoderFn(torch.autograd.Function):
                                                   _ptr(g_h), _ptr(gparams), _ptr(ws), st), "cgvp_node_update_bwd")
                 g_src = torch.empty(N, ROW, **f32)
                 g_dst = torch.empty(N, ROW, **f32)
-                _lib.check(L.cgvp_conv_bwd(d, lay, I, l, _ptr(hs[l]), _ptr(e_s), _ptr(e_v), _ptr(et),
-                                           _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst), N, E,
-                                           1 if m["mean"] else 0, _ptr(g_dh), _ptr(g_src), _ptr(g_dst),
-                                           _ptr(gparams), _ptr(ws), st), "cgvp_conv_bwd")
+                with ops._timed("conv_bwd"):
+                    _lib.check(L.cgvp_conv_bwd(d, lay, I, l, _ptr(hs[l]), _ptr(e_s), _ptr(e_v), _ptr(et),
+                                               _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst), N, E,
+                                               1 if m["mean"] else 0, _ptr(g_dh), _ptr(g_src), _ptr(g_dst),
+                                               _ptr(gparams), _ptr(ws), st), "cgvp_conv_bwd")
                 ups = (g_h if g_h is not None else g_dh, g_src, g_dst)
             _lib.check(L.cgvp_node_embed_bwd(d, lay, I, _ptr(x_s), _ptr(x_v), _ptr(nt), N, _ptr(ups[0]), _ptr(ups[1]),
                                              _ptr(ups[2]), _ptr(g_x_s), _ptr(g_x_v), _ptr(gparams), _ptr(ws), st),

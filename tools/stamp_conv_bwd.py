@@ -1,0 +1,35 @@
+"""Diagnostic: where does a conv_bwd wave spend its cycles?  Uses the -DCGVP_STAMPS build."""
+import ctypes, os, sys
+import numpy as np, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(REPO, "caster-dta_amd"), REPO]
+from gvp_hip import _lib
+_lib.LIB_PATH = os.path.join(REPO, "caster-dta_amd", "lib", "_stamps", "libcaster_gvp_stamps.so")
+import davis_synth as ds
+import __graft_entry__ as entry
+dev = torch.device("cuda:0")
+model, state = entry._load_model(dev)
+pb = ds.protein_batch(64, 0)
+d = {k: (tuple(t.to(dev) for t in v) if isinstance(v, tuple) else v.to(dev)) for k, v in ds.to_torch(pb).items()}
+h = ctypes.CDLL(_lib.LIB_PATH)
+nwaves = 4096
+buf = torch.zeros(nwaves * 16, dtype=torch.int64, device=dev)
+h.cgvp_debug_set_stamp_buffer_bwd(ctypes.c_void_p(buf.data_ptr()))
+params = [p for p in model.protein_gnn.parameters() if p.numel()]
+for _ in range(3):
+    out = model.protein_gnn(**d)
+    torch.autograd.grad(out, params, torch.ones_like(out))
+torch.cuda.synchronize()
+b = buf.cpu().numpy().reshape(nwaves, 16)
+b = b[b[:, 9] > 0]
+names = {1: "stage + barrier", 2: "gather (last tile)", 3: "fwd recompute", 4: "3 msg GVP bwd + wgrads", 5: "edge LN/GVP bwd + wgrads",
+         6: "g_src atomics", 7: "scan + LDS adds"}
+print("waves stamped:", len(b), "(per-tile segments are those of the wave's LAST tile)")
+prev = 1
+b[:, 1] = b[:, 1]
+print(f"{'stage + barrier':28s} median {np.median(b[:,1]-b[:,0]):8.0f}")
+for s in range(3, 8):
+    dt = b[:, s] - b[:, s - 1]
+    print(f"{names[s]:28s} median {np.median(dt):8.0f} cyc   p90 {np.percentile(dt, 90):8.0f}")
+print(f"{'wave total (all tiles)':28s} median {np.median(b[:,8]-b[:,0]):8.0f} cyc   p90 {np.percentile(b[:,8]-b[:,0], 90):8.0f}")
+print(f"{'final barrier + slab write':28s} median {np.median(b[:,9]-b[:,8]):8.0f}")
