@@ -152,8 +152,15 @@ def main():
             peak = 8000.0
             kname = {"conv_fwd": "conv_quad_kernel" if ops.VARIANT == "mfma" else "conv_fwd_kernel",
                      "conv_bwd": "conv_bwd_kernel (+ its 2 slab reductions and g_src memset)"}[name]
+            # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+            # separate runs, gfx950 correction applied; profiles/r01/pmc_traffic.json) -- same workload only
+            traffic = None
+            pmc = os.path.join(REPO, "profiles", "r01", "pmc_traffic.json")
+            if args.workload == "davis_b64" and os.path.exists(pmc):
+                k = "conv_bwd_kernel" if name == "conv_bwd" else "conv_quad_kernel"
+                traffic = json.load(open(pmc))["kernels"].get(k, {}).get("hbm_bytes_per_launch")
             roof = dict(bound="hbm", achieved=round(nbytes / avg / 1e9, 1), peak=peak, unit="GB/s",
-                        frac=round(nbytes / avg / 1e9 / peak, 4), traffic=None, kernel=kname,
+                        frac=round(nbytes / avg / 1e9 / peak, 4), traffic=traffic, kernel=kname,
                         avg_us=round(avg * 1e6, 2), median_us=round(times[len(times) // 2] * 1e6, 2),
                         bytes_per_launch=nbytes, launches=len(times),
                         other={k: round(sum(v) / len(v) * 1e6, 2) for k, v in by.items() if k != name})
