@@ -40,5 +40,6 @@ int node_embed_bwd(int nt_node, const float* img, const float* imgT, const float
                    const int64_t* ntypes, int64_t N, const float* g_up0, const float* g_up1, const float* g_up2,
                    float* g_x_s, float* g_x_v, float* slab, int* grid, hipStream_t st);
 int reduce_slab(const float* slab, int rows, int stride, int col0, int len, float* dst, hipStream_t st);
+int reduce_segments(const cgvp_segment* segs, int nsegs, float* grad_params, hipStream_t st);
 int bwd_block_sizes(int nt_node, int nt_edge, int* emb, int* conv_edge, int* conv_total, int* node, int* head);
 }  // namespace quad

@@ -763,7 +763,7 @@ int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const
                          const float* h, const float* dh, const float* mask0, const float* mask1,
                          const float* g_out, const float* g_up0, const float* g_up1, const float* g_up2,
                          int64_t N, int32_t with_head, float* g_dh, float* g_h, float* grad_params,
-                         float* workspace, void* stream) {
+                         float* workspace, cgvp_segment* segs, int32_t* nsegs, void* stream) {
   if (int rc = check_dims(dims)) return rc;
   if (N < 0 || !layout || !image || !grad_params || !workspace) return CGVP_ERR_BAD_ARG;
   const int nc = num_convs_of(*layout);
@@ -783,8 +783,11 @@ int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const
                                      workspace, &grid, st)) return rc;
   const int stride = with_head ? hd : nd;
   const int node_len = conv_ff1() + LFf1::size(0) - conv_ln0();          // norm.0 .. end of ff_func.1
-  quad::reduce_slab(workspace, grid, stride, 0, node_len, grad_params + layout->conv0 + layer * layout->conv_stride + conv_ln0(), st);
-  if (with_head) quad::reduce_slab(workspace, grid, stride, node_len, layout->total - layout->ln_out, grad_params + layout->ln_out, st);
+  cgvp_segment sg[2] = {{workspace, grid, stride, 0, node_len, layout->conv0 + layer * layout->conv_stride + conv_ln0()},
+                        {workspace, grid, stride, node_len, layout->total - layout->ln_out, layout->ln_out}};
+  const int n = with_head ? 2 : 1;
+  if (segs && nsegs) { for (int k = 0; k < n; ++k) segs[k] = sg[k]; *nsegs = n; }
+  else quad::reduce_segments(sg, n, grad_params, st);
   return launch_status();
 }
 
@@ -792,7 +795,7 @@ int cgvp_conv_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float*
                   const float* h, const float* e_s, const float* e_v, const int64_t* etypes,
                   const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc, const int32_t* edst,
                   int64_t N, int64_t E, int32_t aggr_mean, const float* g_dh, float* g_src, float* g_dst,
-                  float* grad_params, float* workspace, void* stream) {
+                  float* grad_params, float* workspace, cgvp_segment* segs, int32_t* nsegs, void* stream) {
   if (int rc = check_dims(dims)) return rc;
   if (N < 0 || E < 0 || !layout || !image || !grad_params || !workspace) return CGVP_ERR_BAD_ARG;
   const int nc = num_convs_of(*layout);
@@ -812,15 +815,17 @@ int cgvp_conv_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float*
   if (int rc = quad::conv_bwd(layout->nt_edge, image + o.conv0 + layer * o.layer_stride,
                               image + o.convT0 + layer * o.layerT_stride, h, e_s, e_v, etypes, rowptr, eperm, esrc,
                               edst, N, E, aggr_mean ? 1 : 0, g_dh, g_src, g_dst, workspace, &grid, st)) return rc;
-  quad::reduce_slab(workspace, grid, ct, 0, layout->conv0 - layout->edge_gvp, grad_params + layout->edge_gvp, st);
-  quad::reduce_slab(workspace, grid, ct, ce, conv_ln0(), grad_params + layout->conv0 + layer * layout->conv_stride, st);
+  cgvp_segment sg[2] = {{workspace, grid, ct, 0, layout->conv0 - layout->edge_gvp, layout->edge_gvp},
+                        {workspace, grid, ct, ce, conv_ln0(), layout->conv0 + layer * layout->conv_stride}};
+  if (segs && nsegs) { segs[0] = sg[0]; segs[1] = sg[1]; *nsegs = 2; }
+  else quad::reduce_segments(sg, 2, grad_params, st);
   return launch_status();
 }
 
 int cgvp_node_embed_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image, const float* x_s,
                         const float* x_v, const int64_t* ntypes, int64_t N, const float* g_up0,
                         const float* g_up1, const float* g_up2, float* g_x_s, float* g_x_v, float* grad_params,
-                        float* workspace, void* stream) {
+                        float* workspace, cgvp_segment* segs, int32_t* nsegs, void* stream) {
   if (int rc = check_dims(dims)) return rc;
   if (N < 0 || !layout || !image || !grad_params || !workspace) return CGVP_ERR_BAD_ARG;
   if (N == 0) return 0;
@@ -834,7 +839,9 @@ int cgvp_node_embed_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
   hipStream_t st = (hipStream_t)stream;
   if (int rc = quad::node_embed_bwd(layout->nt_node, image + o.emb, image + o.embT, x_s, x_v, ntypes, N, g_up0, g_up1,
                                     g_up2, g_x_s, g_x_v, workspace, &grid, st)) return rc;
-  quad::reduce_slab(workspace, grid, emb, 0, layout->edge_gvp - layout->node_gvp, grad_params + layout->node_gvp, st);
+  cgvp_segment sg[1] = {{workspace, grid, emb, 0, layout->edge_gvp - layout->node_gvp, layout->node_gvp}};
+  if (segs && nsegs) { segs[0] = sg[0]; *nsegs = 1; }
+  else quad::reduce_segments(sg, 1, grad_params, st);
   return launch_status();
 }
 
@@ -854,6 +861,12 @@ int cgvp_gine_conv_fwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
              chid, cout, w->eps, w->we, w->be, w->w0, w->b0, w->w1, w->b1, act_slope, out, mask};
   hipLaunchKernelGGL(gine_conv_kernel, dim3((unsigned)((N + GINE_APB - 1) / GINE_APB)),
                      dim3(WAVE * GINE_APB), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+int cgvp_bwd_reduce(const cgvp_segment* segs, int32_t nsegs, float* grad_params, void* stream) {
+  if (!segs || nsegs < 0 || nsegs > CGVP_MAX_SEGS || !grad_params) return CGVP_ERR_BAD_ARG;
+  quad::reduce_segments(segs, nsegs, grad_params, (hipStream_t)stream);
   return launch_status();
 }
 

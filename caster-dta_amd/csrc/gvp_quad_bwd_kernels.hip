@@ -397,13 +397,16 @@ __global__ __launch_bounds__(TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
         float d_vo[3][1] = {{d_mv[0]}, {d_mv[1]}, {d_mv[2]}};
         QMsg2::Grads gr;
         QMsg2::backward(imgT + IM::TC_M2, lane, c2[0], d_so, d_vo, d_b, d_bv, gr);
+        STAMP(10);
         QMsg2::weight_grads(gblk + B::M2, trash, lane, 0, active, b2[0], bv2[0], c2[0], gr);
       }
       {
         f4 d_so[1] = {f4{d_b[0], d_b[1], d_b[2], d_b[3]}};
         float d_vo[3][1] = {{d_bv[0][0]}, {d_bv[1][0]}, {d_bv[2][0]}};
         QMsg1::Grads gr;
+        STAMP(11);
         QMsg1::backward(imgT + IM::TC_M1, lane, c1[0], d_so, d_vo, d_b, d_bv, gr);
+        STAMP(12);
         QMsg1::weight_grads(gblk + B::M1, trash, lane, 0, active, b1[0], bv1[0], c1[0], gr);
       }
       float d_b0[16], d_bv0[3][3];
@@ -411,7 +414,9 @@ __global__ __launch_bounds__(TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
         f4 d_so[1] = {f4{d_b[0], d_b[1], d_b[2], d_b[3]}};
         float d_vo[3][1] = {{d_bv[0][0]}, {d_bv[1][0]}, {d_bv[2][0]}};
         QMsg0::Grads gr;
+        STAMP(13);
         QMsg0::backward(imgT + IM::TC_M0, lane, c0[0], d_so, d_vo, d_b0, d_bv0, gr);
+        STAMP(14);
         QMsg0::weight_grads(gblk + B::M0, trash, lane, 0, active, b0[0], bv0[0], c0[0], gr);
       }
       STAMP(4);
@@ -598,6 +603,26 @@ __global__ __launch_bounds__(RED_COLS * RED_RG) void reduce_slab_kernel(const fl
   }
 }
 
+struct SegTable { cgvp_segment s[CGVP_MAX_SEGS]; };
+__global__ __launch_bounds__(RED_COLS * RED_RG) void reduce_segments_kernel(SegTable t, float* __restrict__ grad) {
+  __shared__ float part[RED_RG][RED_COLS];
+  const cgvp_segment sg = t.s[blockIdx.y];
+  const int c = threadIdx.x & (RED_COLS - 1), rg = threadIdx.x / RED_COLS;
+  const int j = blockIdx.x * RED_COLS + c;
+  if (blockIdx.x * RED_COLS >= sg.len) return;          // whole block out of range (uniform)
+  float s = 0.f;
+  if (j < sg.len)
+    for (int r = rg; r < sg.rows; r += RED_RG) s += sg.slab[(size_t)r * sg.stride + sg.col0 + j];
+  part[rg][c] = s;
+  __syncthreads();
+  if (rg == 0 && j < sg.len) {
+    float tt = 0.f;
+#pragma unroll
+    for (int k = 0; k < RED_RG; ++k) tt += part[k][c];
+    atomicAdd(grad + sg.dst + j, tt);    // segments of different layers may share a destination (gvp_edge)
+  }
+}
+
 inline int grid_for(int64_t units) {
   int64_t wgs = (units + WPB - 1) / WPB;
   return (int)(wgs < 1 ? 1 : (wgs > MAX_GRID ? MAX_GRID : wgs));
@@ -615,6 +640,16 @@ int bwd_block_sizes(int nt_node, int nt_edge, int* emb, int* conv_edge, int* con
   else return CGVP_ERR_UNSUPPORTED_DIMS;
   *node = pad4(NODE_BLK);
   *head = pad4(NODE_BLK + HEAD_BLK);
+  return 0;
+}
+
+int reduce_segments(const cgvp_segment* segs, int nsegs, float* grad_params, hipStream_t st) {
+  if (nsegs <= 0) return 0;
+  SegTable t;
+  int maxlen = 0;
+  for (int i = 0; i < nsegs; ++i) { t.s[i] = segs[i]; maxlen = segs[i].len > maxlen ? segs[i].len : maxlen; }
+  hipLaunchKernelGGL(reduce_segments_kernel, dim3((maxlen + RED_COLS - 1) / RED_COLS, nsegs), dim3(RED_COLS * RED_RG), 0,
+                     st, t, grad_params);
   return 0;
 }
 

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcaster_gvp.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class HipLibraryError(RuntimeError):
@@ -31,6 +31,11 @@ class Layout(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "nt_node", "nt_edge", "node_gvp", "node_ln", "edge_gvp", "edge_ln", "conv0",
         "conv_stride", "ln_out", "head", "total")]
+
+
+class Segment(C.Structure):
+    _fields_ = [("slab", C.c_void_p), ("rows", C.c_int32), ("stride", C.c_int32), ("col0", C.c_int32),
+                ("len", C.c_int32), ("dst", C.c_int32)]
 
 
 class GineW(C.Structure):
@@ -57,11 +62,12 @@ _SIGNATURES = {
                                              _I32, _P, _P, _P]),
     "cgvp_bwd_workspace_floats": (C.c_int64, [C.POINTER(Dims), C.POINTER(Layout)]),
     "cgvp_node_update_bwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P,
-                                       _I64, _I32, _P, _P, _P, _P, _P]),
+                                       _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "cgvp_conv_bwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64,
-                                _I64, _I32, _P, _P, _P, _P, _P, _P]),
+                                _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cgvp_node_embed_bwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P,
-                                      _P, _P, _P]),
+                                      _P, _P, _P, _P, _P]),
+    "cgvp_bwd_reduce": (C.c_int, [_P, _I32, _P, _P]),
     "cgvp_gine_conv_fwd": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _I64, _I64, _I32, _I32,
                                      _I32, C.POINTER(GineW), C.c_float, _P, _P, _P]),
     "cgvp_gine_bwd_workspace_floats": (C.c_int64, []),

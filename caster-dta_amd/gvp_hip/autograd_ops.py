@@ -74,7 +74,24 @@ class _LbaEncoderFn(torch.autograd.Function):
         g_out = _f32(g_out, "grad_output")
         f32 = dict(dtype=torch.float32, device=dev)
         gparams = torch.zeros(layout.total, **f32)
-        ws = torch.empty(int(L.cgvp_bwd_workspace_floats(C.byref(dims), C.byref(layout))), **f32)
+        # every stage writes its per-workgroup partial weight-gradient blocks into its own region of
+        # one workspace; a single reduce launch at the end sums them all in a fixed order
+        wsz = int(L.cgvp_bwd_workspace_floats(C.byref(dims), C.byref(layout)))
+        nstage = 2 * nc + 1
+        ws_all = torch.empty(nstage * wsz, **f32)
+        segs = (_lib.Segment * (2 * nstage))()
+        nseg, stage = 0, 0
+        cnt = C.c_int32(0)
+
+        def region():
+            nonlocal stage
+            r = ws_all[stage * wsz:(stage + 1) * wsz]
+            stage += 1
+            return r
+
+        def take():
+            nonlocal nseg
+            nseg += cnt.value
         need_x = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         g_x_s = torch.empty(N, dims.node_in_s, **f32) if need_x else None
         g_x_v = torch.empty(N, dims.node_in_v, 3, **f32) if need_x else None
@@ -89,18 +106,27 @@ class _LbaEncoderFn(torch.autograd.Function):
                 _lib.check(L.cgvp_node_update_bwd(d, lay, I, l, _ptr(hs[l]), _ptr(dhs[l]), _ptr(masks[l][0]),
                                                   _ptr(masks[l][1]), _ptr(g_out if last else None), _ptr(ups[0]),
                                                   _ptr(ups[1]), _ptr(ups[2]), N, 1 if last else 0, _ptr(g_dh),
-                                                  _ptr(g_h), _ptr(gparams), _ptr(ws), st), "cgvp_node_update_bwd")
+                                                  _ptr(g_h), _ptr(gparams), _ptr(region()),
+                                                  C.byref(segs, nseg * C.sizeof(_lib.Segment)), C.byref(cnt), st),
+                           "cgvp_node_update_bwd")
+                take()
                 g_src = torch.empty(N, ROW, **f32)
                 g_dst = torch.empty(N, ROW, **f32)
                 with ops._timed("conv_bwd"):
                     _lib.check(L.cgvp_conv_bwd(d, lay, I, l, _ptr(hs[l]), _ptr(e_s), _ptr(e_v), _ptr(et),
                                                _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst), N, E,
                                                1 if m["mean"] else 0, _ptr(g_dh), _ptr(g_src), _ptr(g_dst),
-                                               _ptr(gparams), _ptr(ws), st), "cgvp_conv_bwd")
+                                               _ptr(gparams), _ptr(region()),
+                                               C.byref(segs, nseg * C.sizeof(_lib.Segment)), C.byref(cnt), st),
+                               "cgvp_conv_bwd")
+                take()
                 ups = (g_h if g_h is not None else g_dh, g_src, g_dst)
             _lib.check(L.cgvp_node_embed_bwd(d, lay, I, _ptr(x_s), _ptr(x_v), _ptr(nt), N, _ptr(ups[0]), _ptr(ups[1]),
-                                             _ptr(ups[2]), _ptr(g_x_s), _ptr(g_x_v), _ptr(gparams), _ptr(ws), st),
+                                             _ptr(ups[2]), _ptr(g_x_s), _ptr(g_x_v), _ptr(gparams), _ptr(region()),
+                                             C.byref(segs, nseg * C.sizeof(_lib.Segment)), C.byref(cnt), st),
                        "cgvp_node_embed_bwd")
+            take()
+            _lib.check(L.cgvp_bwd_reduce(segs, nseg, _ptr(gparams), st), "cgvp_bwd_reduce")
         grads = m["arena"].split(gparams)
         return (None, g_x_s, g_x_v, None, None) + tuple(grads)
 

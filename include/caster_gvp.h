@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 4
+#define CGVP_ABI_VERSION 5
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
@@ -156,6 +156,24 @@ int cgvp_node_update_fwd_train(const cgvp_dims* dims, const cgvp_layout* layout,
  * MFMA kernels only (image required). */
 int64_t cgvp_bwd_workspace_floats(const cgvp_dims* dims, const cgvp_layout* layout);
 
+/* DEFERRED REDUCTION.  By default every backward entry point reduces its own
+ * partial blocks.  Pass a non-NULL `segs` (room for CGVP_MAX_SEGS_PER_CALL
+ * entries) and `nsegs` to skip that: the call then only describes WHERE its
+ * partials sit inside `workspace` (which must stay untouched -- give each call its
+ * own region of cgvp_bwd_workspace_floats() floats), and ONE
+ * cgvp_bwd_reduce(all segments) at the end of the backward pass adds everything
+ * into grad_params (same fixed summation order, one launch instead of ten). */
+typedef struct {
+  const float* slab;   /* first partial row                                  */
+  int32_t rows;        /* number of partial rows                             */
+  int32_t stride;      /* floats between rows                                */
+  int32_t col0, len;   /* columns [col0, col0+len) of every row ...          */
+  int32_t dst;         /* ... are summed into grad_params[dst, dst+len)      */
+} cgvp_segment;
+#define CGVP_MAX_SEGS_PER_CALL 2
+#define CGVP_MAX_SEGS 32
+int cgvp_bwd_reduce(const cgvp_segment* segs, int32_t nsegs, float* grad_params, void* stream);
+
 /* d/d(h, dh, weights) of cgvp_node_update_fwd[_train].  Upstream gradient: with
  * the head, g_out [N][64]; otherwise the SUM of up to three [N][28] buffers
  * g_up0..2 (NULL entries skipped).  Writes g_dh [N][28] (= mask0 * d h) and, when
@@ -165,7 +183,7 @@ int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const
                          const float* mask1, const float* g_out, const float* g_up0,
                          const float* g_up1, const float* g_up2, int64_t num_nodes,
                          int32_t with_head, float* g_dh, float* g_h, float* grad_params,
-                         float* workspace, void* stream);
+                         float* workspace, cgvp_segment* segs, int32_t* nsegs, void* stream);
 
 /* d/d(h, weights) of cgvp_conv_fwd given g_dh = d(loss)/d(dh).  Gradients w.r.t.
  * the node rows arrive in two buffers that the consumer sums: g_src [N][28]
@@ -177,7 +195,7 @@ int cgvp_conv_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float*
                   const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
                   const int32_t* edst, int64_t num_nodes, int64_t num_edges, int32_t aggr_mean,
                   const float* g_dh, float* g_src, float* g_dst, float* grad_params,
-                  float* workspace, void* stream);
+                  float* workspace, cgvp_segment* segs, int32_t* nsegs, void* stream);
 
 /* d/d(x_s, x_v, weights) of cgvp_node_embed_fwd; upstream = sum of g_up0..2.
  * g_x_s [N][17] / g_x_v [N][3][3] may both be NULL (inputs without gradient). */
@@ -185,7 +203,7 @@ int cgvp_node_embed_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
                         const float* x_s, const float* x_v, const int64_t* ntypes,
                         int64_t num_nodes, const float* g_up0, const float* g_up1,
                         const float* g_up2, float* g_x_s, float* g_x_v, float* grad_params,
-                        float* workspace, void* stream);
+                        float* workspace, cgvp_segment* segs, int32_t* nsegs, void* stream);
 
 /* One GINEConv + activation of HomoMoleculeGNN_GINE (molecule_gnn.py:254-268,
  * :271-280; PyG GINEConv / MLP restated):

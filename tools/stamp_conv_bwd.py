@@ -31,5 +31,10 @@ print(f"{'stage + barrier':28s} median {np.median(b[:,1]-b[:,0]):8.0f}")
 for s in range(3, 8):
     dt = b[:, s] - b[:, s - 1]
     print(f"{names[s]:28s} median {np.median(dt):8.0f} cyc   p90 {np.percentile(dt, 90):8.0f}")
+seq = [(3, 10, "msg2 backward"), (10, 11, "msg2 weight_grads"), (11, 12, "msg1 backward"), (12, 13, "msg1 weight_grads"),
+       (13, 14, "msg0 backward"), (14, 4, "msg0 weight_grads")]
+for a_, b_, nm in seq:
+    dt = b[:, b_] - b[:, a_]
+    print(f"   {nm:25s} median {np.median(dt):8.0f} cyc")
 print(f"{'wave total (all tiles)':28s} median {np.median(b[:,8]-b[:,0]):8.0f} cyc   p90 {np.percentile(b[:,8]-b[:,0], 90):8.0f}")
 print(f"{'final barrier + slab write':28s} median {np.median(b[:,9]-b[:,8]):8.0f}")
