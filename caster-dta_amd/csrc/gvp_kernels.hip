@@ -354,10 +354,19 @@ struct GineArgs {
 constexpr int GINE_APB = 4;   // atoms (waves) per block
 constexpr int GINE_MAXKE = 16;
 
-// One wave per target atom, one lane per channel.
+// One wave per target atom, one lane per channel.  The two MLP matrices are
+// staged once per workgroup in LDS with odd row strides (cin+1 / chid+1), so the
+// "lane o reads row o" pattern of the mat-vecs is bank-conflict free instead of a
+// 64-cache-line gather from global memory per k.
 __global__ __launch_bounds__(WAVE * GINE_APB) void gine_conv_kernel(GineArgs a) {
-  __shared__ float hbuf[GINE_APB][WAVE];
-  __shared__ float tbuf[GINE_APB][WAVE];
+  extern __shared__ float gsm[];
+  const int s0 = a.cin + 1, s1 = a.chid + 1;
+  float* w0s = gsm;                                   // [chid][cin + 1]
+  float* w1s = w0s + a.chid * s0;                     // [cout][chid + 1]
+  float (*hbuf)[WAVE] = reinterpret_cast<float (*)[WAVE]>(w1s + a.cout * s1);
+  float (*tbuf)[WAVE] = hbuf + GINE_APB;
+  for (int k = threadIdx.x; k < a.chid * a.cin; k += WAVE * GINE_APB) w0s[(k / a.cin) * s0 + k % a.cin] = a.w0[k];
+  for (int k = threadIdx.x; k < a.cout * a.chid; k += WAVE * GINE_APB) w1s[(k / a.chid) * s1 + k % a.chid] = a.w1[k];
   const int lane = threadIdx.x & (WAVE - 1);
   const int w = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * GINE_APB + w;
@@ -399,7 +408,7 @@ __global__ __launch_bounds__(WAVE * GINE_APB) void gine_conv_kernel(GineArgs a) 
   float t = 0.f;
   if (valid && lane < a.chid) {
     t = a.b0[lane];
-    const float* wr = a.w0 + lane * a.cin;
+    const float* wr = w0s + lane * s0;
     for (int k = 0; k < a.cin; ++k) t = fmaf(wr[k], hbuf[w][k], t);
     t = t > 0.f ? t : t * a.slope;
   }
@@ -407,7 +416,7 @@ __global__ __launch_bounds__(WAVE * GINE_APB) void gine_conv_kernel(GineArgs a) 
   __syncthreads();
   if (valid && lane < a.cout) {
     float y = a.b1[lane];
-    const float* wr = a.w1 + lane * a.chid;
+    const float* wr = w1s + lane * s1;
     for (int k = 0; k < a.chid; ++k) y = fmaf(wr[k], tbuf[w][k], y);
     y = y > 0.f ? y : y * a.slope;
     if (a.mask) y *= a.mask[i * a.cout + lane];
@@ -440,8 +449,12 @@ struct GineLay {
 template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
 __global__ __launch_bounds__(WAVE * GINE_APB) void gine_bwd_kernel(GineBArgs a) {
   typedef GineLay<CIN, CHID, COUT, NT, NET, ED> LY;
-  constexpr int KE = NET + ED, XW = CIN - NT;
+  constexpr int KE = NET + ED, XW = CIN - NT, S0 = CIN + 1, S1 = CHID + 1;
   __shared__ float hbuf[GINE_APB][WAVE], tbuf[GINE_APB][WAVE], dybuf[GINE_APB][WAVE], dtbuf[GINE_APB][WAVE];
+  __shared__ float w0s[CHID * S0], w1s[COUT * S1];     // odd strides: row-per-lane AND column-per-lane reads conflict free
+  for (int k = threadIdx.x; k < CHID * CIN; k += WAVE * GINE_APB) w0s[(k / CIN) * S0 + k % CIN] = a.w0[k];
+  for (int k = threadIdx.x; k < COUT * CHID; k += WAVE * GINE_APB) w1s[(k / CHID) * S1 + k % CHID] = a.w1[k];
+  __syncthreads();
   const int lane = threadIdx.x & (WAVE - 1);
   const int w = threadIdx.x >> 6;
   const int wave = blockIdx.x * GINE_APB + w, nwaves = gridDim.x * GINE_APB;
@@ -496,7 +509,7 @@ __global__ __launch_bounds__(WAVE * GINE_APB) void gine_bwd_kernel(GineBArgs a) 
     float tpre = 0.f;
     if (valid && lane < CHID) {
       tpre = a.b0[lane];
-      const float* wr = a.w0 + lane * CIN;
+      const float* wr = w0s + lane * S0;
 #pragma unroll 4
       for (int k = 0; k < CIN; ++k) tpre = fmaf(wr[k], hbuf[w][k], tpre);
     }
@@ -505,7 +518,7 @@ __global__ __launch_bounds__(WAVE * GINE_APB) void gine_bwd_kernel(GineBArgs a) 
     float dy = 0.f;
     if (valid && lane < COUT) {
       float ypre = a.b1[lane];
-      const float* wr = a.w1 + lane * CHID;
+      const float* wr = w1s + lane * S1;
 #pragma unroll 4
       for (int k = 0; k < CHID; ++k) ypre = fmaf(wr[k], tbuf[w][k], ypre);
       dy = a.g_out[i * COUT + lane] * (ypre > 0.f ? 1.f : a.slope);
@@ -520,7 +533,7 @@ __global__ __launch_bounds__(WAVE * GINE_APB) void gine_bwd_kernel(GineBArgs a) 
     if (valid && lane < CHID) {
       float dt = 0.f;
 #pragma unroll 4
-      for (int o = 0; o < COUT; ++o) dt = fmaf(a.w1[o * CHID + lane], dybuf[w][o], dt);
+      for (int o = 0; o < COUT; ++o) dt = fmaf(w1s[o * S1 + lane], dybuf[w][o], dt);
       dtp = dt * (tpre > 0.f ? 1.f : a.slope);
       acc_b0 += dtp;
 #pragma unroll
@@ -531,7 +544,7 @@ __global__ __launch_bounds__(WAVE * GINE_APB) void gine_bwd_kernel(GineBArgs a) 
     if (valid && lane < CIN) {
       float dh = 0.f;
 #pragma unroll 4
-      for (int k = 0; k < CHID; ++k) dh = fmaf(a.w0[k * CIN + lane], dtbuf[w][k], dh);
+      for (int k = 0; k < CHID; ++k) dh = fmaf(w0s[k * S0 + lane], dtbuf[w][k], dh);
       acc_eps = fmaf(dh, xi, acc_eps);
       if (a.g_x && lane >= NT) atomicAdd(a.g_x + i * XW + (lane - NT), eps1 * dh);
       for (int32_t p = p0; p < p1; ++p) {
@@ -587,7 +600,7 @@ template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
 int gine_bwd_launch(GineBArgs& a, float* grad_layer, hipStream_t st) {
   typedef GineLay<CIN, CHID, COUT, NT, NET, ED> LY;
   int64_t wgs = (a.N + GINE_APB - 1) / GINE_APB;
-  const int G = (int)(wgs < 1 ? 1 : (wgs > 64 ? 64 : wgs));          // <= 256 waves = slab rows
+  const int G = (int)(wgs < 1 ? 1 : (wgs > 128 ? 128 : wgs));        // <= 512 waves = slab rows
   hipLaunchKernelGGL((gine_bwd_kernel<CIN, CHID, COUT, NT, NET, ED>), dim3(G), dim3(WAVE * GINE_APB), 0, st, a);
   quad::reduce_slab(a.slab, G * GINE_APB, LY::SIZE, 0, LY::SIZE, grad_layer, st);
   return 0;
@@ -859,8 +872,9 @@ int cgvp_gine_conv_fwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
   if (E > 0 && (!eperm || !esrc || (edge_dim > 0 && !eattr) || (num_etypes > 0 && !etypes))) return CGVP_ERR_BAD_ARG;
   GineArgs a{x, ntypes, num_ntypes, eattr, etypes, num_etypes, edge_dim, rowptr, eperm, esrc, N, cin,
              chid, cout, w->eps, w->we, w->be, w->w0, w->b0, w->w1, w->b1, act_slope, out, mask};
+  const size_t lds = (size_t)(chid * (cin + 1) + cout * (chid + 1) + 2 * GINE_APB * WAVE) * sizeof(float);
   hipLaunchKernelGGL(gine_conv_kernel, dim3((unsigned)((N + GINE_APB - 1) / GINE_APB)),
-                     dim3(WAVE * GINE_APB), 0, (hipStream_t)stream, a);
+                     dim3(WAVE * GINE_APB), lds, (hipStream_t)stream, a);
   return launch_status();
 }
 
@@ -870,7 +884,7 @@ int cgvp_bwd_reduce(const cgvp_segment* segs, int32_t nsegs, float* grad_params,
   return launch_status();
 }
 
-int64_t cgvp_gine_bwd_workspace_floats(void) { return (int64_t)256 * GineLay<16, 64, 64, 0, 5, 9>::SIZE; }
+int64_t cgvp_gine_bwd_workspace_floats(void) { return (int64_t)512 * GineLay<16, 64, 64, 0, 5, 9>::SIZE; }
 
 int cgvp_gine_conv_bwd(const float* x, const int64_t* ntypes, int32_t num_ntypes, const float* eattr,
                        const int64_t* etypes, int32_t num_etypes, int32_t edge_dim, const int32_t* rowptr,
