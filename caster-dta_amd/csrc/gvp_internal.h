@@ -12,7 +12,7 @@ struct QuadOffsets {
   int embT, convT0, nodeT0, layerT_stride, headT;     // transposed slices (backward)
 };
 
-constexpr int kBwdMaxGrid = 512;   // persistent workgroups of the backward kernels = slab rows
+constexpr int kBwdMaxGrid = 1024;   // persistent workgroups of the backward kernels; slab rows = 4 per workgroup
 
 namespace quad {
 int offsets(int nt_node, int nt_edge, int num_convs, QuadOffsets* o);

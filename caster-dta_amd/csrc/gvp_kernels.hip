@@ -769,7 +769,7 @@ int64_t cgvp_bwd_workspace_floats(const cgvp_dims* dims, const cgvp_layout* layo
   if (int rc = quad::bwd_block_sizes(layout->nt_node, layout->nt_edge, &emb, &ce, &ct, &nd, &hd)) return rc;
   int mx = emb > ct ? emb : ct;
   mx = mx > hd ? mx : hd;
-  return (int64_t)kBwdMaxGrid * mx;
+  return (int64_t)kBwdMaxGrid * 4 * mx;
 }
 
 int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image, int32_t layer,

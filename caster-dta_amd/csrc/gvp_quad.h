@@ -213,11 +213,23 @@ __device__ __forceinline__ void outer_items(const f4 (&A)[MT], const f4 (&B)[NT_
       for (int nt = 0; nt < NT_; ++nt) acc[mt][nt] = mfma(A[mt][rr], B[nt][rr], acc[mt][nt]);
 }
 
-// Add a slot-ordered weight-gradient tile grid into W-layout block `dst` ([.][LD]).
-// (Padding slots are skipped with a branch: redirecting them to a shared dummy
-// word was measured 2.6x slower -- every lane of every wave serialises on it.)
-template <class RowSegs, class ColSegs, int MT, int NT_>
-__device__ __forceinline__ void flush_slots(float* dst, float* trash, int LD, const f4 (&acc)[MT][NT_], int lane) {
+// Add a slot-ordered weight-gradient tile grid into W-layout block `dst` ([.][LD])
+// of the wave's PRIVATE slab row (global memory): plain store on the wave's first
+// tile, read-add-store afterwards.  No atomics anywhere: a workgroup-shared LDS
+// block with ds_add_f32 was measured at ~470 cycles per wave-instruction.
+// Two accumulation policies for weight-gradient partials:
+//   AccRow: the wave owns its row of the slab in global memory -> plain store on its
+//           first tile, private read-add-store afterwards (no atomics).  Best when a
+//           wave has one tile (node / embed backward): four lockstep waves adding
+//           into one LDS block were measured at ~470 cycles per ds_add_f32.
+//   AccLds: the workgroup shares one block in LDS, ds_add_f32; written to the slab
+//           once per workgroup.  Best when waves own several tiles at different
+//           phases (conv backward), where global read-add-store stalls instead.
+struct AccRow { static __device__ __forceinline__ void add(float* p, float v, bool first) { *p = first ? v : *p + v; } };
+struct AccLds { static __device__ __forceinline__ void add(float* p, float v, bool) { atomicAdd(p, v); } };
+
+template <class Acc, class RowSegs, class ColSegs, int MT, int NT_>
+__device__ __forceinline__ void flush_slots(float* dst, bool first, int LD, const f4 (&acc)[MT][NT_], int lane) {
   const int n = lane & 15, gq_ = lane >> 4;
 #pragma unroll
   for (int nt = 0; nt < NT_; ++nt) {
@@ -229,7 +241,7 @@ __device__ __forceinline__ void flush_slots(float* dst, float* trash, int LD, co
       for (int r = 0; r < 4; ++r) {
         const int m = 4 * gq_ + r, rs = 4 * mt + (m >> 2);
         const int row = rs < RowSegs::steps ? RowSegs::col(rs, m & 3) : -1;
-        if (row >= 0 && col >= 0) atomicAdd(dst + row * LD + col, acc[mt][nt][r]);
+        if (row >= 0 && col >= 0) Acc::add(dst + row * LD + col, acc[mt][nt][r], first);
       }
   }
 }
@@ -480,12 +492,14 @@ struct GvpQ {
     }
   }
 
-  // Weight gradients of this GVP for one tile, added into its arena-layout
-  // gradient block `gblk` (LDS, one per workgroup).  Registers and MFMAs only.
+  // Weight gradients of this GVP for one tile, written (first) / added into the
+  // arena-layout gradient block `gblk` of the wave's private slab row.  Registers
+  // and MFMAs only.
   static constexpr int WG_SCRATCH = 0;
   static constexpr int NTS = ceil4(NT);                 // k-steps of the one-hot type columns
   typedef Segs<Seg<P2, 0, (NT > 0 ? NT : 1)>, SSegs, Seg<P2, NT + SI, H>> WsCols;   // [types | scalars | norms]
-  static __device__ __forceinline__ void weight_grads(float* gblk, float* trash, int lane, int type, bool active,
+  template <class Acc>
+  static __device__ __forceinline__ void weight_grads(float* gblk, bool first, int lane, int type, bool active,
                                                       const float (&bs)[SSTEPS], const float (&bv)[3][VSTEPS],
                                                       const Cache& c, const Grads& gr) {
     const int i = lane & 15, g = lane >> 4;
@@ -515,14 +529,14 @@ struct GvpQ {
 #pragma unroll
         for (int y = 0; y < ceil4(NB); ++y) acc[x][y] = zero;
       outer_items<OT, ceil4(NB)>(AT, BT, acc);
-      flush_slots<Segs<Seg<P1, 0, SO>>, WsCols, OT, ceil4(NB)>(gblk + A::ws(NT), trash, K, acc, lane);
+      flush_slots<Acc, Segs<Seg<P1, 0, SO>>, WsCols, OT, ceil4(NB)>(gblk + A::ws(NT), first, K, acc, lane);
     }
 #pragma unroll
     for (int t = 0; t < OT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float tot = row_total(active ? gr.dsp[t][r] : 0.f);
-        if (i == 15) atomicAdd(gblk + A::bs(NT) + 16 * t + 4 * g + r, tot);
+        if (i == 15) Acc::add(gblk + A::bs(NT) + 16 * t + 4 * g + r, tot, first);
       }
     if (VO > 0) {
       // ---- dWsv = dgate (x) sp, dbsv = sum dgate
@@ -539,11 +553,11 @@ struct GvpQ {
 #pragma unroll
       for (int y = 0; y < OT; ++y) acc[0][y] = zero;
       outer_items<1, OT>(AT, BT, acc);
-      flush_slots<Segs<Seg<P2, 0, (VO > 0 ? VO : 1)>>, Segs<Seg<P1, 0, SO>>, 1, OT>(gblk + A::wsv(NT), trash, SO, acc, lane);
+      flush_slots<Acc, Segs<Seg<P2, 0, (VO > 0 ? VO : 1)>>, Segs<Seg<P1, 0, SO>>, 1, OT>(gblk + A::wsv(NT), first, SO, acc, lane);
 #pragma unroll
       for (int r = 0; r < VOR; ++r) {
         const float tot = row_total(active ? gr.dgate[r] : 0.f);
-        if (i == 15 && 4 * r + g < VO) atomicAdd(gblk + A::bsv(NT) + 4 * r + g, tot);
+        if (i == 15 && 4 * r + g < VO) Acc::add(gblk + A::bsv(NT) + 4 * r + g, tot, first);
       }
       // ---- dWv = sum_planes dvp (x) vh
       f4 accv[1][1] = {{zero}};
@@ -559,7 +573,7 @@ struct GvpQ {
         transpose_slots<HR>(bh, BH, lane);
         outer_items<1, 1>(AV, BH, accv);
       }
-      flush_slots<Segs<Seg<P2, 0, (VO > 0 ? VO : 1)>>, Segs<Seg<P2, 0, H>>, 1, 1>(gblk + A::wv(NT), trash, H, accv, lane);
+      flush_slots<Acc, Segs<Seg<P2, 0, (VO > 0 ? VO : 1)>>, Segs<Seg<P2, 0, H>>, 1, 1>(gblk + A::wv(NT), first, H, accv, lane);
     }
     // ---- dWh = sum_planes dvh (x) V_in
     {
@@ -577,7 +591,7 @@ struct GvpQ {
         transpose_slots<VSTEPS>(bin, BI, lane);
         outer_items<1, 1>(AH, BI, acch);
       }
-      flush_slots<Segs<Seg<P2, 0, H>>, VSegs, 1, 1>(gblk, trash, VI, acch, lane);
+      flush_slots<Acc, Segs<Seg<P2, 0, H>>, VSegs, 1, 1>(gblk, first, VI, acch, lane);
     }
   }
 };

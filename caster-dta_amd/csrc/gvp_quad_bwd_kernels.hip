@@ -49,7 +49,7 @@ constexpr int TILE = 16;
 #else
 #define STAMP(slot) do {} while (0)
 #endif
-constexpr int MAX_GRID = kBwdMaxGrid;  // persistent workgroups (one slab row each)
+constexpr int MAX_GRID = kBwdMaxGrid;  // persistent workgroups; every WAVE owns one slab row
 constexpr int ACC_ROWS = 32;           // target nodes a wave owns at most (conv backward accumulator)
 
 template <int NFLOATS>
@@ -69,8 +69,8 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int pad4(int x) { return (x + 3) / 4 * 4; }
 
 // LayerNorm parameter gradients of a tile -> [gamma | beta] block in LDS.
-template <int S>
-__device__ __forceinline__ void ln_param_grads(float* blk, float* trash, int lane, bool active,
+template <class Acc, int S>
+__device__ __forceinline__ void ln_param_grads(float* blk, bool first, int lane, bool active,
                                                const f4 (&dgamma)[S / 16], const f4 (&dbeta)[S / 16]) {
   const int i = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -80,8 +80,8 @@ __device__ __forceinline__ void ln_param_grads(float* blk, float* trash, int lan
       const float tg = row_total(active ? dgamma[t][r] : 0.f);
       const float tb = row_total(active ? dbeta[t][r] : 0.f);
       if (i == 15) {
-        atomicAdd(blk + 16 * t + 4 * g + r, tg);
-        atomicAdd(blk + S + 16 * t + 4 * g + r, tb);
+        Acc::add(blk + 16 * t + 4 * g + r, tg, first);
+        Acc::add(blk + S + 16 * t + 4 * g + r, tb, first);
       }
     }
 }
@@ -111,24 +111,27 @@ __global__ __launch_bounds__(TPB, 2) void node_bwd_kernel(NodeBArgs a) {
   float* f_head = f_node + IM::ND_SIZE;
   float* t_node = f_head + (HEAD ? IM::HD_SIZE : 0);
   float* t_head = t_node + IM::TN_SIZE;
-  float* gblk = t_head + (HEAD ? IM::TH_SIZE : 0);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float* trash = gblk + GB;
-  float* scr = trash;
+  float* gblk = a.slab + ((size_t)blockIdx.x * WPB + w) * GB;       // this wave's private slab row
   stage_slice<IM::ND_SIZE>(f_node, a.img_node, threadIdx.x);
   stage_slice<IM::TN_SIZE>(t_node, a.imgT_node, threadIdx.x);
   if (HEAD) {
     stage_slice<IM::HD_SIZE>(f_head, a.img_head, threadIdx.x);
     stage_slice<IM::TH_SIZE>(t_head, a.imgT_head, threadIdx.x);
   }
-  for (int k = threadIdx.x; k < GB; k += TPB) gblk[k] = 0.f;
+  STAMP(0);
   __syncthreads();
+  STAMP(1);
 
   const int i = lane & 15, g = lane >> 4;
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
   const int zt[1] = {0};
   const int64_t ntiles = (a.N + TILE - 1) / TILE;
-  for (int64_t tile = (int64_t)blockIdx.x * WPB + w; tile < ntiles; tile += (int64_t)gridDim.x * WPB) {
+  const int64_t tile0 = (int64_t)blockIdx.x * WPB + w;
+  if (tile0 >= ntiles)                                 // idle wave: its row still takes part in the reduction
+    for (int k = lane; k < GB; k += WAVE) gblk[k] = 0.f;
+  for (int64_t tile = tile0; tile < ntiles; tile += (int64_t)gridDim.x * WPB) {
+    const bool first = tile == tile0;
     const int64_t n = tile * TILE + i;
     const bool active = n < a.N;
     // ---- recompute the forward of this tile
@@ -170,6 +173,7 @@ __global__ __launch_bounds__(TPB, 2) void node_bwd_kernel(NodeBArgs a) {
 #pragma unroll
     for (int p = 0; p < 3; ++p) zv[p][0] = yv[p][0] + v2[0][p][0] * m1v;
 
+    STAMP(2);
     // ---- upstream gradient of this stage's output
     f4 gs[1] = {zero};
     float gv[3][1] = {{0.f}, {0.f}, {0.f}};
@@ -197,12 +201,12 @@ __global__ __launch_bounds__(TPB, 2) void node_bwd_kernel(NodeBArgs a) {
       float d_vo[3][1] = {{0.f}, {0.f}, {0.f}}, d_bs[4], d_bv[3][1];
       QHead::Grads grh;
       QHead::backward(t_head, lane, ch[0], d_o, d_vo, d_bs, d_bv, grh);
-      QHead::weight_grads(gblk + NODE_BLK + HB_GVP, trash, lane, 0, active, bsh[0], bvh[0], ch[0], grh);
+      QHead::weight_grads<AccRow>(gblk + NODE_BLK + HB_GVP, first, lane, 0, active, bsh[0], bvh[0], ch[0], grh);
       f4 dws[1] = {f4{d_bs[0], d_bs[1], d_bs[2], d_bs[3]}};
       float dwv[3][1] = {{d_bv[0][0]}, {d_bv[1][0]}, {d_bv[2][0]}};
       f4 dga[1], dbe[1];
       ln_quad_bwd<NS, NV>(f_head + IM::HD_LN, lane, o1, ov1, dws, dwv, dga, dbe);
-      ln_param_grads<NS>(gblk + NODE_BLK + HB_LN, trash, lane, active, dga, dbe);
+      ln_param_grads<AccRow, NS>(gblk + NODE_BLK + HB_LN, first, lane, active, dga, dbe);
       gs[0] = dws[0];
 #pragma unroll
       for (int p = 0; p < 3; ++p) gv[p][0] = dwv[p][0];
@@ -218,19 +222,22 @@ __global__ __launch_bounds__(TPB, 2) void node_bwd_kernel(NodeBArgs a) {
         }
     }
 
+    STAMP(3);
     // ---- norm.1, feed-forward, residual, norm.0
     {
       f4 dga[1], dbe[1];
       ln_quad_bwd<NS, NV>(f_node + IM::ND_LN1, lane, z, zv, gs, gv, dga, dbe);      // gs/gv := d z
-      ln_param_grads<NS>(gblk + NB_LN1, trash, lane, active, dga, dbe);
+      ln_param_grads<AccRow, NS>(gblk + NB_LN1, first, lane, active, dga, dbe);
     }
     float d_hs[16], d_hv[3][2];
     {
       f4 d_so[1] = {gs[0] * m1s};
       float d_vo[3][1] = {{gv[0][0] * m1v}, {gv[1][0] * m1v}, {gv[2][0] * m1v}};
       QFf1::Grads gr1;
+      STAMP(4);
       QFf1::backward(t_node + IM::TN_FF1, lane, c1[0], d_so, d_vo, d_hs, d_hv, gr1);
-      QFf1::weight_grads(gblk + NB_FF1, trash, lane, 0, active, bs1[0], bv1[0], c1[0], gr1);
+      STAMP(5);
+      QFf1::weight_grads<AccRow>(gblk + NB_FF1, first, lane, 0, active, bs1[0], bv1[0], c1[0], gr1);
     }
     {
       f4 d_so[4];
@@ -238,17 +245,20 @@ __global__ __launch_bounds__(TPB, 2) void node_bwd_kernel(NodeBArgs a) {
       for (int t = 0; t < 4; ++t) d_so[t] = f4{d_hs[4 * t], d_hs[4 * t + 1], d_hs[4 * t + 2], d_hs[4 * t + 3]};
       float d_ys[4], d_yv[3][1];
       QFf0::Grads gr0;
+      STAMP(6);
       QFf0::backward(t_node + IM::TN_FF0, lane, c0[0], d_so, d_hv, d_ys, d_yv, gr0);
-      QFf0::weight_grads(gblk + NB_FF0, trash, lane, 0, active, bs0[0], bv0[0], c0[0], gr0);
+      STAMP(7);
+      QFf0::weight_grads<AccRow>(gblk + NB_FF0, first, lane, 0, active, bs0[0], bv0[0], c0[0], gr0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) gs[0][r] += d_ys[r];
 #pragma unroll
       for (int p = 0; p < 3; ++p) gv[p][0] += d_yv[p][0];
     }
+    STAMP(8);
     {
       f4 dga[1], dbe[1];
       ln_quad_bwd<NS, NV>(f_node + IM::ND_LN0, lane, x0, xv0, gs, gv, dga, dbe);    // gs/gv := d (h + dh)
-      ln_param_grads<NS>(gblk + NB_LN0, trash, lane, active, dga, dbe);
+      ln_param_grads<AccRow, NS>(gblk + NB_LN0, first, lane, active, dga, dbe);
     }
     if (active) {               // d h (residual path) and d dh = mask0 * d h (equal without dropout)
       if (a.g_h) {
@@ -263,9 +273,7 @@ __global__ __launch_bounds__(TPB, 2) void node_bwd_kernel(NodeBArgs a) {
       for (int p = 0; p < 3; ++p) row[NS + 3 * g + p] = gv[p][0] * m0v;
     }
   }
-  __syncthreads();
-  float* out = a.slab + (size_t)blockIdx.x * GB;
-  for (int k = threadIdx.x; k < GB; k += TPB) out[k] = gblk[k];
+  STAMP(10);
 }
 
 // ===================================================================== conv
@@ -293,10 +301,9 @@ __global__ __launch_bounds__(TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* img = lds;
   float* imgT = img + IM::CV_SIZE;
-  float* gblk = imgT + IM::TC_SIZE;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float* trash = gblk + B::SIZE;
-  float* acc = trash + 4 + w * (ACC + SCR);
+  float* gblk = imgT + IM::TC_SIZE;                                 // workgroup-shared gradient block (AccLds)
+  float* acc = gblk + B::SIZE + w * (ACC + SCR);
   float* scr = acc + ACC;
   stage_slice<IM::CV_SIZE>(img, a.img, threadIdx.x);
   stage_slice<IM::TC_SIZE>(imgT, a.imgT, threadIdx.x);
@@ -310,7 +317,9 @@ __global__ __launch_bounds__(TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
   const int zt[1] = {0};
   const int64_t ngroups = (a.N + a.npw - 1) / a.npw;
-  for (int64_t grp = (int64_t)blockIdx.x * WPB + w; grp < ngroups; grp += (int64_t)gridDim.x * WPB) {
+  const int64_t grp0 = (int64_t)blockIdx.x * WPB + w;
+  bool first = true;                                   // nothing written to this wave's slab row yet
+  for (int64_t grp = grp0; grp < ngroups; grp += (int64_t)gridDim.x * WPB) {
     const int64_t n0 = grp * a.npw;
     const int nn = (int)((a.N - n0 < a.npw) ? (a.N - n0) : a.npw);
     const int32_t e0 = a.rowptr[n0], e1 = a.rowptr[n0 + nn];
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
         QMsg2::Grads gr;
         QMsg2::backward(imgT + IM::TC_M2, lane, c2[0], d_so, d_vo, d_b, d_bv, gr);
         STAMP(10);
-        QMsg2::weight_grads(gblk + B::M2, trash, lane, 0, active, b2[0], bv2[0], c2[0], gr);
+        QMsg2::weight_grads<AccLds>(gblk + B::M2, first, lane, 0, active, b2[0], bv2[0], c2[0], gr);
       }
       {
         f4 d_so[1] = {f4{d_b[0], d_b[1], d_b[2], d_b[3]}};
@@ -407,7 +416,7 @@ __global__ __launch_bounds__(TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
         STAMP(11);
         QMsg1::backward(imgT + IM::TC_M1, lane, c1[0], d_so, d_vo, d_b, d_bv, gr);
         STAMP(12);
-        QMsg1::weight_grads(gblk + B::M1, trash, lane, 0, active, b1[0], bv1[0], c1[0], gr);
+        QMsg1::weight_grads<AccLds>(gblk + B::M1, first, lane, 0, active, b1[0], bv1[0], c1[0], gr);
       }
       float d_b0[16], d_bv0[3][3];
       {
@@ -417,7 +426,7 @@ __global__ __launch_bounds__(TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
         STAMP(13);
         QMsg0::backward(imgT + IM::TC_M0, lane, c0[0], d_so, d_vo, d_b0, d_bv0, gr);
         STAMP(14);
-        QMsg0::weight_grads(gblk + B::M0, trash, lane, 0, active, b0[0], bv0[0], c0[0], gr);
+        QMsg0::weight_grads<AccLds>(gblk + B::M0, first, lane, 0, active, b0[0], bv0[0], c0[0], gr);
       }
       STAMP(4);
       // ---- edge embedding: LayerNorm and GVP (weight gradients only; raw edge features get none)
@@ -426,11 +435,11 @@ __global__ __launch_bounds__(TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
         float d_ev[3][1] = {{d_bv0[0][2]}, {d_bv0[1][2]}, {d_bv0[2][2]}};
         f4 dga[2], dbe[2];
         ln_quad_bwd<ES, EV>(img + IM::CV_ELN, lane, e_pre[0], ev_pre[0], d_es, d_ev, dga, dbe);
-        ln_param_grads<ES>(gblk + B::E_LN, trash, lane, active, dga, dbe);
+        ln_param_grads<AccLds, ES>(gblk + B::E_LN, first, lane, active, dga, dbe);
         float d_in[8], d_inv[3][1];
         typename QEdge<NTE>::Grads gr;
         QEdge<NTE>::backward(imgT + IM::TC_EDGE, lane, ce[0], d_es, d_ev, d_in, d_inv, gr);
-        QEdge<NTE>::weight_grads(gblk + B::E_GVP, trash, lane, et[0], active, bse[0], bve[0], ce[0], gr);
+        QEdge<NTE>::template weight_grads<AccLds>(gblk + B::E_GVP, first, lane, et[0], active, bse[0], bve[0], ce[0], gr);
       }
       STAMP(5);
       // ---- d h[src]: unsorted sources -> float atomics on the zero-initialised g_src.  The rows
@@ -459,6 +468,7 @@ __global__ __launch_bounds__(TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
         __builtin_amdgcn_wave_barrier();
       }
       STAMP(6);
+      first = false;
       // ---- d h[dst]: segmented scan over the sorted targets, owned rows
       {
         float x[7] = {d_b0[12], d_b0[13], d_b0[14], d_b0[15], d_bv0[0][1], d_bv0[1][1], d_bv0[2][1]};
@@ -509,18 +519,19 @@ __global__ __launch_bounds__(TPB) void embed_bwd_kernel(EmbBArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* img = lds;
   float* imgT = img + IM::EMB_SIZE;
-  float* gblk = imgT + IM::TE_SIZE;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float* trash = gblk + B::SIZE;
-  float* scr = trash;
+  float* gblk = a.slab + ((size_t)blockIdx.x * WPB + w) * B::SIZE;  // this wave's private slab row
   stage_slice<IM::EMB_SIZE>(img, a.img, threadIdx.x);
   stage_slice<IM::TE_SIZE>(imgT, a.imgT, threadIdx.x);
-  for (int k = threadIdx.x; k < B::SIZE; k += TPB) gblk[k] = 0.f;
   __syncthreads();
   const int i = lane & 15, g = lane >> 4;
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
   const int64_t ntiles = (a.N + TILE - 1) / TILE;
-  for (int64_t tile = (int64_t)blockIdx.x * WPB + w; tile < ntiles; tile += (int64_t)gridDim.x * WPB) {
+  const int64_t tile0 = (int64_t)blockIdx.x * WPB + w;
+  if (tile0 >= ntiles)
+    for (int k = lane; k < B::SIZE; k += WAVE) gblk[k] = 0.f;
+  for (int64_t tile = tile0; tile < ntiles; tile += (int64_t)gridDim.x * WPB) {
+    const bool first = tile == tile0;
     const int64_t n = tile * TILE + i;
     const bool active = n < a.N;
     float bs[1][Q::SSTEPS], bv[1][3][1];
@@ -555,11 +566,11 @@ __global__ __launch_bounds__(TPB) void embed_bwd_kernel(EmbBArgs a) {
     }
     f4 dga[1], dbe[1];
     ln_quad_bwd<NS, NV>(img + IM::EMB_LN, lane, s_pre[0], v_pre[0], gs, gv, dga, dbe);
-    ln_param_grads<NS>(gblk + B::LN, trash, lane, active, dga, dbe);
+    ln_param_grads<AccRow, NS>(gblk + B::LN, first, lane, active, dga, dbe);
     float d_bs[Q::SSTEPS], d_bv[3][1];
     typename Q::Grads gr;
     Q::backward(imgT, lane, c[0], gs, gv, d_bs, d_bv, gr);
-    Q::weight_grads(gblk + B::GVP, trash, lane, type[0], active, bs[0], bv[0], c[0], gr);
+    Q::template weight_grads<AccRow>(gblk + B::GVP, first, lane, type[0], active, bs[0], bv[0], c[0], gr);
     if (active && a.g_x_s) {
 #pragma unroll
       for (int s = 0; s < Q::SSTEPS; ++s) {
@@ -572,11 +583,6 @@ __global__ __launch_bounds__(TPB) void embed_bwd_kernel(EmbBArgs a) {
       }
     }
   }
-  STAMP(8);
-  __syncthreads();
-  float* out = a.slab + (size_t)blockIdx.x * B::SIZE;
-  for (int k = threadIdx.x; k < B::SIZE; k += TPB) out[k] = gblk[k];
-  STAMP(9);
 }
 
 // dst[j] += sum_r slab[r][col0 + j], j < len.  A block owns 64 columns; its 16
@@ -623,7 +629,7 @@ __global__ __launch_bounds__(RED_COLS * RED_RG) void reduce_segments_kernel(SegT
   }
 }
 
-inline int grid_for(int64_t units) {
+inline int grid_for(int64_t units) {          // workgroups; slab rows = WPB x this
   int64_t wgs = (units + WPB - 1) / WPB;
   return (int)(wgs < 1 ? 1 : (wgs > MAX_GRID ? MAX_GRID : wgs));
 }
@@ -665,14 +671,13 @@ int node_update_bwd(const float* img_node, const float* img_head, const float* i
   typedef Image<0, 0> IM;
   NodeBArgs a{img_node, img_head, imgT_node, imgT_head, h, dh, mask0, mask1, g_out, g_up0, g_up1, g_up2, N, g_dh, g_h, slab};
   const int G = grid_for((N + TILE - 1) / TILE);
-  *grid = G;
+  *grid = G * WPB;
   if (with_head) {
-    const size_t lds = (size_t)(IM::ND_SIZE + IM::HD_SIZE + IM::TN_SIZE + IM::TH_SIZE + pad4(NODE_BLK + HEAD_BLK) + 4 +
-                                WPB * NODE_SCR) * sizeof(float);
+    const size_t lds = (size_t)(IM::ND_SIZE + IM::HD_SIZE + IM::TN_SIZE + IM::TH_SIZE + 0) * sizeof(float);
     hipFuncSetAttribute(reinterpret_cast<const void*>(node_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(node_bwd_kernel<true>, dim3(G), dim3(TPB), lds, st, a);
   } else {
-    const size_t lds = (size_t)(IM::ND_SIZE + IM::TN_SIZE + pad4(NODE_BLK) + 4 + WPB * NODE_SCR) * sizeof(float);
+    const size_t lds = (size_t)(IM::ND_SIZE + IM::TN_SIZE) * sizeof(float);
     hipFuncSetAttribute(reinterpret_cast<const void*>(node_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(node_bwd_kernel<false>, dim3(G), dim3(TPB), lds, st, a);
   }
@@ -683,9 +688,10 @@ template <int NTE>
 int conv_bwd_impl(ConvBArgs& a, int* grid, hipStream_t st) {
   typedef Image<0, NTE> IM;
   const int64_t groups = (a.N + a.npw - 1) / a.npw;
-  const int G = grid_for(groups);
+  const int64_t cwg = (groups + WPB - 1) / WPB;
+  const int G = (int)(cwg < 1 ? 1 : (cwg > 512 ? 512 : cwg));     // one slab row per workgroup
   *grid = G;
-  const size_t lds = (size_t)(IM::CV_SIZE + IM::TC_SIZE + ConvBlk<NTE>::SIZE + 4 + WPB * (ACC_ROWS * ROW + conv_scr<NTE>())) * sizeof(float);
+  const size_t lds = (size_t)(IM::CV_SIZE + IM::TC_SIZE + ConvBlk<NTE>::SIZE + WPB * (ACC_ROWS * ROW + conv_scr<NTE>())) * sizeof(float);
   hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_kernel<NTE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(conv_bwd_kernel<NTE>, dim3(G), dim3(TPB), lds, st, a);
   return 0;
@@ -709,8 +715,8 @@ template <int NTN>
 int embed_bwd_impl(EmbBArgs& a, int* grid, hipStream_t st) {
   typedef Image<NTN, 0> IM;
   const int G = grid_for((a.N + TILE - 1) / TILE);
-  *grid = G;
-  const size_t lds = (size_t)(IM::EMB_SIZE + IM::TE_SIZE + EmbBlk<NTN>::SIZE + 4 + WPB * QNode<NTN>::WG_SCRATCH) * sizeof(float);
+  *grid = G * WPB;
+  const size_t lds = (size_t)(IM::EMB_SIZE + IM::TE_SIZE) * sizeof(float);
   hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel<NTN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(embed_bwd_kernel<NTN>, dim3(G), dim3(TPB), lds, st, a);
   return 0;
