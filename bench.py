@@ -56,11 +56,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal on a box with fewer GPUs than ranks (BENCH_REHEARSAL=1): all ranks share cuda:0 and the
+    # timing collective runs over gloo.  The real multi-GPU run is one rank per GPU over RCCL ("nccl").
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    dev = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import davis_synth as ds
     from gvp_hip import ops
@@ -126,7 +132,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            t = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t)
 
