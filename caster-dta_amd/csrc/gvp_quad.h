@@ -213,21 +213,35 @@ __device__ __forceinline__ void outer_items(const f4 (&A)[MT], const f4 (&B)[NT_
       for (int nt = 0; nt < NT_; ++nt) acc[mt][nt] = mfma(A[mt][rr], B[nt][rr], acc[mt][nt]);
 }
 
-// Add a slot-ordered weight-gradient tile grid into W-layout block `dst` ([.][LD])
-// of the wave's PRIVATE slab row (global memory): plain store on the wave's first
-// tile, read-add-store afterwards.  No atomics anywhere: a workgroup-shared LDS
-// block with ds_add_f32 was measured at ~470 cycles per wave-instruction.
-// Two accumulation policies for weight-gradient partials:
-//   AccRow: the wave owns its row of the slab in global memory -> plain store on its
-//           first tile, private read-add-store afterwards (no atomics).  Best when a
-//           wave has one tile (node / embed backward): four lockstep waves adding
-//           into one LDS block were measured at ~470 cycles per ds_add_f32.
-//   AccLds: the workgroup shares one block in LDS, ds_add_f32; written to the slab
-//           once per workgroup.  Best when waves own several tiles at different
-//           phases (conv backward), where global read-add-store stalls instead.
-struct AccRow { static __device__ __forceinline__ void add(float* p, float v, bool first) { *p = first ? v : *p + v; } };
-struct AccLds { static __device__ __forceinline__ void add(float* p, float v, bool) { atomicAdd(p, v); } };
+// Weight-gradient partials are accumulated WITHOUT atomics, in a block that exactly
+// one wave owns.  Two places to keep that block:
+//   AccRow : a row of the slab in global memory -> plain store on the wave's first
+//            tile, read-add-store afterwards.  Node / embed backward (one tile per
+//            wave at Davis sizes, so almost always the plain-store case).
+//   AccPriv: a wave-private block in LDS, zeroed at kernel start, read-add-write per
+//            tile; the workgroup sums its waves' blocks once at the end and writes ONE
+//            slab row.  Conv backward (several tiles per wave).
+// A workgroup-SHARED LDS block with ds_add_f32 is what this replaces: LDS float
+// atomics retire ~1 lane per 3 cycles per CU (tools/ldsatomic_probe.hip: 193 cycles
+// for one 64-lane instruction, linear in active lanes and in waves), which made the
+// flush 63 % of the conv backward; a private ds_read/add/ds_write costs ~10 cycles.
+struct AccRow {
+  static constexpr bool BATCHED = false;
+  static __device__ __forceinline__ float load(const float* p, bool first) { return first ? 0.f : *p; }
+  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ void add(float* p, float v, bool first) { *p = first ? v : *p + v; }
+};
+struct AccPriv {
+  static constexpr bool BATCHED = true;
+  static __device__ __forceinline__ float load(const float* p, bool) { return *p; }
+  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ void add(float* p, float v, bool) { *p += v; }
+};
 
+// Add a slot-ordered weight-gradient tile grid into the W-layout block `dst` ([.][LD]).
+// BATCHED policies read the old values of a column tile before writing its sums (the
+// targets of one call are distinct elements), so the reads are in flight together
+// instead of one read-add-write round trip per element.
 template <class Acc, class RowSegs, class ColSegs, int MT, int NT_>
 __device__ __forceinline__ void flush_slots(float* dst, bool first, int LD, const f4 (&acc)[MT][NT_], int lane) {
   const int n = lane & 15, gq_ = lane >> 4;
@@ -235,14 +249,33 @@ __device__ __forceinline__ void flush_slots(float* dst, bool first, int LD, cons
   for (int nt = 0; nt < NT_; ++nt) {
     const int cs = 4 * nt + (n >> 2);
     const int col = cs < ColSegs::steps ? ColSegs::col(cs, n & 3) : -1;
+    if constexpr (Acc::BATCHED) {                   // one column tile at a time: MT x 4 reads in flight, then the writes
+      int idx[MT][4];
+      float old[MT][4];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = 4 * gq_ + r, rs = 4 * mt + (m >> 2);
-        const int row = rs < RowSegs::steps ? RowSegs::col(rs, m & 3) : -1;
-        if (row >= 0 && col >= 0) Acc::add(dst + row * LD + col, acc[mt][nt][r], first);
-      }
+        for (int r = 0; r < 4; ++r) {
+          const int m = 4 * gq_ + r, rs = 4 * mt + (m >> 2);
+          const int row = rs < RowSegs::steps ? RowSegs::col(rs, m & 3) : -1;
+          idx[mt][r] = (row >= 0 && col >= 0) ? row * LD + col : -1;
+          old[mt][r] = idx[mt][r] >= 0 ? Acc::load(dst + idx[mt][r], first) : 0.f;
+        }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (idx[mt][r] >= 0) Acc::store(dst + idx[mt][r], old[mt][r] + acc[mt][nt][r]);
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 4 * gq_ + r, rs = 4 * mt + (m >> 2);
+          const int row = rs < RowSegs::steps ? RowSegs::col(rs, m & 3) : -1;
+          if (row >= 0 && col >= 0) Acc::add(dst + row * LD + col, acc[mt][nt][r], first);
+        }
+    }
   }
 }
 

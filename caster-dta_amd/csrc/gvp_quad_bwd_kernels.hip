@@ -44,25 +44,24 @@ constexpr int TILE = 16;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
     __builtin_amdgcn_sched_barrier(0);                                                       \
     if (g_stamp_buf_bwd && (threadIdx.x & 63) == 0)                                          \
-      g_stamp_buf_bwd[((size_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * 16 + (slot)] = t_;    \
+      g_stamp_buf_bwd[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (slot)] = t_;    \
   } while (0)
 #else
 #define STAMP(slot) do {} while (0)
 #endif
 constexpr int MAX_GRID = kBwdMaxGrid;  // persistent workgroups; every WAVE owns one slab row
-constexpr int ACC_ROWS = 32;           // target nodes a wave owns at most (conv backward accumulator)
 
-template <int NFLOATS>
+template <int NFLOATS, int NTHR = TPB>
 __device__ __forceinline__ void stage_slice(float* lds, const float* __restrict__ src, int tid) {
   static_assert(NFLOATS % 4 == 0, "image slices are whole float4s");
-  constexpr int NF4 = NFLOATS / 4, IT = (NF4 + TPB - 1) / TPB;
+  constexpr int NF4 = NFLOATS / 4, IT = (NF4 + NTHR - 1) / NTHR;
   const f4* s = reinterpret_cast<const f4*>(src);
   f4* d = reinterpret_cast<f4*>(lds);
   f4 v[IT];
 #pragma unroll
-  for (int k = 0; k < IT; ++k) { const int idx = tid + k * TPB; if (idx < NF4) v[k] = s[idx]; }
+  for (int k = 0; k < IT; ++k) { const int idx = tid + k * NTHR; if (idx < NF4) v[k] = s[idx]; }
 #pragma unroll
-  for (int k = 0; k < IT; ++k) { const int idx = tid + k * TPB; if (idx < NF4) d[idx] = v[k]; }
+  for (int k = 0; k < IT; ++k) { const int idx = tid + k * NTHR; if (idx < NF4) d[idx] = v[k]; }
 }
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
@@ -283,8 +282,13 @@ struct ConvBlk {
   static constexpr int E_GVP = 0, E_LN = LEdgeGvp::size(NTE), E_SIZE = pad4(E_LN + 2 * ES);
   static constexpr int M0 = E_SIZE, M1 = M0 + LMsg0::size(0), M2 = M1 + LMsg::size(0), SIZE = pad4(M2 + LMsg::size(0));
 };
+// One workgroup of 8 waves per CU (2 per SIMD) owning all 160 KB of LDS:
+//   [forward slices | transposed slices | per wave: private gradient block, g_src scratch]
+constexpr int CB_WPB = 8, CB_TPB = WAVE * CB_WPB, CB_MAX_GRID = 256;
+constexpr int CB_SCR = (TILE / 2) * ROW + TILE;      // half a tile of [28]-rows + 16 source ids (g_src transpose)
 template <int NTE>
-constexpr int conv_scr() { return 512; }   // per-wave LDS scratch: [16][28] gradient rows + 16 source ids (g_src transpose)
+constexpr int conv_bwd_lds_floats() { return Image<0, NTE>::CV_SIZE + Image<0, NTE>::TC_SIZE + CB_WPB * (ConvBlk<NTE>::SIZE + CB_SCR); }
+static_assert(conv_bwd_lds_floats<1>() * 4 <= 160 * 1024 && conv_bwd_lds_floats<0>() * 4 <= 160 * 1024, "conv backward LDS plan exceeds the CU");
 
 struct ConvBArgs {
   const float* img; const float* imgT;
@@ -294,21 +298,20 @@ struct ConvBArgs {
 };
 
 template <int NTE>
-__global__ __launch_bounds__(TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
+__global__ __launch_bounds__(CB_TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
   typedef Image<0, NTE> IM;
   typedef ConvBlk<NTE> B;
-  constexpr int ACC = ACC_ROWS * ROW, SCR = conv_scr<NTE>();
+  constexpr int PW = B::SIZE + CB_SCR;                                // per-wave LDS floats
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* img = lds;
   float* imgT = img + IM::CV_SIZE;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float* gblk = imgT + IM::TC_SIZE;                                 // workgroup-shared gradient block (AccLds)
-  float* acc = gblk + B::SIZE + w * (ACC + SCR);
-  float* scr = acc + ACC;
-  stage_slice<IM::CV_SIZE>(img, a.img, threadIdx.x);
-  stage_slice<IM::TC_SIZE>(imgT, a.imgT, threadIdx.x);
-  for (int k = threadIdx.x; k < B::SIZE; k += TPB) gblk[k] = 0.f;
-  for (int k = lane; k < ACC; k += WAVE) acc[k] = 0.f;
+  float* blocks = imgT + IM::TC_SIZE;
+  float* gblk = blocks + w * PW;                                      // this wave's private gradient block (AccPriv)
+  float* scr = gblk + B::SIZE;
+  stage_slice<IM::CV_SIZE, CB_TPB>(img, a.img, threadIdx.x);
+  stage_slice<IM::TC_SIZE, CB_TPB>(imgT, a.imgT, threadIdx.x);
+  for (int k = lane; k < B::SIZE / 4; k += WAVE) reinterpret_cast<f4*>(gblk)[k] = f4{0.f, 0.f, 0.f, 0.f};
   STAMP(0);
   __syncthreads();
   STAMP(1);
@@ -317,12 +320,19 @@ __global__ __launch_bounds__(TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
   const int zt[1] = {0};
   const int64_t ngroups = (a.N + a.npw - 1) / a.npw;
-  const int64_t grp0 = (int64_t)blockIdx.x * WPB + w;
-  bool first = true;                                   // nothing written to this wave's slab row yet
-  for (int64_t grp = grp0; grp < ngroups; grp += (int64_t)gridDim.x * WPB) {
+  const int64_t grp0 = (int64_t)blockIdx.x * CB_WPB + w;
+  const bool first = false;                            // AccPriv: the block starts zeroed
+  float carry[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // lane i == 0: running sum of the target that straddles into this tile
+  int carry_dst = -1;
+  for (int64_t grp = grp0; grp < ngroups; grp += (int64_t)gridDim.x * CB_WPB) {
     const int64_t n0 = grp * a.npw;
     const int nn = (int)((a.N - n0 < a.npw) ? (a.N - n0) : a.npw);
     const int32_t e0 = a.rowptr[n0], e1 = a.rowptr[n0 + nn];
+    // owned targets without incoming edges get a zero row (every other owned row is stored below)
+    for (int k = lane; k < nn * ROW; k += WAVE) {
+      const int64_t nd = n0 + k / ROW;
+      if (a.rowptr[nd + 1] == a.rowptr[nd]) a.g_dst[n0 * ROW + k] = 0.f;
+    }
     for (int32_t base = e0; base < e1; base += TILE) {
       const int32_t p = base + i;
       const bool active = p < e1;
@@ -407,7 +417,7 @@ __global__ __launch_bounds__(TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
         QMsg2::Grads gr;
         QMsg2::backward(imgT + IM::TC_M2, lane, c2[0], d_so, d_vo, d_b, d_bv, gr);
         STAMP(10);
-        QMsg2::weight_grads<AccLds>(gblk + B::M2, first, lane, 0, active, b2[0], bv2[0], c2[0], gr);
+        QMsg2::weight_grads<AccPriv>(gblk + B::M2, first, lane, 0, active, b2[0], bv2[0], c2[0], gr);
       }
       {
         f4 d_so[1] = {f4{d_b[0], d_b[1], d_b[2], d_b[3]}};
@@ -416,7 +426,7 @@ __global__ __launch_bounds__(TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
         STAMP(11);
         QMsg1::backward(imgT + IM::TC_M1, lane, c1[0], d_so, d_vo, d_b, d_bv, gr);
         STAMP(12);
-        QMsg1::weight_grads<AccLds>(gblk + B::M1, first, lane, 0, active, b1[0], bv1[0], c1[0], gr);
+        QMsg1::weight_grads<AccPriv>(gblk + B::M1, first, lane, 0, active, b1[0], bv1[0], c1[0], gr);
       }
       float d_b0[16], d_bv0[3][3];
       {
@@ -426,7 +436,7 @@ __global__ __launch_bounds__(TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
         STAMP(13);
         QMsg0::backward(imgT + IM::TC_M0, lane, c0[0], d_so, d_vo, d_b0, d_bv0, gr);
         STAMP(14);
-        QMsg0::weight_grads<AccLds>(gblk + B::M0, first, lane, 0, active, b0[0], bv0[0], c0[0], gr);
+        QMsg0::weight_grads<AccPriv>(gblk + B::M0, first, lane, 0, active, b0[0], bv0[0], c0[0], gr);
       }
       STAMP(4);
       // ---- edge embedding: LayerNorm and GVP (weight gradients only; raw edge features get none)
@@ -435,68 +445,81 @@ __global__ __launch_bounds__(TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
         float d_ev[3][1] = {{d_bv0[0][2]}, {d_bv0[1][2]}, {d_bv0[2][2]}};
         f4 dga[2], dbe[2];
         ln_quad_bwd<ES, EV>(img + IM::CV_ELN, lane, e_pre[0], ev_pre[0], d_es, d_ev, dga, dbe);
-        ln_param_grads<AccLds, ES>(gblk + B::E_LN, first, lane, active, dga, dbe);
+        ln_param_grads<AccPriv, ES>(gblk + B::E_LN, first, lane, active, dga, dbe);
         float d_in[8], d_inv[3][1];
         typename QEdge<NTE>::Grads gr;
         QEdge<NTE>::backward(imgT + IM::TC_EDGE, lane, ce[0], d_es, d_ev, d_in, d_inv, gr);
-        QEdge<NTE>::template weight_grads<AccLds>(gblk + B::E_GVP, first, lane, et[0], active, bse[0], bve[0], ce[0], gr);
+        QEdge<NTE>::template weight_grads<AccPriv>(gblk + B::E_GVP, first, lane, et[0], active, bse[0], bve[0], ce[0], gr);
       }
       STAMP(5);
       // ---- d h[src]: unsorted sources -> float atomics on the zero-initialised g_src.  The rows
-      // are transposed through LDS so that one wave-instruction adds two whole 112-B rows
-      // (lane-per-row atomics run an order of magnitude slower).
+      // are transposed through LDS (half a tile at a time) so that one wave-instruction adds
+      // two whole 112-B rows (lane-per-row atomics run an order of magnitude slower).
       {
-        float* trow = scr;                          // [16][28]
-        int* tsrc = reinterpret_cast<int*>(scr + TILE * ROW);
-        *reinterpret_cast<f4*>(trow + i * ROW + 4 * g) = f4{d_b0[0], d_b0[1], d_b0[2], d_b0[3]};
-#pragma unroll
-        for (int d = 0; d < 3; ++d) trow[i * ROW + NS + 3 * g + d] = d_bv0[d][0];
+        float* trow = scr;                          // [8][28]
+        int* tsrc = reinterpret_cast<int*>(scr + (TILE / 2) * ROW);
         if (g == 0) tsrc[i] = active ? src : -1;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int half = lane / ROW, col = lane - half * ROW;      // lanes 0..27 -> row 2k, 28..55 -> row 2k+1
-        if (half < 2) {
 #pragma unroll
-          for (int k = 0; k < TILE / 2; ++k) {
-            const int r = 2 * k + half;
-            const int sr = tsrc[r];
-            if (sr >= 0) atomicAdd(a.g_src + (int64_t)sr * ROW + col, trow[r * ROW + col]);
+        for (int hb = 0; hb < 2; ++hb) {
+          if ((i >> 3) == hb) {
+            float* tr = trow + (i & 7) * ROW;
+            *reinterpret_cast<f4*>(tr + 4 * g) = f4{d_b0[0], d_b0[1], d_b0[2], d_b0[3]};
+#pragma unroll
+            for (int d = 0; d < 3; ++d) tr[NS + 3 * g + d] = d_bv0[d][0];
           }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          if (half < 2) {
+#pragma unroll
+            for (int k = 0; k < TILE / 4; ++k) {
+              const int r = 2 * k + half;
+              const int sr = tsrc[8 * hb + r];
+              if (sr >= 0) atomicAdd(a.g_src + (int64_t)sr * ROW + col, trow[r * ROW + col]);
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
       }
       STAMP(6);
-      first = false;
-      // ---- d h[dst]: segmented scan over the sorted targets, owned rows
+      // ---- d h[dst]: the wave owns its targets and their edges are consecutive, so a row is
+      // the segment sum of a DPP scan plus (for the one target that straddles tiles) a carry
+      // kept in registers; plain stores, the later store of a straddling row overwrites the
+      // partial one stored at the end of the previous tile.
       {
         float x[7] = {d_b0[12], d_b0[13], d_b0[14], d_b0[15], d_bv0[0][1], d_bv0[1][1], d_bv0[2][1]};
+        if (i == 0 && active && dst == carry_dst) {
+#pragma unroll
+          for (int k = 0; k < 7; ++k) x[k] += carry[k];
+        }
         seg_scan16<7>(dst, x);
         const int nxt = __builtin_amdgcn_update_dpp(-1, dst, 0x100 | 1, 0xf, 0xf, false);
         if (active && (i == TILE - 1 || nxt != dst)) {
-          float* row = acc + (dst - (int)n0) * ROW;
+          float* row = a.g_dst + (int64_t)dst * ROW;
+          *reinterpret_cast<f4*>(row + 4 * g) = f4{x[0], x[1], x[2], x[3]};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) atomicAdd(row + 4 * g + r, x[r]);
-#pragma unroll
-          for (int d = 0; d < 3; ++d) atomicAdd(row + NS + 3 * g + d, x[4 + d]);
+          for (int d = 0; d < 3; ++d) row[NS + 3 * g + d] = x[4 + d];
         }
+        carry_dst = __builtin_amdgcn_update_dpp(-1, dst, 0x100 | 15, 0xf, 0xf, false);       // lane 0 <- lane 15
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+          carry[k] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x[k]), 0x100 | 15, 0xf, 0xf, false));
       }
     }
     STAMP(7);
-    // flush this group's owned rows and clear the accumulator for the next group
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    float* out = a.g_dst + n0 * ROW;
-    for (int k = lane; k < nn * ROW; k += WAVE) { out[k] = acc[k]; acc[k] = 0.f; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
   }
   STAMP(8);
+  // one slab row per workgroup: sum of its waves' private blocks
   __syncthreads();
   float* out = a.slab + (size_t)blockIdx.x * B::SIZE;
-  for (int k = threadIdx.x; k < B::SIZE; k += TPB) out[k] = gblk[k];
+  for (int k = threadIdx.x; k < B::SIZE; k += CB_TPB) {
+    float t = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < CB_WPB; ++ww) t += blocks[ww * PW + k];
+    out[k] = t;
+  }
   STAMP(9);
 }
 
@@ -688,12 +711,12 @@ template <int NTE>
 int conv_bwd_impl(ConvBArgs& a, int* grid, hipStream_t st) {
   typedef Image<0, NTE> IM;
   const int64_t groups = (a.N + a.npw - 1) / a.npw;
-  const int64_t cwg = (groups + WPB - 1) / WPB;
-  const int G = (int)(cwg < 1 ? 1 : (cwg > 512 ? 512 : cwg));     // one slab row per workgroup
+  const int64_t cwg = (groups + CB_WPB - 1) / CB_WPB;
+  const int G = (int)(cwg < 1 ? 1 : (cwg > CB_MAX_GRID ? CB_MAX_GRID : cwg));     // one workgroup per CU, one slab row each
   *grid = G;
-  const size_t lds = (size_t)(IM::CV_SIZE + IM::TC_SIZE + ConvBlk<NTE>::SIZE + WPB * (ACC_ROWS * ROW + conv_scr<NTE>())) * sizeof(float);
+  const size_t lds = (size_t)conv_bwd_lds_floats<NTE>() * sizeof(float);
   hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_kernel<NTE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(conv_bwd_kernel<NTE>, dim3(G), dim3(TPB), lds, st, a);
+  hipLaunchKernelGGL(conv_bwd_kernel<NTE>, dim3(G), dim3(CB_TPB), lds, st, a);
   return 0;
 }
 
@@ -704,7 +727,7 @@ int conv_bwd(int nt_edge, const float* img, const float* imgT, const float* h, c
   int64_t deg = N > 0 ? (E + N - 1) / N : 1;
   if (deg < 1) deg = 1;
   int npw = (int)((2 * TILE - 2) / deg);
-  npw = npw < 1 ? 1 : (npw > ACC_ROWS ? ACC_ROWS : npw);
+  npw = npw < 1 ? 1 : npw;
   ConvBArgs a{img, imgT, h, e_s, e_v, etypes, rowptr, eperm, esrc, edst, N, npw, mean, g_dh, g_src, g_dst, slab};
   if (nt_edge == 0) return conv_bwd_impl<0>(a, grid, st);
   if (nt_edge == 1) return conv_bwd_impl<1>(a, grid, st);
