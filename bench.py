@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--cache-csr", action="store_true", help="reuse the CSR tables across steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only", default=None, choices=["protein", "drug"],
+                    help="diagnostic: time one encoder alone (the reported metric needs both; never the default)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -83,7 +85,9 @@ def main():
     side = torch.cuda.Stream(device=dev)
 
     train = args.mode == "fwdbwd"
-    enc_params = [p for p in list(model.protein_gnn.parameters()) + list(model.molecule_gnn.parameters()) if p.numel()]
+    prot_params = [p for p in model.protein_gnn.parameters() if p.numel()]
+    drug_params = [p for p in model.molecule_gnn.parameters() if p.numel()]
+    enc_params = prot_params + drug_params
     for p in model.parameters():
         p.requires_grad_(train)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -92,6 +96,12 @@ def main():
 
     def step():
         main_s = torch.cuda.current_stream()
+        if args.only == "protein":                    # diagnostic: one encoder alone
+            residues = model.protein_gnn(**pdata)
+            return torch.autograd.grad([residues], prot_params, [g_res]) if train else residues
+        if args.only == "drug":
+            atoms = model.molecule_gnn(**mdata)
+            return torch.autograd.grad([atoms], drug_params, [g_atm]) if train else atoms
         side.wait_stream(main_s)
         with torch.cuda.stream(side):                 # drug graphs are tiny: run them beside the protein kernels
             atoms = model.molecule_gnn(**mdata)

@@ -12,7 +12,7 @@ struct QuadOffsets {
   int embT, convT0, nodeT0, layerT_stride, headT;     // transposed slices (backward)
 };
 
-constexpr int kBwdMaxGrid = 1024;   // persistent workgroups of the backward kernels; slab rows = 4 per workgroup
+constexpr int kBwdMaxGrid = 256;    // persistent workgroups of the backward kernels (one per CU) = slab rows per stage
 
 namespace quad {
 int offsets(int nt_node, int nt_edge, int num_convs, QuadOffsets* o);
@@ -28,10 +28,11 @@ int node_update(const float* img_node, const float* img_head, const float* h, co
 // ---- backward (gvp_quad_bwd_kernels.hip).  Weight gradients are written as one
 // partial block per workgroup into `slab` ([grid][block floats]); `grid` returns
 // the number of rows to reduce.
-int node_update_bwd(const float* img_node, const float* img_head, const float* imgT_node, const float* imgT_head,
-                    const float* h, const float* dh, const float* mask0, const float* mask1, const float* g_out,
-                    const float* g_up0, const float* g_up1, const float* g_up2, int64_t N, int with_head,
-                    float* g_dh, float* g_h, float* slab, int* grid, hipStream_t st);
+int node_update_bwd(const float* img_node, const float* imgT_node, const float* h, const float* dh,
+                    const float* mask0, const float* mask1, const float* g_up0, const float* g_up1,
+                    const float* g_up2, int64_t N, float* g_dh, float* g_h, float* slab, int* grid, hipStream_t st);
+int head_bwd(const float* img_head, const float* imgT_head, const float* h_out, const float* g_out, int64_t N,
+             float* g_h_out, float* slab, int* grid, hipStream_t st);
 int conv_bwd(int nt_edge, const float* img, const float* imgT, const float* h, const float* e_s, const float* e_v,
              const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
              const int32_t* edst, int64_t N, int64_t E, int mean, const float* g_dh, float* g_src, float* g_dst,

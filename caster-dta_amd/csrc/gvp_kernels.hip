@@ -323,12 +323,15 @@ void node_update_kernel(NodeUpdateArgs a) {
   const int lane = threadIdx.x;
   const int64_t n0 = (int64_t)blockIdx.x * WAVE;
   const int cnt = (int)((a.N - n0 < WAVE) ? (a.N - n0) : WAVE);
+  float row_keep[HEAD ? ROW : 1];
   if (lane < cnt) {
     float x[ROW], dh[ROW], row[ROW], out[OUT];
     load_row28(a.h, n0 + lane, x);
     load_row28(a.dh, n0 + lane, dh);
     node_update_item<HEAD>(a.params, a.L, a.layer, x, dh, row, out);
     if (HEAD) {
+#pragma unroll
+      for (int k = 0; k < ROW; ++k) row_keep[k] = row[k];
 #pragma unroll
       for (int k = 0; k < OUT; ++k) lds[lane * RS + k] = out[k];
     } else {
@@ -339,6 +342,15 @@ void node_update_kernel(NodeUpdateArgs a) {
   __syncthreads();
   if (HEAD) stage_out<OUT, RS>(a.out + n0 * OUT, cnt * OUT, lds, lane);
   else stage_out<ROW, RS>(a.h_out + n0 * ROW, cnt * ROW, lds, lane);
+  if (HEAD && a.h_out) {                      // optional with the head: the head's input, kept for a backward pass
+    __syncthreads();
+    if (lane < cnt) {
+#pragma unroll
+      for (int k = 0; k < ROW; ++k) lds[lane * RS + k] = row_keep[k];
+    }
+    __syncthreads();
+    stage_out<ROW, RS>(a.h_out + n0 * ROW, cnt * ROW, lds, lane);
+  }
 }
 
 // ------------------------------------------------------------- GINE
@@ -374,35 +386,54 @@ __global__ __launch_bounds__(WAVE * GINE_APB) void gine_conv_kernel(GineArgs a) 
   const int ke = a.net + a.ed;
   const int xw = a.cin - a.nt;                  // raw feature width
   float hval = 0.f;
-  if (valid && lane < a.cin) {
-    float wa[GINE_MAXKE];                        // this channel's W_e columns for the bond features
+  // The atom's edge metadata is fetched lane-parallel (lane q <- q-th incoming edge) and handed to the
+  // channel lanes by readlane, so an atom costs three dependent memory hops (rowptr -> eperm/esrc ->
+  // bond features / source row) instead of three per edge.
+  int32_t p0 = 0, p1 = 0;
+  if (valid) { p0 = a.rowptr[i]; p1 = a.rowptr[i + 1]; }
+  p0 = __builtin_amdgcn_readfirstlane(p0);
+  p1 = __builtin_amdgcn_readfirstlane(p1);
+  float wa[GINE_MAXKE];                          // this channel's W_e columns for the bond features
+  float bias = 0.f;
+  if (lane < a.cin) {
 #pragma unroll
     for (int k = 0; k < GINE_MAXKE; ++k) wa[k] = (k < a.ed) ? a.we[lane * ke + a.net + k] : 0.f;
-    const float bias = a.be[lane];
-    auto xcat = [&](int64_t n) -> float {
-      if (lane < a.nt) return ((int)a.ntypes[n] == lane) ? 1.f : 0.f;
-      return a.x[n * xw + (lane - a.nt)];
-    };
-    float agg = 0.f;
-    const int32_t p0 = a.rowptr[i], p1 = a.rowptr[i + 1];
-    for (int32_t p = p0; p < p1; ++p) {
-      const int32_t eid = a.eperm[p];
-      const int32_t j = a.esrc[p];
-      float e = bias;
-      if (a.net > 0) {                            // one-hot bond type = column lookup
-        int et = (int)a.etypes[eid];
-        et = et < 0 ? 0 : (et >= a.net ? a.net - 1 : et);
-        e += a.we[lane * ke + et];
-      }
-      const float* ea = a.eattr + (int64_t)eid * a.ed;
-#pragma unroll
-      for (int k = 0; k < GINE_MAXKE; ++k)
-        if (k < a.ed) e = fmaf(wa[k], ea[k], e);
-      const float mj = xcat(j) + e;
-      agg += mj > 0.f ? mj : 0.f;
-    }
-    hval = fmaf(1.0f + a.eps[0], xcat(i), agg);
+    bias = a.be[lane];
   }
+  auto xcat = [&](int64_t n) -> float {
+    if (lane < a.nt) return ((int)a.ntypes[n] == lane) ? 1.f : 0.f;
+    return a.x[n * xw + (lane - a.nt)];
+  };
+  float agg = 0.f;
+  for (int32_t c0 = p0; c0 < p1; c0 += WAVE) {
+    const int n = (p1 - c0 < WAVE) ? (p1 - c0) : WAVE;
+    int32_t m_eid = 0, m_src = 0, m_et = 0;
+    if (lane < n) {
+      m_eid = a.eperm[c0 + lane];
+      m_src = a.esrc[c0 + lane];
+      if (a.net > 0) {                            // one-hot bond type = column lookup
+        m_et = (int)a.etypes[m_eid];
+        m_et = m_et < 0 ? 0 : (m_et >= a.net ? a.net - 1 : m_et);
+      }
+    }
+#pragma unroll 4
+    for (int q = 0; q < n; ++q) {
+      const int32_t eid = __builtin_amdgcn_readlane(m_eid, q);
+      const int32_t j = __builtin_amdgcn_readlane(m_src, q);
+      const int32_t et = __builtin_amdgcn_readlane(m_et, q);
+      if (lane < a.cin) {
+        float e = bias;
+        if (a.net > 0) e += a.we[lane * ke + et];
+        const float* ea = a.eattr + (int64_t)eid * a.ed;
+#pragma unroll
+        for (int k = 0; k < GINE_MAXKE; ++k)
+          if (k < a.ed) e = fmaf(wa[k], ea[k], e);
+        const float mj = xcat(j) + e;
+        agg += mj > 0.f ? mj : 0.f;
+      }
+    }
+  }
+  if (valid && lane < a.cin) hval = fmaf(1.0f + a.eps[0], xcat(i), agg);
   hbuf[w][lane] = hval;
   __syncthreads();
   float t = 0.f;
@@ -468,9 +499,11 @@ __global__ __launch_bounds__(WAVE * GINE_APB) void gine_bwd_kernel(GineBArgs a) 
   for (int k = 0; k < ED; ++k) acc_wa[k] = 0.f;
 #pragma unroll
   for (int k = 0; k < NET; ++k) acc_wt[k] = 0.f;
-  float wa[ED > 0 ? ED : 1];
+  float wa[ED > 0 ? ED : 1], wt[NET > 0 ? NET : 1];     // this channel's W_e columns: bond features, bond types
 #pragma unroll
   for (int k = 0; k < ED; ++k) wa[k] = lane < CIN ? a.we[lane * KE + NET + k] : 0.f;
+#pragma unroll
+  for (int k = 0; k < NET; ++k) wt[k] = lane < CIN ? a.we[lane * KE + k] : 0.f;
   const float bias_e = lane < CIN ? a.be[lane] : 0.f;
   const float eps1 = 1.0f + a.eps[0];
   auto xcat = [&](int64_t n) -> float {
@@ -484,23 +517,71 @@ __global__ __launch_bounds__(WAVE * GINE_APB) void gine_bwd_kernel(GineBArgs a) 
     const bool valid = i < a.N;
     float xi = 0.f, hval = 0.f;
     int32_t p0 = 0, p1 = 0;
+    if (valid) { p0 = a.rowptr[i]; p1 = a.rowptr[i + 1]; }
+    p0 = __builtin_amdgcn_readfirstlane(p0);
+    p1 = __builtin_amdgcn_readfirstlane(p1);
+    const int deg = p1 - p0;
+    // Up to 64 incoming edges (every molecule): edge metadata fetched lane-parallel and handed out
+    // by readlane (three dependent hops per ATOM, not per edge); the ReLU pattern of the messages is
+    // kept as a bit mask plus per-lane sums so that the edge half of the backward needs no loads.
+    const bool fast = deg <= WAVE;
+    int32_t m_eid = 0, m_src = 0, m_et = 0;
+    if (fast && lane < deg) {
+      m_eid = a.eperm[p0 + lane];
+      m_src = a.esrc[p0 + lane];
+      if (NET > 0) {
+        m_et = (int)a.etypes[m_eid];
+        m_et = m_et < 0 ? 0 : (m_et >= NET ? NET - 1 : m_et);
+      }
+    }
+    unsigned long long pos = 0ull;               // bit q: message of edge q passed the ReLU (this channel)
+    float cnt = 0.f, s_a[ED > 0 ? ED : 1], s_t[NET > 0 ? NET : 1];
+#pragma unroll
+    for (int k = 0; k < ED; ++k) s_a[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NET; ++k) s_t[k] = 0.f;
     if (valid && lane < CIN) {
       xi = xcat(i);
-      p0 = a.rowptr[i]; p1 = a.rowptr[i + 1];
       float agg = 0.f;
-      for (int32_t p = p0; p < p1; ++p) {
-        const int32_t eid = a.eperm[p];
-        float e = bias_e;
-        if (NET > 0) {
-          int et = (int)a.etypes[eid];
-          et = et < 0 ? 0 : (et >= NET ? NET - 1 : et);
-          e += a.we[lane * KE + et];
-        }
-        const float* ea = a.eattr + (int64_t)eid * ED;
+      if (fast) {
+#pragma unroll 4
+        for (int q = 0; q < deg; ++q) {
+          const int32_t eid = __builtin_amdgcn_readlane(m_eid, q);
+          const int32_t j = __builtin_amdgcn_readlane(m_src, q);
+          const int32_t et = __builtin_amdgcn_readlane(m_et, q);
+          float e = bias_e;
 #pragma unroll
-        for (int k = 0; k < ED; ++k) e = fmaf(wa[k], ea[k], e);
-        const float mj = xcat(a.esrc[p]) + e;
-        agg += mj > 0.f ? mj : 0.f;
+          for (int k = 0; k < NET; ++k) e += (k == et) ? wt[k] : 0.f;
+          const float* ea = a.eattr + (int64_t)eid * ED;
+          float eav[ED > 0 ? ED : 1];
+#pragma unroll
+          for (int k = 0; k < ED; ++k) { eav[k] = ea[k]; e = fmaf(wa[k], eav[k], e); }
+          const float mj = xcat(j) + e;
+          if (mj > 0.f) {
+            agg += mj;
+            pos |= 1ull << q;
+            cnt += 1.f;
+#pragma unroll
+            for (int k = 0; k < ED; ++k) s_a[k] += eav[k];
+#pragma unroll
+            for (int k = 0; k < NET; ++k) s_t[k] += (k == et) ? 1.f : 0.f;
+          }
+        }
+      } else {
+        for (int32_t p = p0; p < p1; ++p) {
+          const int32_t eid = a.eperm[p];
+          float e = bias_e;
+          if (NET > 0) {
+            int et = (int)a.etypes[eid];
+            et = et < 0 ? 0 : (et >= NET ? NET - 1 : et);
+            e += a.we[lane * KE + et];
+          }
+          const float* ea = a.eattr + (int64_t)eid * ED;
+#pragma unroll
+          for (int k = 0; k < ED; ++k) e = fmaf(wa[k], ea[k], e);
+          const float mj = xcat(a.esrc[p]) + e;
+          agg += mj > 0.f ? mj : 0.f;
+        }
       }
       hval = fmaf(eps1, xi, agg);
     }
@@ -547,6 +628,18 @@ __global__ __launch_bounds__(WAVE * GINE_APB) void gine_bwd_kernel(GineBArgs a) 
       for (int k = 0; k < CHID; ++k) dh = fmaf(w0s[k * S0 + lane], dtbuf[w][k], dh);
       acc_eps = fmaf(dh, xi, acc_eps);
       if (a.g_x && lane >= NT) atomicAdd(a.g_x + i * XW + (lane - NT), eps1 * dh);
+      if (fast) {
+        acc_be = fmaf(dh, cnt, acc_be);
+#pragma unroll
+        for (int k = 0; k < NET; ++k) acc_wt[k] = fmaf(dh, s_t[k], acc_wt[k]);
+#pragma unroll
+        for (int k = 0; k < ED; ++k) acc_wa[k] = fmaf(dh, s_a[k], acc_wa[k]);
+        if (a.g_x && lane >= NT)
+          for (int q = 0; q < deg; ++q) {
+            const int32_t j = __builtin_amdgcn_readlane(m_src, q);
+            if ((pos >> q) & 1ull) atomicAdd(a.g_x + (int64_t)j * XW + (lane - NT), dh);
+          }
+      } else
       for (int32_t p = p0; p < p1; ++p) {
         const int32_t eid = a.eperm[p];
         const int32_t j = a.esrc[p];
@@ -768,36 +861,39 @@ int64_t cgvp_bwd_workspace_floats(const cgvp_dims* dims, const cgvp_layout* layo
   int emb, ce, ct, nd, hd;
   if (int rc = quad::bwd_block_sizes(layout->nt_node, layout->nt_edge, &emb, &ce, &ct, &nd, &hd)) return rc;
   int mx = emb > ct ? emb : ct;
-  mx = mx > hd ? mx : hd;
-  return (int64_t)kBwdMaxGrid * 4 * mx;
+  mx = mx > nd + hd ? mx : nd + hd;
+  return (int64_t)kBwdMaxGrid * mx;
 }
 
 int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image, int32_t layer,
                          const float* h, const float* dh, const float* mask0, const float* mask1,
-                         const float* g_out, const float* g_up0, const float* g_up1, const float* g_up2,
-                         int64_t N, int32_t with_head, float* g_dh, float* g_h, float* grad_params,
-                         float* workspace, cgvp_segment* segs, int32_t* nsegs, void* stream) {
+                         const float* h_out, const float* g_out, const float* g_up0, const float* g_up1,
+                         const float* g_up2, int64_t N, int32_t with_head, float* g_dh, float* g_h,
+                         float* grad_params, float* workspace, cgvp_segment* segs, int32_t* nsegs, void* stream) {
   if (int rc = check_dims(dims)) return rc;
   if (N < 0 || !layout || !image || !grad_params || !workspace) return CGVP_ERR_BAD_ARG;
   const int nc = num_convs_of(*layout);
   if (layer < 0 || layer >= nc) return CGVP_ERR_BAD_ARG;
   if (N == 0) return 0;
-  if (!h || !dh || !g_dh || (with_head && !g_out)) return CGVP_ERR_BAD_ARG;
-  const void* al[] = {h, dh, mask0, mask1, g_out, g_up0, g_up1, g_up2, g_dh, g_h};
+  if (!h || !dh || !g_dh || (with_head && (!g_out || !h_out))) return CGVP_ERR_BAD_ARG;
+  const void* al[] = {h, dh, mask0, mask1, h_out, g_out, g_up0, g_up1, g_up2, g_dh, g_h};
   for (const void* q : al) if ((uintptr_t)q & 15) return CGVP_ERR_BAD_ARG;
   QuadOffsets o;
   if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, nc, &o)) return rc;
-  int emb, ce, ct, nd, hd, grid = 0;
+  int emb, ce, ct, nd, hd, grid = 0, hgrid = 0;
   if (int rc = quad::bwd_block_sizes(layout->nt_node, layout->nt_edge, &emb, &ce, &ct, &nd, &hd)) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (int rc = quad::node_update_bwd(image + o.node0 + layer * o.layer_stride, image + o.head,
-                                     image + o.nodeT0 + layer * o.layerT_stride, image + o.headT, h, dh, mask0,
-                                     mask1, g_out, g_up0, g_up1, g_up2, N, with_head ? 1 : 0, g_dh, g_h,
-                                     workspace, &grid, st)) return rc;
-  const int stride = with_head ? hd : nd;
+  float* head_slab = workspace + (size_t)kBwdMaxGrid * nd;
+  if (with_head) {
+    // the head's d h_out lands in g_dh and is consumed in place as the node stage's upstream
+    if (int rc = quad::head_bwd(image + o.head, image + o.headT, h_out, g_out, N, g_dh, head_slab, &hgrid, st)) return rc;
+    g_up0 = g_dh; g_up1 = nullptr; g_up2 = nullptr;
+  }
+  if (int rc = quad::node_update_bwd(image + o.node0 + layer * o.layer_stride, image + o.nodeT0 + layer * o.layerT_stride,
+                                     h, dh, mask0, mask1, g_up0, g_up1, g_up2, N, g_dh, g_h, workspace, &grid, st)) return rc;
   const int node_len = conv_ff1() + LFf1::size(0) - conv_ln0();          // norm.0 .. end of ff_func.1
-  cgvp_segment sg[2] = {{workspace, grid, stride, 0, node_len, layout->conv0 + layer * layout->conv_stride + conv_ln0()},
-                        {workspace, grid, stride, node_len, layout->total - layout->ln_out, layout->ln_out}};
+  cgvp_segment sg[2] = {{workspace, grid, nd, 0, node_len, layout->conv0 + layer * layout->conv_stride + conv_ln0()},
+                        {head_slab, hgrid, hd, 0, layout->total - layout->ln_out, layout->ln_out}};
   const int n = with_head ? 2 : 1;
   if (segs && nsegs) { for (int k = 0; k < n; ++k) segs[k] = sg[k]; *nsegs = n; }
   else quad::reduce_segments(sg, n, grad_params, st);

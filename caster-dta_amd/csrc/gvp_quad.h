@@ -213,26 +213,20 @@ __device__ __forceinline__ void outer_items(const f4 (&A)[MT], const f4 (&B)[NT_
       for (int nt = 0; nt < NT_; ++nt) acc[mt][nt] = mfma(A[mt][rr], B[nt][rr], acc[mt][nt]);
 }
 
-// Weight-gradient partials are accumulated WITHOUT atomics, in a block that exactly
-// one wave owns.  Two places to keep that block:
-//   AccRow : a row of the slab in global memory -> plain store on the wave's first
-//            tile, read-add-store afterwards.  Node / embed backward (one tile per
-//            wave at Davis sizes, so almost always the plain-store case).
-//   AccPriv: a wave-private block in LDS, zeroed at kernel start, read-add-write per
-//            tile; the workgroup sums its waves' blocks once at the end and writes ONE
-//            slab row.  Conv backward (several tiles per wave).
-// A workgroup-SHARED LDS block with ds_add_f32 is what this replaces: LDS float
-// atomics retire ~1 lane per 3 cycles per CU (tools/ldsatomic_probe.hip: 193 cycles
-// for one 64-lane instruction, linear in active lanes and in waves), which made the
-// flush 63 % of the conv backward; a private ds_read/add/ds_write costs ~10 cycles.
-struct AccRow {
-  static constexpr bool BATCHED = false;
-  static __device__ __forceinline__ float load(const float* p, bool first) { return first ? 0.f : *p; }
-  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
-  static __device__ __forceinline__ void add(float* p, float v, bool first) { *p = first ? v : *p + v; }
-};
+// Weight-gradient partials are accumulated WITHOUT atomics, in a block that exactly one
+// wave owns: AccPriv = a wave-private block in LDS, zeroed at kernel start, read-add-write
+// per tile; the workgroup sums its waves' blocks once at the end and writes ONE slab row.
+// What this replaces, both measured on MI355X:
+//   * a workgroup-SHARED LDS block with ds_add_f32: LDS float atomics retire ~1 lane per
+//     3 cycles per CU (tools/ldsatomic_probe.hip: 193 cycles for one 64-lane instruction,
+//     linear in active lanes and in waves) -- 63 % of the conv backward;
+//   * a wave-private slab row in GLOBAL memory (plain stores): 11-30 us of store drain per
+//     node-backward launch and a 4x larger reduction.
+// A private ds_read / add / ds_write costs ~10 cycles per wave-instruction.
 struct AccPriv {
   static constexpr bool BATCHED = true;
+  // the first blockDim.x floats of the kernel's dynamic LDS: one trash word per thread
+  static __device__ __forceinline__ float* trash() { extern __shared__ float cgvp_dyn_lds[]; return cgvp_dyn_lds + threadIdx.x; }
   static __device__ __forceinline__ float load(const float* p, bool) { return *p; }
   static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
   static __device__ __forceinline__ void add(float* p, float v, bool) { *p += v; }
@@ -249,23 +243,27 @@ __device__ __forceinline__ void flush_slots(float* dst, bool first, int LD, cons
   for (int nt = 0; nt < NT_; ++nt) {
     const int cs = 4 * nt + (n >> 2);
     const int col = cs < ColSegs::steps ? ColSegs::col(cs, n & 3) : -1;
-    if constexpr (Acc::BATCHED) {                   // one column tile at a time: MT x 4 reads in flight, then the writes
-      int idx[MT][4];
-      float old[MT][4];
+    if constexpr (Acc::BATCHED) {
+      // One accumulator register quad at a time: 4 reads, 4 adds, 4 writes, all unconditional --
+      // padding lanes are pointed at the thread's trash word.  (A load under a lane mask is
+      // waited for at the join, one LDS round trip per element; letting the scheduler hoist all
+      // reads of a call instead spills.)
+      const int trash = (int)(Acc::trash() - dst);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt) {
+        int idx[4];
+        float old[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = 4 * gq_ + r, rs = 4 * mt + (m >> 2);
           const int row = rs < RowSegs::steps ? RowSegs::col(rs, m & 3) : -1;
-          idx[mt][r] = (row >= 0 && col >= 0) ? row * LD + col : -1;
-          old[mt][r] = idx[mt][r] >= 0 ? Acc::load(dst + idx[mt][r], first) : 0.f;
+          idx[r] = (row >= 0 && col >= 0) ? row * LD + col : trash;
+          old[r] = Acc::load(dst + idx[r], first);
         }
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (idx[mt][r] >= 0) Acc::store(dst + idx[mt][r], old[mt][r] + acc[mt][nt][r]);
+        for (int r = 0; r < 4; ++r) Acc::store(dst + idx[r], old[r] + acc[mt][nt][r]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     } else {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)

@@ -32,8 +32,6 @@ extern "C" int cgvp_debug_set_stamp_buffer_bwd(unsigned long long* buf) {
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int WPB = 4;
-constexpr int TPB = WAVE * WPB;
 constexpr int TILE = 16;
 
 #ifdef CGVP_STAMPS     // diagnostic build only, see gvp_quad_kernels.hip
@@ -49,9 +47,32 @@ constexpr int TILE = 16;
 #else
 #define STAMP(slot) do {} while (0)
 #endif
-constexpr int MAX_GRID = kBwdMaxGrid;  // persistent workgroups; every WAVE owns one slab row
+// Every backward kernel runs ONE workgroup of 8 waves per CU (2 per SIMD) that owns the CU's
+// LDS: [trash word per thread | image slices | one private weight-gradient block per wave (AccPriv)].  Waves take
+// tiles round-robin across workgroups, so a small batch still spreads over all CUs; at the
+// end the workgroup sums its waves' blocks and writes ONE slab row.
+constexpr int BW_WPB = 8, BW_TPB = WAVE * BW_WPB, BW_MAX_GRID = kBwdMaxGrid;
+static_assert(BW_MAX_GRID == 256, "one workgroup per CU");
 
-template <int NFLOATS, int NTHR = TPB>
+template <int BLK>
+__device__ __forceinline__ void zero_block(float* gblk, int lane) {
+  static_assert(BLK % 4 == 0, "blocks are whole float4s");
+  for (int k = lane; k < BLK / 4; k += WAVE) reinterpret_cast<f4*>(gblk)[k] = f4{0.f, 0.f, 0.f, 0.f};
+}
+// slab row of this workgroup = sum of its waves' private blocks (stride PW floats apart)
+template <int BLK, int PW>
+__device__ __forceinline__ void write_slab_row(float* slab, const float* blocks) {
+  __syncthreads();
+  float* out = slab + (size_t)blockIdx.x * BLK;
+  for (int k = threadIdx.x; k < BLK; k += BW_TPB) {
+    float t = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < BW_WPB; ++ww) t += blocks[ww * PW + k];
+    out[k] = t;
+  }
+}
+
+template <int NFLOATS, int NTHR>
 __device__ __forceinline__ void stage_slice(float* lds, const float* __restrict__ src, int tid) {
   static_assert(NFLOATS % 4 == 0, "image slices are whole float4s");
   constexpr int NF4 = NFLOATS / 4, IT = (NF4 + NTHR - 1) / NTHR;
@@ -91,33 +112,31 @@ __device__ __forceinline__ void ln_param_grads(float* blk, bool first, int lane,
 constexpr int NB_LN0 = 0, NB_LN1 = 2 * NS, NB_FF0 = 4 * NS, NB_FF1 = NB_FF0 + LFf0::size(0),
               NODE_BLK = NB_FF1 + LFf1::size(0);
 constexpr int HB_LN = 0, HB_GVP = 2 * NS, HEAD_BLK = HB_GVP + LHead::size(0);
-constexpr int NODE_SCR = cmax(cmax(QFf0::WG_SCRATCH, QFf1::WG_SCRATCH), QHead::WG_SCRATCH);
+constexpr int NODE_GB = pad4(NODE_BLK), HEAD_GB = pad4(HEAD_BLK);
 
 constexpr int MROW = NS + NV;          // dropout mask row: 16 scalar + 4 vector-channel factors
 struct NodeBArgs {
-  const float* img_node; const float* img_head; const float* imgT_node; const float* imgT_head;
+  const float* img_node; const float* imgT_node;
   const float* h; const float* dh; const float* mask0; const float* mask1;
-  const float* g_out; const float* g_up0; const float* g_up1; const float* g_up2;
+  const float* g_up0; const float* g_up1; const float* g_up2;
   int64_t N; float* g_dh; float* g_h; float* slab;
 };
+constexpr int node_bwd_lds_floats() { return BW_TPB + Image<0, 0>::ND_SIZE + Image<0, 0>::TN_SIZE + BW_WPB * NODE_GB; }
+static_assert(node_bwd_lds_floats() * 4 <= 160 * 1024, "node backward LDS plan exceeds the CU");
 
-template <bool HEAD>
-__global__ __launch_bounds__(TPB, 2) void node_bwd_kernel(NodeBArgs a) {
+// g_up0 may alias g_dh (the head backward leaves d h_out there): a tile's rows are read
+// by the same lanes that overwrite them at the end of the tile.
+__global__ __launch_bounds__(BW_TPB, 2) void node_bwd_kernel(NodeBArgs a) {
   typedef Image<0, 0> IM;
-  constexpr int GB = pad4(NODE_BLK + (HEAD ? HEAD_BLK : 0));       // slab row; LDS block has 4 extra floats (trash word)
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* f_node = lds;
-  float* f_head = f_node + IM::ND_SIZE;
-  float* t_node = f_head + (HEAD ? IM::HD_SIZE : 0);
-  float* t_head = t_node + IM::TN_SIZE;
+  float* f_node = lds + BW_TPB;                                     // lds[0..BW_TPB): AccPriv::trash()
+  float* t_node = f_node + IM::ND_SIZE;
+  float* blocks = t_node + IM::TN_SIZE;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float* gblk = a.slab + ((size_t)blockIdx.x * WPB + w) * GB;       // this wave's private slab row
-  stage_slice<IM::ND_SIZE>(f_node, a.img_node, threadIdx.x);
-  stage_slice<IM::TN_SIZE>(t_node, a.imgT_node, threadIdx.x);
-  if (HEAD) {
-    stage_slice<IM::HD_SIZE>(f_head, a.img_head, threadIdx.x);
-    stage_slice<IM::TH_SIZE>(t_head, a.imgT_head, threadIdx.x);
-  }
+  float* gblk = blocks + w * NODE_GB;                               // this wave's private gradient block
+  stage_slice<IM::ND_SIZE, BW_TPB>(f_node, a.img_node, threadIdx.x);
+  stage_slice<IM::TN_SIZE, BW_TPB>(t_node, a.imgT_node, threadIdx.x);
+  zero_block<NODE_GB>(gblk, lane);
   STAMP(0);
   __syncthreads();
   STAMP(1);
@@ -125,12 +144,9 @@ __global__ __launch_bounds__(TPB, 2) void node_bwd_kernel(NodeBArgs a) {
   const int i = lane & 15, g = lane >> 4;
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
   const int zt[1] = {0};
+  const bool first = false;
   const int64_t ntiles = (a.N + TILE - 1) / TILE;
-  const int64_t tile0 = (int64_t)blockIdx.x * WPB + w;
-  if (tile0 >= ntiles)                                 // idle wave: its row still takes part in the reduction
-    for (int k = lane; k < GB; k += WAVE) gblk[k] = 0.f;
-  for (int64_t tile = tile0; tile < ntiles; tile += (int64_t)gridDim.x * WPB) {
-    const bool first = tile == tile0;
+  for (int64_t tile = (int64_t)w * gridDim.x + blockIdx.x; tile < ntiles; tile += (int64_t)gridDim.x * BW_WPB) {
     const int64_t n = tile * TILE + i;
     const bool active = n < a.N;
     // ---- recompute the forward of this tile
@@ -138,6 +154,8 @@ __global__ __launch_bounds__(TPB, 2) void node_bwd_kernel(NodeBArgs a) {
     float xv0[3][1] = {{0.f}, {0.f}, {0.f}};
     f4 m0s = {1.f, 1.f, 1.f, 1.f}, m1s = {1.f, 1.f, 1.f, 1.f};
     float m0v = 1.f, m1v = 1.f;
+    f4 gs[1] = {zero};
+    float gv[3][1] = {{0.f}, {0.f}, {0.f}};
     if (active) {
       const float* hr = a.h + n * ROW;
       const float* dr = a.dh + n * ROW;
@@ -146,6 +164,16 @@ __global__ __launch_bounds__(TPB, 2) void node_bwd_kernel(NodeBArgs a) {
       x0[0] = *reinterpret_cast<const f4*>(hr + 4 * g) + *reinterpret_cast<const f4*>(dr + 4 * g) * m0s;
 #pragma unroll
       for (int p = 0; p < 3; ++p) xv0[p][0] = hr[NS + 3 * g + p] + dr[NS + 3 * g + p] * m0v;
+      // upstream gradient of this stage's output (sum of up to three buffers)
+      const float* ups[3] = {a.g_up0, a.g_up1, a.g_up2};
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (ups[u]) {
+          const float* r_ = ups[u] + n * ROW;
+          gs[0] += *reinterpret_cast<const f4*>(r_ + 4 * g);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) gv[p][0] += r_[NS + 3 * g + p];
+        }
     }
     f4 y[1] = {x0[0]};
     float yv[3][1] = {{xv0[0][0]}, {xv0[1][0]}, {xv0[2][0]}};
@@ -173,60 +201,12 @@ __global__ __launch_bounds__(TPB, 2) void node_bwd_kernel(NodeBArgs a) {
     for (int p = 0; p < 3; ++p) zv[p][0] = yv[p][0] + v2[0][p][0] * m1v;
 
     STAMP(2);
-    // ---- upstream gradient of this stage's output
-    f4 gs[1] = {zero};
-    float gv[3][1] = {{0.f}, {0.f}, {0.f}};
-    if (HEAD) {
-      f4 o1[1] = {z[0]};
-      float ov1[3][1] = {{zv[0][0]}, {zv[1][0]}, {zv[2][0]}};
-      ln_quad<NS, NV>(f_node + IM::ND_LN1, lane, o1, ov1);        // output of norm.1 (input of the head)
-      f4 wsn[1] = {o1[0]};
-      float wvn[3][1] = {{ov1[0][0]}, {ov1[1][0]}, {ov1[2][0]}};
-      ln_quad<NS, NV>(f_head + IM::HD_LN, lane, wsn, wvn);
-      float bsh[1][4], bvh[1][3][1], dummy[1][3][1];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bsh[0][r] = wsn[0][r];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) bvh[0][p][0] = wvn[p][0];
-      f4 o[1][4];
-      QHead::Cache ch[1];
-      QHead::forward<1>(f_head + IM::HD_GVP, lane, zt, bsh, bvh, o, dummy, ch);
-      f4 d_o[4] = {zero, zero, zero, zero};
-      if (active) {
-        const float* gr_ = a.g_out + n * OUT;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) d_o[t] = *reinterpret_cast<const f4*>(gr_ + 16 * t + 4 * g);
-      }
-      float d_vo[3][1] = {{0.f}, {0.f}, {0.f}}, d_bs[4], d_bv[3][1];
-      QHead::Grads grh;
-      QHead::backward(t_head, lane, ch[0], d_o, d_vo, d_bs, d_bv, grh);
-      QHead::weight_grads<AccRow>(gblk + NODE_BLK + HB_GVP, first, lane, 0, active, bsh[0], bvh[0], ch[0], grh);
-      f4 dws[1] = {f4{d_bs[0], d_bs[1], d_bs[2], d_bs[3]}};
-      float dwv[3][1] = {{d_bv[0][0]}, {d_bv[1][0]}, {d_bv[2][0]}};
-      f4 dga[1], dbe[1];
-      ln_quad_bwd<NS, NV>(f_head + IM::HD_LN, lane, o1, ov1, dws, dwv, dga, dbe);
-      ln_param_grads<AccRow, NS>(gblk + NODE_BLK + HB_LN, first, lane, active, dga, dbe);
-      gs[0] = dws[0];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) gv[p][0] = dwv[p][0];
-    } else if (active) {
-      const float* ups[3] = {a.g_up0, a.g_up1, a.g_up2};
-#pragma unroll
-      for (int u = 0; u < 3; ++u)
-        if (ups[u]) {
-          const float* r_ = ups[u] + n * ROW;
-          gs[0] += *reinterpret_cast<const f4*>(r_ + 4 * g);
-#pragma unroll
-          for (int p = 0; p < 3; ++p) gv[p][0] += r_[NS + 3 * g + p];
-        }
-    }
-
     STAMP(3);
     // ---- norm.1, feed-forward, residual, norm.0
     {
       f4 dga[1], dbe[1];
       ln_quad_bwd<NS, NV>(f_node + IM::ND_LN1, lane, z, zv, gs, gv, dga, dbe);      // gs/gv := d z
-      ln_param_grads<AccRow, NS>(gblk + NB_LN1, first, lane, active, dga, dbe);
+      ln_param_grads<AccPriv, NS>(gblk + NB_LN1, first, lane, active, dga, dbe);
     }
     float d_hs[16], d_hv[3][2];
     {
@@ -236,7 +216,7 @@ __global__ __launch_bounds__(TPB, 2) void node_bwd_kernel(NodeBArgs a) {
       STAMP(4);
       QFf1::backward(t_node + IM::TN_FF1, lane, c1[0], d_so, d_vo, d_hs, d_hv, gr1);
       STAMP(5);
-      QFf1::weight_grads<AccRow>(gblk + NB_FF1, first, lane, 0, active, bs1[0], bv1[0], c1[0], gr1);
+      QFf1::weight_grads<AccPriv>(gblk + NB_FF1, first, lane, 0, active, bs1[0], bv1[0], c1[0], gr1);
     }
     {
       f4 d_so[4];
@@ -247,7 +227,7 @@ __global__ __launch_bounds__(TPB, 2) void node_bwd_kernel(NodeBArgs a) {
       STAMP(6);
       QFf0::backward(t_node + IM::TN_FF0, lane, c0[0], d_so, d_hv, d_ys, d_yv, gr0);
       STAMP(7);
-      QFf0::weight_grads<AccRow>(gblk + NB_FF0, first, lane, 0, active, bs0[0], bv0[0], c0[0], gr0);
+      QFf0::weight_grads<AccPriv>(gblk + NB_FF0, first, lane, 0, active, bs0[0], bv0[0], c0[0], gr0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) gs[0][r] += d_ys[r];
 #pragma unroll
@@ -257,7 +237,7 @@ __global__ __launch_bounds__(TPB, 2) void node_bwd_kernel(NodeBArgs a) {
     {
       f4 dga[1], dbe[1];
       ln_quad_bwd<NS, NV>(f_node + IM::ND_LN0, lane, x0, xv0, gs, gv, dga, dbe);    // gs/gv := d (h + dh)
-      ln_param_grads<AccRow, NS>(gblk + NB_LN0, first, lane, active, dga, dbe);
+      ln_param_grads<AccPriv, NS>(gblk + NB_LN0, first, lane, active, dga, dbe);
     }
     if (active) {               // d h (residual path) and d dh = mask0 * d h (equal without dropout)
       if (a.g_h) {
@@ -272,7 +252,81 @@ __global__ __launch_bounds__(TPB, 2) void node_bwd_kernel(NodeBArgs a) {
       for (int p = 0; p < 3; ++p) row[NS + 3 * g + p] = gv[p][0] * m0v;
     }
   }
+  STAMP(9);
+  write_slab_row<NODE_GB, NODE_GB>(a.slab, blocks);
   STAMP(10);
+}
+
+// ===================================================================== output head
+// gvp_norm_before_scalar + gvp_to_scalar (protein_gnn.py:385-386) on h_out, the saved output of
+// the last conv layer: d h_out and the head's weight gradients from g_out [N][64].
+struct HeadBArgs {
+  const float* img_head; const float* imgT_head; const float* h_out; const float* g_out;
+  int64_t N; float* g_h_out; float* slab;
+};
+constexpr int head_bwd_lds_floats() { return BW_TPB + Image<0, 0>::HD_SIZE + Image<0, 0>::TH_SIZE + BW_WPB * HEAD_GB; }
+
+__global__ __launch_bounds__(BW_TPB, 2) void head_bwd_kernel(HeadBArgs a) {
+  typedef Image<0, 0> IM;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* f_head = lds + BW_TPB;
+  float* t_head = f_head + IM::HD_SIZE;
+  float* blocks = t_head + IM::TH_SIZE;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* gblk = blocks + w * HEAD_GB;
+  stage_slice<IM::HD_SIZE, BW_TPB>(f_head, a.img_head, threadIdx.x);
+  stage_slice<IM::TH_SIZE, BW_TPB>(t_head, a.imgT_head, threadIdx.x);
+  zero_block<HEAD_GB>(gblk, lane);
+  __syncthreads();
+
+  const int i = lane & 15, g = lane >> 4;
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  const int zt[1] = {0};
+  const bool first = false;
+  const int64_t ntiles = (a.N + TILE - 1) / TILE;
+  for (int64_t tile = (int64_t)w * gridDim.x + blockIdx.x; tile < ntiles; tile += (int64_t)gridDim.x * BW_WPB) {
+    const int64_t n = tile * TILE + i;
+    const bool active = n < a.N;
+    f4 o1[1] = {zero};
+    float ov1[3][1] = {{0.f}, {0.f}, {0.f}};
+    f4 d_o[4] = {zero, zero, zero, zero};
+    if (active) {
+      const float* hr = a.h_out + n * ROW;
+      o1[0] = *reinterpret_cast<const f4*>(hr + 4 * g);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) ov1[p][0] = hr[NS + 3 * g + p];
+      const float* gr_ = a.g_out + n * OUT;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) d_o[t] = *reinterpret_cast<const f4*>(gr_ + 16 * t + 4 * g);
+    }
+    f4 wsn[1] = {o1[0]};
+    float wvn[3][1] = {{ov1[0][0]}, {ov1[1][0]}, {ov1[2][0]}};
+    ln_quad<NS, NV>(f_head + IM::HD_LN, lane, wsn, wvn);
+    float bsh[1][4], bvh[1][3][1], dummy[1][3][1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bsh[0][r] = wsn[0][r];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) bvh[0][p][0] = wvn[p][0];
+    f4 o[1][4];
+    QHead::Cache ch[1];
+    QHead::forward<1>(f_head + IM::HD_GVP, lane, zt, bsh, bvh, o, dummy, ch);
+    float d_vo[3][1] = {{0.f}, {0.f}, {0.f}}, d_bs[4], d_bv[3][1];
+    QHead::Grads grh;
+    QHead::backward(t_head, lane, ch[0], d_o, d_vo, d_bs, d_bv, grh);
+    QHead::weight_grads<AccPriv>(gblk + HB_GVP, first, lane, 0, active, bsh[0], bvh[0], ch[0], grh);
+    f4 dws[1] = {f4{d_bs[0], d_bs[1], d_bs[2], d_bs[3]}};
+    float dwv[3][1] = {{d_bv[0][0]}, {d_bv[1][0]}, {d_bv[2][0]}};
+    f4 dga[1], dbe[1];
+    ln_quad_bwd<NS, NV>(f_head + IM::HD_LN, lane, o1, ov1, dws, dwv, dga, dbe);
+    ln_param_grads<AccPriv, NS>(gblk + HB_LN, first, lane, active, dga, dbe);
+    if (active) {
+      float* row = a.g_h_out + n * ROW;
+      *reinterpret_cast<f4*>(row + 4 * g) = dws[0];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) row[NS + 3 * g + p] = dwv[p][0];
+    }
+  }
+  write_slab_row<HEAD_GB, HEAD_GB>(a.slab, blocks);
 }
 
 // ===================================================================== conv
@@ -284,10 +338,10 @@ struct ConvBlk {
 };
 // One workgroup of 8 waves per CU (2 per SIMD) owning all 160 KB of LDS:
 //   [forward slices | transposed slices | per wave: private gradient block, g_src scratch]
-constexpr int CB_WPB = 8, CB_TPB = WAVE * CB_WPB, CB_MAX_GRID = 256;
+constexpr int CB_WPB = BW_WPB, CB_TPB = BW_TPB, CB_MAX_GRID = BW_MAX_GRID;
 constexpr int CB_SCR = (TILE / 2) * ROW + TILE;      // half a tile of [28]-rows + 16 source ids (g_src transpose)
 template <int NTE>
-constexpr int conv_bwd_lds_floats() { return Image<0, NTE>::CV_SIZE + Image<0, NTE>::TC_SIZE + CB_WPB * (ConvBlk<NTE>::SIZE + CB_SCR); }
+constexpr int conv_bwd_lds_floats() { return BW_TPB + Image<0, NTE>::CV_SIZE + Image<0, NTE>::TC_SIZE + CB_WPB * (ConvBlk<NTE>::SIZE + CB_SCR); }
 static_assert(conv_bwd_lds_floats<1>() * 4 <= 160 * 1024 && conv_bwd_lds_floats<0>() * 4 <= 160 * 1024, "conv backward LDS plan exceeds the CU");
 
 struct ConvBArgs {
@@ -303,7 +357,7 @@ __global__ __launch_bounds__(CB_TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
   typedef ConvBlk<NTE> B;
   constexpr int PW = B::SIZE + CB_SCR;                                // per-wave LDS floats
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* img = lds;
+  float* img = lds + BW_TPB;
   float* imgT = img + IM::CV_SIZE;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float* blocks = imgT + IM::TC_SIZE;
@@ -511,15 +565,7 @@ __global__ __launch_bounds__(CB_TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
     STAMP(7);
   }
   STAMP(8);
-  // one slab row per workgroup: sum of its waves' private blocks
-  __syncthreads();
-  float* out = a.slab + (size_t)blockIdx.x * B::SIZE;
-  for (int k = threadIdx.x; k < B::SIZE; k += CB_TPB) {
-    float t = 0.f;
-#pragma unroll
-    for (int ww = 0; ww < CB_WPB; ++ww) t += blocks[ww * PW + k];
-    out[k] = t;
-  }
+  write_slab_row<B::SIZE, PW>(a.slab, blocks);
   STAMP(9);
 }
 
@@ -535,26 +581,28 @@ struct EmbBArgs {
 };
 
 template <int NTN>
-__global__ __launch_bounds__(TPB) void embed_bwd_kernel(EmbBArgs a) {
+constexpr int embed_bwd_lds_floats() { return BW_TPB + Image<NTN, 0>::EMB_SIZE + Image<NTN, 0>::TE_SIZE + BW_WPB * EmbBlk<NTN>::SIZE; }
+
+template <int NTN>
+__global__ __launch_bounds__(BW_TPB, 2) void embed_bwd_kernel(EmbBArgs a) {
   typedef Image<NTN, 0> IM;
   typedef QNode<NTN> Q;
   typedef EmbBlk<NTN> B;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* img = lds;
+  float* img = lds + BW_TPB;
   float* imgT = img + IM::EMB_SIZE;
+  float* blocks = imgT + IM::TE_SIZE;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float* gblk = a.slab + ((size_t)blockIdx.x * WPB + w) * B::SIZE;  // this wave's private slab row
-  stage_slice<IM::EMB_SIZE>(img, a.img, threadIdx.x);
-  stage_slice<IM::TE_SIZE>(imgT, a.imgT, threadIdx.x);
+  float* gblk = blocks + w * B::SIZE;                               // this wave's private gradient block
+  stage_slice<IM::EMB_SIZE, BW_TPB>(img, a.img, threadIdx.x);
+  stage_slice<IM::TE_SIZE, BW_TPB>(imgT, a.imgT, threadIdx.x);
+  zero_block<B::SIZE>(gblk, lane);
   __syncthreads();
   const int i = lane & 15, g = lane >> 4;
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
   const int64_t ntiles = (a.N + TILE - 1) / TILE;
-  const int64_t tile0 = (int64_t)blockIdx.x * WPB + w;
-  if (tile0 >= ntiles)
-    for (int k = lane; k < B::SIZE; k += WAVE) gblk[k] = 0.f;
-  for (int64_t tile = tile0; tile < ntiles; tile += (int64_t)gridDim.x * WPB) {
-    const bool first = tile == tile0;
+  const bool first = false;
+  for (int64_t tile = (int64_t)w * gridDim.x + blockIdx.x; tile < ntiles; tile += (int64_t)gridDim.x * BW_WPB) {
     const int64_t n = tile * TILE + i;
     const bool active = n < a.N;
     float bs[1][Q::SSTEPS], bv[1][3][1];
@@ -589,11 +637,11 @@ __global__ __launch_bounds__(TPB) void embed_bwd_kernel(EmbBArgs a) {
     }
     f4 dga[1], dbe[1];
     ln_quad_bwd<NS, NV>(img + IM::EMB_LN, lane, s_pre[0], v_pre[0], gs, gv, dga, dbe);
-    ln_param_grads<AccRow, NS>(gblk + B::LN, first, lane, active, dga, dbe);
+    ln_param_grads<AccPriv, NS>(gblk + B::LN, first, lane, active, dga, dbe);
     float d_bs[Q::SSTEPS], d_bv[3][1];
     typename Q::Grads gr;
     Q::backward(imgT, lane, c[0], gs, gv, d_bs, d_bv, gr);
-    Q::template weight_grads<AccRow>(gblk + B::GVP, first, lane, type[0], active, bs[0], bv[0], c[0], gr);
+    Q::template weight_grads<AccPriv>(gblk + B::GVP, first, lane, type[0], active, bs[0], bv[0], c[0], gr);
     if (active && a.g_x_s) {
 #pragma unroll
       for (int s = 0; s < Q::SSTEPS; ++s) {
@@ -606,6 +654,7 @@ __global__ __launch_bounds__(TPB) void embed_bwd_kernel(EmbBArgs a) {
       }
     }
   }
+  write_slab_row<B::SIZE, B::SIZE>(a.slab, blocks);
 }
 
 // dst[j] += sum_r slab[r][col0 + j], j < len.  A block owns 64 columns; its 16
@@ -652,9 +701,8 @@ __global__ __launch_bounds__(RED_COLS * RED_RG) void reduce_segments_kernel(SegT
   }
 }
 
-inline int grid_for(int64_t units) {          // workgroups; slab rows = WPB x this
-  int64_t wgs = (units + WPB - 1) / WPB;
-  return (int)(wgs < 1 ? 1 : (wgs > MAX_GRID ? MAX_GRID : wgs));
+inline int grid_for(int64_t tiles) {          // workgroups = slab rows; tiles go round-robin over them
+  return (int)(tiles < 1 ? 1 : (tiles > BW_MAX_GRID ? BW_MAX_GRID : tiles));
 }
 
 }  // namespace
@@ -667,8 +715,8 @@ int bwd_block_sizes(int nt_node, int nt_edge, int* emb, int* conv_edge, int* con
   if (nt_edge == 0) { *conv_edge = ConvBlk<0>::E_SIZE; *conv_total = ConvBlk<0>::SIZE; }
   else if (nt_edge == 1) { *conv_edge = ConvBlk<1>::E_SIZE; *conv_total = ConvBlk<1>::SIZE; }
   else return CGVP_ERR_UNSUPPORTED_DIMS;
-  *node = pad4(NODE_BLK);
-  *head = pad4(NODE_BLK + HEAD_BLK);
+  *node = NODE_GB;
+  *head = HEAD_GB;
   return 0;
 }
 
@@ -687,23 +735,26 @@ int reduce_slab(const float* slab, int rows, int stride, int col0, int len, floa
   return 0;
 }
 
-int node_update_bwd(const float* img_node, const float* img_head, const float* imgT_node, const float* imgT_head,
-                    const float* h, const float* dh, const float* mask0, const float* mask1, const float* g_out,
-                    const float* g_up0, const float* g_up1, const float* g_up2, int64_t N, int with_head,
-                    float* g_dh, float* g_h, float* slab, int* grid, hipStream_t st) {
-  typedef Image<0, 0> IM;
-  NodeBArgs a{img_node, img_head, imgT_node, imgT_head, h, dh, mask0, mask1, g_out, g_up0, g_up1, g_up2, N, g_dh, g_h, slab};
+int node_update_bwd(const float* img_node, const float* imgT_node, const float* h, const float* dh,
+                    const float* mask0, const float* mask1, const float* g_up0, const float* g_up1,
+                    const float* g_up2, int64_t N, float* g_dh, float* g_h, float* slab, int* grid, hipStream_t st) {
+  NodeBArgs a{img_node, imgT_node, h, dh, mask0, mask1, g_up0, g_up1, g_up2, N, g_dh, g_h, slab};
   const int G = grid_for((N + TILE - 1) / TILE);
-  *grid = G * WPB;
-  if (with_head) {
-    const size_t lds = (size_t)(IM::ND_SIZE + IM::HD_SIZE + IM::TN_SIZE + IM::TH_SIZE + 0) * sizeof(float);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(node_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(node_bwd_kernel<true>, dim3(G), dim3(TPB), lds, st, a);
-  } else {
-    const size_t lds = (size_t)(IM::ND_SIZE + IM::TN_SIZE) * sizeof(float);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(node_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(node_bwd_kernel<false>, dim3(G), dim3(TPB), lds, st, a);
-  }
+  *grid = G;
+  const size_t lds = (size_t)node_bwd_lds_floats() * sizeof(float);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(node_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(node_bwd_kernel, dim3(G), dim3(BW_TPB), lds, st, a);
+  return 0;
+}
+
+int head_bwd(const float* img_head, const float* imgT_head, const float* h_out, const float* g_out, int64_t N,
+             float* g_h_out, float* slab, int* grid, hipStream_t st) {
+  HeadBArgs a{img_head, imgT_head, h_out, g_out, N, g_h_out, slab};
+  const int G = grid_for((N + TILE - 1) / TILE);
+  *grid = G;
+  const size_t lds = (size_t)head_bwd_lds_floats() * sizeof(float);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(head_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(G), dim3(BW_TPB), lds, st, a);
   return 0;
 }
 
@@ -736,12 +787,11 @@ int conv_bwd(int nt_edge, const float* img, const float* imgT, const float* h, c
 
 template <int NTN>
 int embed_bwd_impl(EmbBArgs& a, int* grid, hipStream_t st) {
-  typedef Image<NTN, 0> IM;
   const int G = grid_for((a.N + TILE - 1) / TILE);
-  *grid = G * WPB;
-  const size_t lds = (size_t)(IM::EMB_SIZE + IM::TE_SIZE) * sizeof(float);
+  *grid = G;
+  const size_t lds = (size_t)embed_bwd_lds_floats<NTN>() * sizeof(float);
   hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel<NTN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(embed_bwd_kernel<NTN>, dim3(G), dim3(TPB), lds, st, a);
+  hipLaunchKernelGGL(embed_bwd_kernel<NTN>, dim3(G), dim3(BW_TPB), lds, st, a);
   return 0;
 }
 

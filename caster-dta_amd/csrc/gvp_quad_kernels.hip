@@ -436,15 +436,13 @@ __global__ __launch_bounds__(TPB) void node_quad_kernel(NodeQArgs a) {
     for (int p = 0; p < 3; ++p) v[p][0] += v2[0][p][0] * m1v;
   }
   ln_quad<NS, NV>(lds + IM::ND_LN1, lane, s, v);
-  if (!HEAD) {
-    if (active) {
-      float* row = a.h_out + n * ROW;
-      *reinterpret_cast<f4*>(row + 4 * g) = s[0];
+  if (active && (!HEAD || a.h_out)) {       // with the head h_out is optional (training saves it for the backward)
+    float* row = a.h_out + n * ROW;
+    *reinterpret_cast<f4*>(row + 4 * g) = s[0];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) row[NS + 3 * g + p] = v[p][0];
-    }
-    return;
+    for (int p = 0; p < 3; ++p) row[NS + 3 * g + p] = v[p][0];
   }
+  if (!HEAD) return;
   const float* hd = lds + IM::ND_SIZE;
   ln_quad<NS, NV>(hd + IM::HD_LN, lane, s, v);
   float bs[1][4], bv[1][3][1], dummy[1][3][1];

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcaster_gvp.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class HipLibraryError(RuntimeError):
@@ -61,7 +61,7 @@ _SIGNATURES = {
     "cgvp_node_update_fwd_train": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _P, _P, _I64,
                                              _I32, _P, _P, _P]),
     "cgvp_bwd_workspace_floats": (C.c_int64, [C.POINTER(Dims), C.POINTER(Layout)]),
-    "cgvp_node_update_bwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P,
+    "cgvp_node_update_bwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                        _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "cgvp_conv_bwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64,
                                 _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -42,6 +42,7 @@ class _LbaEncoderFn(torch.autograd.Function):
         if m["dropout"] > 0:
             masks = [(_dropout_mask(N, m["dropout"], dev), _dropout_mask(N, m["dropout"], dev)) for _ in range(nc)]
         out = torch.empty(N, dims.out_s, dtype=torch.float32, device=dev)
+        h_last = torch.empty(N, ROW, dtype=torch.float32, device=dev)     # input of the head, saved for its backward
         with torch.cuda.device(dev):
             st = _stream()
             d, lay, P, I = C.byref(dims), C.byref(layout), _ptr(m["params"]), _ptr(image)
@@ -55,10 +56,10 @@ class _LbaEncoderFn(torch.autograd.Function):
                 last = l == nc - 1
                 _lib.check(L.cgvp_node_update_fwd_train(d, lay, I, l, _ptr(hs[l]), _ptr(dhs[l]), _ptr(masks[l][0]),
                                                         _ptr(masks[l][1]), N, 1 if last else 0,
-                                                        _ptr(None if last else hs[l + 1]), _ptr(out), st),
+                                                        _ptr(h_last if last else hs[l + 1]), _ptr(out), st),
                            "cgvp_node_update_fwd_train")
         ctx.meta = m
-        ctx.saved = (x_s, x_v, e_s, e_v, nt, et, hs, dhs, masks)
+        ctx.saved = (x_s, x_v, e_s, e_v, nt, et, hs, dhs, masks, h_last)
         ctx.n_params = len(params)
         return out
 
@@ -67,7 +68,7 @@ class _LbaEncoderFn(torch.autograd.Function):
         L = _lib.lib()
         m = ctx.meta
         dims, layout, image, csr = m["dims"], m["layout"], m["image"], m["csr"]
-        x_s, x_v, e_s, e_v, nt, et, hs, dhs, masks = ctx.saved
+        x_s, x_v, e_s, e_v, nt, et, hs, dhs, masks, h_last = ctx.saved
         N, E = int(x_s.shape[0]), int(e_s.shape[0])
         dev = x_s.device
         nc = m["num_convs"]
@@ -104,7 +105,8 @@ class _LbaEncoderFn(torch.autograd.Function):
                 g_dh = torch.empty(N, ROW, **f32)
                 g_h = torch.empty(N, ROW, **f32) if masks[l][0] is not None else None
                 _lib.check(L.cgvp_node_update_bwd(d, lay, I, l, _ptr(hs[l]), _ptr(dhs[l]), _ptr(masks[l][0]),
-                                                  _ptr(masks[l][1]), _ptr(g_out if last else None), _ptr(ups[0]),
+                                                  _ptr(masks[l][1]), _ptr(h_last if last else None),
+                                                  _ptr(g_out if last else None), _ptr(ups[0]),
                                                   _ptr(ups[1]), _ptr(ups[2]), N, 1 if last else 0, _ptr(g_dh),
                                                   _ptr(g_h), _ptr(gparams), _ptr(region()),
                                                   C.byref(segs, nseg * C.sizeof(_lib.Segment)), C.byref(cnt), st),

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 5
+#define CGVP_ABI_VERSION 6
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
@@ -175,15 +175,19 @@ typedef struct {
 int cgvp_bwd_reduce(const cgvp_segment* segs, int32_t nsegs, float* grad_params, void* stream);
 
 /* d/d(h, dh, weights) of cgvp_node_update_fwd[_train].  Upstream gradient: with
- * the head, g_out [N][64]; otherwise the SUM of up to three [N][28] buffers
- * g_up0..2 (NULL entries skipped).  Writes g_dh [N][28] (= mask0 * d h) and, when
- * g_h != NULL, g_h [N][28] (the residual path; equals g_dh without dropout). */
+ * the head, g_out [N][64] together with h_out [N][28], the h_out the forward call
+ * wrote (the head's input; pass a buffer to the forward even when with_head);
+ * otherwise the SUM of up to three [N][28] buffers g_up0..2 (NULL entries
+ * skipped; h_out / g_out ignored).  Writes g_dh [N][28] (= mask0 * d h) and, when
+ * g_h != NULL, g_h [N][28] (the residual path; equals g_dh without dropout).
+ * With the head this is two launches (head, then the layer). */
 int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image,
                          int32_t layer, const float* h, const float* dh, const float* mask0,
-                         const float* mask1, const float* g_out, const float* g_up0,
-                         const float* g_up1, const float* g_up2, int64_t num_nodes,
-                         int32_t with_head, float* g_dh, float* g_h, float* grad_params,
-                         float* workspace, cgvp_segment* segs, int32_t* nsegs, void* stream);
+                         const float* mask1, const float* h_out, const float* g_out,
+                         const float* g_up0, const float* g_up1, const float* g_up2,
+                         int64_t num_nodes, int32_t with_head, float* g_dh, float* g_h,
+                         float* grad_params, float* workspace, cgvp_segment* segs, int32_t* nsegs,
+                         void* stream);
 
 /* d/d(h, weights) of cgvp_conv_fwd given g_dh = d(loss)/d(dh).  Gradients w.r.t.
  * the node rows arrive in two buffers that the consumer sums: g_src [N][28]

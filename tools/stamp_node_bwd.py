@@ -30,7 +30,7 @@ for head in (0, 1):
     h.cgvp_debug_set_stamp_buffer_bwd(ctypes.c_void_p(buf.data_ptr()))
     for _ in range(3):
         rc = L.cgvp_node_update_bwd(C.byref(dims), C.byref(layout), P(image), 1 if head else 0, P(hh), P(dh), P(None), P(None),
-                                    P(gout if head else None), P(None if head else g), P(None), P(None), N, head, P(gdh), P(None),
+                                    P(hh if head else None), P(gout if head else None), P(None if head else g), P(None), P(None), N, head, P(gdh), P(None),
                                     P(gp), P(ws), P(None), P(None), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0, rc
     torch.cuda.synchronize()
@@ -42,3 +42,17 @@ for head in (0, 1):
     for k,(a_,b_) in enumerate(seq):
         print(f"{names[k+1]:32s} median {np.median(b[:,b_]-b[:,a_]):8.0f} cyc")
     print(f"{'wave total':32s} median {np.median(b[:,10]-b[:,0]):8.0f} cyc")
+    last = b[:, 1:11].max(axis=1)
+    t0 = b[:, 0].min()
+    print(f"{'first-stamp skew':32s} median {np.median(b[:,0]-t0):8.0f}  max {np.max(b[:,0]-t0):8.0f}")
+    print(f"{'span first stamp -> last stamp':32s} {last.max()-t0:8.0f} cyc  (median wave end {np.median(last-t0):8.0f})")
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    segs = (_lib.Segment * 8)(); nsegs = C.c_int32(0)
+    ev0.record()
+    for _ in range(20):
+        nsegs.value = 0
+        L.cgvp_node_update_bwd(C.byref(dims), C.byref(layout), P(image), 1 if head else 0, P(hh), P(dh), P(None), P(None),
+                               P(hh if head else None), P(gout if head else None), P(None if head else g), P(None), P(None), N, head, P(gdh), P(None),
+                               P(gp), P(ws), segs, C.byref(nsegs), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    ev1.record(); torch.cuda.synchronize()
+    print(f"{'kernel alone (deferred reduce), back to back':32s} {ev0.elapsed_time(ev1)/20*1000:8.1f} us")
