@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--cache-csr", action="store_true", help="reuse the CSR tables across steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--drug-stream", default="side", choices=["side", "main"],
+                    help="diagnostic: 'main' runs the drug encoder on the protein stream (no overlap)")
     ap.add_argument("--only", default=None, choices=["protein", "drug"],
                     help="diagnostic: time one encoder alone (the reported metric needs both; never the default)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -103,7 +105,7 @@ def main():
             atoms = model.molecule_gnn(**mdata)
             return torch.autograd.grad([atoms], drug_params, [g_atm]) if train else atoms
         side.wait_stream(main_s)
-        with torch.cuda.stream(side):                 # drug graphs are tiny: run them beside the protein kernels
+        with torch.cuda.stream(side if args.drug_stream == "side" else main_s):   # drug graphs are tiny: run them beside the protein kernels
             atoms = model.molecule_gnn(**mdata)
         residues = model.protein_gnn(**pdata)
         main_s.wait_stream(side)
@@ -116,7 +118,7 @@ def main():
         out = step()
         torch.cuda.synchronize()
         graph = None
-        if not args.no_graph:
+        if not args.no_graph and args.only is None and args.drug_stream == "side":   # the diagnostics run eagerly
             s = torch.cuda.Stream(device=dev)
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
@@ -161,6 +163,8 @@ def main():
             conv_bytes = 224 * N + 156 * E            # algorithmic bytes of one conv launch
             # dominant kernel = the conv kernel with the largest share of the step (backward when training);
             # backward counted as 2x the forward bytes (fwd + bwd = 3x forward)
+            if not by:                                # --only drug: no conv kernel to report
+                by = {"conv_fwd": [float("nan")]}
             name = max(by, key=lambda k: sum(by[k]))
             times = sorted(by[name])
             nbytes = conv_bytes * (2 if name == "conv_bwd" else 1)

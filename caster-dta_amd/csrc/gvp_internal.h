@@ -12,7 +12,10 @@ struct QuadOffsets {
   int embT, convT0, nodeT0, layerT_stride, headT;     // transposed slices (backward)
 };
 
-constexpr int kBwdMaxGrid = 256;    // persistent workgroups of the backward kernels (one per CU) = slab rows per stage
+#ifndef CGVP_BWD_MAX_GRID
+#define CGVP_BWD_MAX_GRID 256       // A/B builds only (-DCGVP_BWD_MAX_GRID=...)
+#endif
+constexpr int kBwdMaxGrid = CGVP_BWD_MAX_GRID;    // persistent workgroups of the backward kernels (one per CU) = slab rows per stage
 
 namespace quad {
 int offsets(int nt_node, int nt_edge, int num_convs, QuadOffsets* o);

@@ -475,20 +475,51 @@ struct GineLay {
   static constexpr int KE = NET + ED;
   static constexpr int EPS = 0, W0 = 1, B0 = W0 + CHID * CIN, W1 = B0 + CHID, B1 = W1 + COUT * CHID,
                        WE = B1 + COUT, BE = WE + CIN * KE, SIZE = BE + CIN;
+  // the same blocks with odd row strides: the layout of a wave's partial in LDS ("lane o writes row o")
+  static constexpr int P_W0 = 1, P_B0 = P_W0 + CHID * (CIN + 1), P_W1 = P_B0 + CHID, P_B1 = P_W1 + COUT * (CHID + 1),
+                       P_WE = P_B1 + COUT, P_BE = P_WE + CIN * (KE + 1), P_SIZE = P_BE + CIN;
+  static __device__ __forceinline__ int padded(int j) {          // state_dict offset -> padded offset
+    if (j < B0) return j < W0 ? j : P_W0 + ((j - W0) / CIN) * (CIN + 1) + (j - W0) % CIN;
+    if (j < W1) return P_B0 + (j - B0);
+    if (j < B1) return P_W1 + ((j - W1) / CHID) * (CHID + 1) + (j - W1) % CHID;
+    if (j < WE) return P_B1 + (j - B1);
+    if (j < BE) return P_WE + ((j - WE) / KE) * (KE + 1) + (j - WE) % KE;
+    return P_BE + (j - BE);
+  }
 };
+
+__device__ __forceinline__ float lane_bcast(float v, int k) {          // value of lane k (k uniform) as a scalar operand
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+}
 
 template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
 __global__ __launch_bounds__(WAVE * GINE_APB) void gine_bwd_kernel(GineBArgs a) {
   typedef GineLay<CIN, CHID, COUT, NT, NET, ED> LY;
   constexpr int KE = NET + ED, XW = CIN - NT, S0 = CIN + 1, S1 = CHID + 1;
-  __shared__ float hbuf[GINE_APB][WAVE], tbuf[GINE_APB][WAVE], dybuf[GINE_APB][WAVE], dtbuf[GINE_APB][WAVE];
-  __shared__ float w0s[CHID * S0], w1s[COUT * S1];     // odd strides: row-per-lane AND column-per-lane reads conflict free
+  static_assert(CIN <= WAVE && CHID <= WAVE && COUT <= WAVE, "one lane per channel");
+  // The two MLP matrices go through LDS once per workgroup (odd strides: row-per-lane AND
+  // column-per-lane reads conflict free) into REGISTERS: lane o keeps row o and column o of both.
+  // The mat-vecs then broadcast the activation of lane k with v_readlane: no LDS round trips and
+  // no workgroup barriers inside the atom loop (every wave runs on its own).
+  extern __shared__ float gsm[];                 // prologue: [w0s | w1s]; epilogue: GINE_APB padded partials
+  float* w0s = gsm;
+  float* w1s = gsm + CHID * S0;
   for (int k = threadIdx.x; k < CHID * CIN; k += WAVE * GINE_APB) w0s[(k / CIN) * S0 + k % CIN] = a.w0[k];
   for (int k = threadIdx.x; k < COUT * CHID; k += WAVE * GINE_APB) w1s[(k / CHID) * S1 + k % CHID] = a.w1[k];
   __syncthreads();
   const int lane = threadIdx.x & (WAVE - 1);
   const int w = threadIdx.x >> 6;
   const int wave = blockIdx.x * GINE_APB + w, nwaves = gridDim.x * GINE_APB;
+  float w0r[CIN], w0c[CHID], w1r[CHID], w1c[COUT];
+#pragma unroll
+  for (int c = 0; c < CIN; ++c) w0r[c] = lane < CHID ? w0s[lane * S0 + c] : 0.f;      // row `lane` of nn.lins.0
+#pragma unroll
+  for (int k = 0; k < CHID; ++k) w0c[k] = lane < CIN ? w0s[k * S0 + lane] : 0.f;      // column `lane`
+#pragma unroll
+  for (int k = 0; k < CHID; ++k) w1r[k] = lane < COUT ? w1s[lane * S1 + k] : 0.f;     // row `lane` of nn.lins.1
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) w1c[o] = lane < CHID ? w1s[o * S1 + lane] : 0.f;     // column `lane`
+  const float b0v = lane < CHID ? a.b0[lane] : 0.f, b1v = lane < COUT ? a.b1[lane] : 0.f;
   float acc_w1[CHID], acc_w0[CIN], acc_wa[ED > 0 ? ED : 1], acc_wt[NET > 0 ? NET : 1];
   float acc_b1 = 0.f, acc_b0 = 0.f, acc_be = 0.f, acc_eps = 0.f;
 #pragma unroll
@@ -510,11 +541,8 @@ __global__ __launch_bounds__(WAVE * GINE_APB) void gine_bwd_kernel(GineBArgs a) 
     if (lane < NT) return ((int)a.ntypes[n] == lane) ? 1.f : 0.f;
     return a.x[n * XW + (lane - NT)];
   };
-  // all waves run the same trip count so the workgroup barriers below line up
-  const int64_t iters = (a.N + nwaves - 1) / nwaves;
-  for (int64_t it = 0; it < iters; ++it) {
-    const int64_t i = wave + it * nwaves;
-    const bool valid = i < a.N;
+  for (int64_t i = wave; i < a.N; i += nwaves) {
+    const bool valid = true;
     float xi = 0.f, hval = 0.f;
     int32_t p0 = 0, p1 = 0;
     if (valid) { p0 = a.rowptr[i]; p1 = a.rowptr[i + 1]; }
@@ -585,47 +613,33 @@ __global__ __launch_bounds__(WAVE * GINE_APB) void gine_bwd_kernel(GineBArgs a) 
       }
       hval = fmaf(eps1, xi, agg);
     }
-    hbuf[w][lane] = hval;
-    __syncthreads();
-    float tpre = 0.f;
-    if (valid && lane < CHID) {
-      tpre = a.b0[lane];
-      const float* wr = w0s + lane * S0;
-#pragma unroll 4
-      for (int k = 0; k < CIN; ++k) tpre = fmaf(wr[k], hbuf[w][k], tpre);
-    }
-    tbuf[w][lane] = tpre > 0.f ? tpre : tpre * a.slope;
-    __syncthreads();
+    // ---- MLP forward (recomputed) and backward, activations broadcast lane -> scalar
+    float tpre = b0v;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) tpre = fmaf(w0r[c], lane_bcast(hval, c), tpre);
+    const float tval = tpre > 0.f ? tpre : tpre * a.slope;          // lanes >= CHID: 0
+    float ypre = b1v;
+#pragma unroll
+    for (int k = 0; k < CHID; ++k) ypre = fmaf(w1r[k], lane_bcast(tval, k), ypre);
     float dy = 0.f;
-    if (valid && lane < COUT) {
-      float ypre = a.b1[lane];
-      const float* wr = w1s + lane * S1;
-#pragma unroll 4
-      for (int k = 0; k < CHID; ++k) ypre = fmaf(wr[k], tbuf[w][k], ypre);
+    if (lane < COUT) {
       dy = a.g_out[i * COUT + lane] * (ypre > 0.f ? 1.f : a.slope);
       if (a.mask) dy *= a.mask[i * COUT + lane];
-      acc_b1 += dy;
-#pragma unroll
-      for (int k = 0; k < CHID; ++k) acc_w1[k] = fmaf(dy, tbuf[w][k], acc_w1[k]);
     }
-    dybuf[w][lane] = dy;
-    __syncthreads();
-    float dtp = 0.f;
-    if (valid && lane < CHID) {
-      float dt = 0.f;
-#pragma unroll 4
-      for (int o = 0; o < COUT; ++o) dt = fmaf(w1s[o * S1 + lane], dybuf[w][o], dt);
-      dtp = dt * (tpre > 0.f ? 1.f : a.slope);
-      acc_b0 += dtp;
+    acc_b1 += dy;
 #pragma unroll
-      for (int c = 0; c < CIN; ++c) acc_w0[c] = fmaf(dtp, hbuf[w][c], acc_w0[c]);
-    }
-    dtbuf[w][lane] = dtp;
-    __syncthreads();
+    for (int k = 0; k < CHID; ++k) acc_w1[k] = fmaf(dy, lane_bcast(tval, k), acc_w1[k]);
+    float dt = 0.f;
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) dt = fmaf(w1c[o], lane_bcast(dy, o), dt);
+    const float dtp = lane < CHID ? dt * (tpre > 0.f ? 1.f : a.slope) : 0.f;
+    acc_b0 += dtp;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) acc_w0[c] = fmaf(dtp, lane_bcast(hval, c), acc_w0[c]);
+    float dh = 0.f;
+#pragma unroll
+    for (int k = 0; k < CHID; ++k) dh = fmaf(w0c[k], lane_bcast(dtp, k), dh);
     if (valid && lane < CIN) {
-      float dh = 0.f;
-#pragma unroll 4
-      for (int k = 0; k < CHID; ++k) dh = fmaf(w0s[k * S0 + lane], dtbuf[w][k], dh);
       acc_eps = fmaf(dh, xi, acc_eps);
       if (a.g_x && lane >= NT) atomicAdd(a.g_x + i * XW + (lane - NT), eps1 * dh);
       if (fast) {
@@ -663,39 +677,53 @@ __global__ __launch_bounds__(WAVE * GINE_APB) void gine_bwd_kernel(GineBArgs a) 
         if (a.g_x && lane >= NT) atomicAdd(a.g_x + (int64_t)j * XW + (lane - NT), dm);
       }
     }
-    __syncthreads();
   }
-  float* row = a.slab + (size_t)wave * LY::SIZE;
-  // eps: sum over the lanes of the wave
+  // ---- the workgroup's waves add up through LDS and write ONE slab row (state_dict order)
+  __syncthreads();                               // everybody is done with w0s / w1s
+  float* row = gsm + w * LY::P_SIZE;
   float e = acc_eps;
   for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off);
   if (lane == 0) row[LY::EPS] = e;
   if (lane < CHID) {
-    row[LY::B0 + lane] = acc_b0;
+    row[LY::P_B0 + lane] = acc_b0;
 #pragma unroll
-    for (int c = 0; c < CIN; ++c) row[LY::W0 + lane * CIN + c] = acc_w0[c];
+    for (int c = 0; c < CIN; ++c) row[LY::P_W0 + lane * (CIN + 1) + c] = acc_w0[c];
   }
   if (lane < COUT) {
-    row[LY::B1 + lane] = acc_b1;
+    row[LY::P_B1 + lane] = acc_b1;
 #pragma unroll
-    for (int k = 0; k < CHID; ++k) row[LY::W1 + lane * CHID + k] = acc_w1[k];
+    for (int k = 0; k < CHID; ++k) row[LY::P_W1 + lane * (CHID + 1) + k] = acc_w1[k];
   }
   if (lane < CIN) {
-    row[LY::BE + lane] = acc_be;
+    row[LY::P_BE + lane] = acc_be;
 #pragma unroll
-    for (int k = 0; k < NET; ++k) row[LY::WE + lane * KE + k] = acc_wt[k];
+    for (int k = 0; k < NET; ++k) row[LY::P_WE + lane * (KE + 1) + k] = acc_wt[k];
 #pragma unroll
-    for (int k = 0; k < ED; ++k) row[LY::WE + lane * KE + NET + k] = acc_wa[k];
+    for (int k = 0; k < ED; ++k) row[LY::P_WE + lane * (KE + 1) + NET + k] = acc_wa[k];
+  }
+  __syncthreads();
+  float* out = a.slab + (size_t)blockIdx.x * LY::SIZE;
+  for (int j = threadIdx.x; j < LY::SIZE; j += WAVE * GINE_APB) {
+    const int pj = LY::padded(j);
+    float t = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < GINE_APB; ++ww) t += gsm[ww * LY::P_SIZE + pj];
+    out[j] = t;
   }
 }
 
+constexpr int GINE_BWD_MAX_GRID = 256;          // one workgroup per CU; slab rows = workgroups
 template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
 int gine_bwd_launch(GineBArgs& a, float* grad_layer, hipStream_t st) {
   typedef GineLay<CIN, CHID, COUT, NT, NET, ED> LY;
   int64_t wgs = (a.N + GINE_APB - 1) / GINE_APB;
-  const int G = (int)(wgs < 1 ? 1 : (wgs > 128 ? 128 : wgs));        // <= 512 waves = slab rows
-  hipLaunchKernelGGL((gine_bwd_kernel<CIN, CHID, COUT, NT, NET, ED>), dim3(G), dim3(WAVE * GINE_APB), 0, st, a);
-  quad::reduce_slab(a.slab, G * GINE_APB, LY::SIZE, 0, LY::SIZE, grad_layer, st);
+  const int G = (int)(wgs < 1 ? 1 : (wgs > GINE_BWD_MAX_GRID ? GINE_BWD_MAX_GRID : wgs));
+  constexpr int stage = CHID * (CIN + 1) + COUT * (CHID + 1), red = GINE_APB * LY::P_SIZE;
+  const size_t lds = (size_t)(stage > red ? stage : red) * sizeof(float);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(gine_bwd_kernel<CIN, CHID, COUT, NT, NET, ED>),
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((gine_bwd_kernel<CIN, CHID, COUT, NT, NET, ED>), dim3(G), dim3(WAVE * GINE_APB), lds, st, a);
+  quad::reduce_slab(a.slab, G, LY::SIZE, 0, LY::SIZE, grad_layer, st);
   return 0;
 }
 
@@ -980,7 +1008,7 @@ int cgvp_bwd_reduce(const cgvp_segment* segs, int32_t nsegs, float* grad_params,
   return launch_status();
 }
 
-int64_t cgvp_gine_bwd_workspace_floats(void) { return (int64_t)512 * GineLay<16, 64, 64, 0, 5, 9>::SIZE; }
+int64_t cgvp_gine_bwd_workspace_floats(void) { return (int64_t)GINE_BWD_MAX_GRID * GineLay<16, 64, 64, 0, 5, 9>::SIZE; }
 
 int cgvp_gine_conv_bwd(const float* x, const int64_t* ntypes, int32_t num_ntypes, const float* eattr,
                        const int64_t* etypes, int32_t num_etypes, int32_t edge_dim, const int32_t* rowptr,

@@ -52,7 +52,7 @@ constexpr int TILE = 16;
 // tiles round-robin across workgroups, so a small batch still spreads over all CUs; at the
 // end the workgroup sums its waves' blocks and writes ONE slab row.
 constexpr int BW_WPB = 8, BW_TPB = WAVE * BW_WPB, BW_MAX_GRID = kBwdMaxGrid;
-static_assert(BW_MAX_GRID == 256, "one workgroup per CU");
+static_assert(BW_MAX_GRID <= 256, "at most one workgroup per CU");
 
 template <int BLK>
 __device__ __forceinline__ void zero_block(float* gblk, int lane) {

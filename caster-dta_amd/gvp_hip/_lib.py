@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the HIP runtime we bind to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcaster_gvp.so")
+# CGVP_LIB_PATH: A/B builds of the same ABI (diagnostics); the default is the in-tree library
+LIB_PATH = os.environ.get("CGVP_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libcaster_gvp.so")
 ABI_VERSION = 6
 
 
