@@ -54,6 +54,14 @@ constexpr int TILE = 16;
 constexpr int BW_WPB = 8, BW_TPB = WAVE * BW_WPB, BW_MAX_GRID = kBwdMaxGrid;
 static_assert(BW_MAX_GRID <= 256, "at most one workgroup per CU");
 
+// Lane id the compiler cannot see through.  Taken at the top of every tile: the ~150 lane-dependent
+// flush addresses (and friends) of a tile are then recomputed per tile with a few VALU ops instead of
+// being hoisted out of the tile loop, spilled to scratch and reloaded one memory round trip at a time.
+__device__ __forceinline__ int opaque_lane(int lane) {
+  asm volatile("" : "+v"(lane));
+  return lane;
+}
+
 template <int BLK>
 __device__ __forceinline__ void zero_block(float* gblk, int lane) {
   static_assert(BLK % 4 == 0, "blocks are whole float4s");
@@ -132,21 +140,21 @@ __global__ __launch_bounds__(BW_TPB, 2) void node_bwd_kernel(NodeBArgs a) {
   float* f_node = lds + BW_TPB;                                     // lds[0..BW_TPB): AccPriv::trash()
   float* t_node = f_node + IM::ND_SIZE;
   float* blocks = t_node + IM::TN_SIZE;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane0 = threadIdx.x & 63, w = threadIdx.x >> 6;
   float* gblk = blocks + w * NODE_GB;                               // this wave's private gradient block
   stage_slice<IM::ND_SIZE, BW_TPB>(f_node, a.img_node, threadIdx.x);
   stage_slice<IM::TN_SIZE, BW_TPB>(t_node, a.imgT_node, threadIdx.x);
-  zero_block<NODE_GB>(gblk, lane);
+  zero_block<NODE_GB>(gblk, lane0);
   STAMP(0);
   __syncthreads();
   STAMP(1);
 
-  const int i = lane & 15, g = lane >> 4;
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
   const int zt[1] = {0};
   const bool first = false;
   const int64_t ntiles = (a.N + TILE - 1) / TILE;
   for (int64_t tile = (int64_t)w * gridDim.x + blockIdx.x; tile < ntiles; tile += (int64_t)gridDim.x * BW_WPB) {
+    const int lane = opaque_lane(lane0), i = lane & 15, g = lane >> 4;
     const int64_t n = tile * TILE + i;
     const bool active = n < a.N;
     // ---- recompute the forward of this tile
@@ -359,18 +367,17 @@ __global__ __launch_bounds__(CB_TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* img = lds + BW_TPB;
   float* imgT = img + IM::CV_SIZE;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane0 = threadIdx.x & 63, w = threadIdx.x >> 6;
   float* blocks = imgT + IM::TC_SIZE;
   float* gblk = blocks + w * PW;                                      // this wave's private gradient block (AccPriv)
   float* scr = gblk + B::SIZE;
   stage_slice<IM::CV_SIZE, CB_TPB>(img, a.img, threadIdx.x);
   stage_slice<IM::TC_SIZE, CB_TPB>(imgT, a.imgT, threadIdx.x);
-  for (int k = lane; k < B::SIZE / 4; k += WAVE) reinterpret_cast<f4*>(gblk)[k] = f4{0.f, 0.f, 0.f, 0.f};
+  for (int k = lane0; k < B::SIZE / 4; k += WAVE) reinterpret_cast<f4*>(gblk)[k] = f4{0.f, 0.f, 0.f, 0.f};
   STAMP(0);
   __syncthreads();
   STAMP(1);
 
-  const int i = lane & 15, g = lane >> 4;
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
   const int zt[1] = {0};
   const int64_t ngroups = (a.N + a.npw - 1) / a.npw;
@@ -383,11 +390,12 @@ __global__ __launch_bounds__(CB_TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
     const int nn = (int)((a.N - n0 < a.npw) ? (a.N - n0) : a.npw);
     const int32_t e0 = a.rowptr[n0], e1 = a.rowptr[n0 + nn];
     // owned targets without incoming edges get a zero row (every other owned row is stored below)
-    for (int k = lane; k < nn * ROW; k += WAVE) {
+    for (int k = lane0; k < nn * ROW; k += WAVE) {
       const int64_t nd = n0 + k / ROW;
       if (a.rowptr[nd + 1] == a.rowptr[nd]) a.g_dst[n0 * ROW + k] = 0.f;
     }
     for (int32_t base = e0; base < e1; base += TILE) {
+      const int lane = opaque_lane(lane0), i = lane & 15, g = lane >> 4;
       const int32_t p = base + i;
       const bool active = p < e1;
       // ---- gather (as the forward)
