@@ -232,6 +232,19 @@ struct AccPriv {
   static __device__ __forceinline__ void add(float* p, float v, bool) { *p += v; }
 };
 
+// v[k] is added to p[k] by the lanes with on[k], everybody else adds into the thread's trash word:
+// N unconditional read-add-writes with the reads in flight together (bias / LayerNorm gradients,
+// which only lane i == 15 of a group row holds after row_total).
+template <class Acc, int N>
+__device__ __forceinline__ void add_where(float* const (&p)[N], const bool (&on)[N], const float (&v)[N]) {
+  float* q[N];
+  float old[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) { q[k] = on[k] ? p[k] : Acc::trash(); old[k] = Acc::load(q[k], false); }
+#pragma unroll
+  for (int k = 0; k < N; ++k) Acc::store(q[k], old[k] + v[k]);
+}
+
 // Add a slot-ordered weight-gradient tile grid into the W-layout block `dst` ([.][LD]).
 // BATCHED policies read the old values of a column tile before writing its sums (the
 // targets of one call are distinct elements), so the reads are in flight together
@@ -262,7 +275,9 @@ __device__ __forceinline__ void flush_slots(float* dst, bool first, int LD, cons
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) Acc::store(dst + idx[r], old[r] + acc[mt][nt][r]);
+#ifndef CGVP_FLUSH_NOBARRIER
         __builtin_amdgcn_sched_barrier(0);
+#endif
       }
     } else {
 #pragma unroll
@@ -563,12 +578,18 @@ struct GvpQ {
       flush_slots<Acc, Segs<Seg<P1, 0, SO>>, WsCols, OT, ceil4(NB)>(gblk + A::ws(NT), first, K, acc, lane);
     }
 #pragma unroll
-    for (int t = 0; t < OT; ++t)
+    for (int t = 0; t < OT; ++t) {
+      float tot[4];
+      float* q[4];
+      bool on[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float tot = row_total(active ? gr.dsp[t][r] : 0.f);
-        if (i == 15) Acc::add(gblk + A::bs(NT) + 16 * t + 4 * g + r, tot, first);
+        tot[r] = row_total(active ? gr.dsp[t][r] : 0.f);
+        q[r] = gblk + A::bs(NT) + 16 * t + 4 * g + r;
+        on[r] = i == 15;
       }
+      add_where<Acc, 4>(q, on, tot);
+    }
     if (VO > 0) {
       // ---- dWsv = dgate (x) sp, dbsv = sum dgate
       float a[VOR], b[4 * OT];
@@ -585,10 +606,17 @@ struct GvpQ {
       for (int y = 0; y < OT; ++y) acc[0][y] = zero;
       outer_items<1, OT>(AT, BT, acc);
       flush_slots<Acc, Segs<Seg<P2, 0, (VO > 0 ? VO : 1)>>, Segs<Seg<P1, 0, SO>>, 1, OT>(gblk + A::wsv(NT), first, SO, acc, lane);
+      {
+        float tot[VOR];
+        float* q[VOR];
+        bool on[VOR];
 #pragma unroll
-      for (int r = 0; r < VOR; ++r) {
-        const float tot = row_total(active ? gr.dgate[r] : 0.f);
-        if (i == 15 && 4 * r + g < VO) Acc::add(gblk + A::bsv(NT) + 4 * r + g, tot, first);
+        for (int r = 0; r < VOR; ++r) {
+          tot[r] = row_total(active ? gr.dgate[r] : 0.f);
+          q[r] = gblk + A::bsv(NT) + 4 * r + g;
+          on[r] = i == 15 && 4 * r + g < VO;
+        }
+        add_where<Acc, VOR>(q, on, tot);
       }
       // ---- dWv = sum_planes dvp (x) vh
       f4 accv[1][1] = {{zero}};

@@ -102,16 +102,20 @@ __device__ __forceinline__ void ln_param_grads(float* blk, bool first, int lane,
                                                const f4 (&dgamma)[S / 16], const f4 (&dbeta)[S / 16]) {
   const int i = lane & 15, g = lane >> 4;
 #pragma unroll
-  for (int t = 0; t < S / 16; ++t)
+  for (int t = 0; t < S / 16; ++t) {
+    float tot[8];
+    float* q[8];
+    bool on[8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float tg = row_total(active ? dgamma[t][r] : 0.f);
-      const float tb = row_total(active ? dbeta[t][r] : 0.f);
-      if (i == 15) {
-        Acc::add(blk + 16 * t + 4 * g + r, tg, first);
-        Acc::add(blk + S + 16 * t + 4 * g + r, tb, first);
-      }
+      tot[r] = row_total(active ? dgamma[t][r] : 0.f);
+      tot[4 + r] = row_total(active ? dbeta[t][r] : 0.f);
+      q[r] = blk + 16 * t + 4 * g + r;
+      q[4 + r] = blk + S + 16 * t + 4 * g + r;
+      on[r] = on[4 + r] = i == 15;
     }
+    add_where<Acc, 8>(q, on, tot);
+  }
 }
 
 // ===================================================================== node update
