@@ -118,7 +118,7 @@ def main():
         out = step()
         torch.cuda.synchronize()
         graph = None
-        if not args.no_graph and args.only is None and args.drug_stream == "side":   # the diagnostics run eagerly
+        if not args.no_graph and args.only != "drug" and args.drug_stream == "side":   # drug-only / same-stream diagnostics run eagerly
             s = torch.cuda.Stream(device=dev)
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):

@@ -1,0 +1,470 @@
+// gine_quad_kernels.hip -- backward of one GINEConv layer (PyG GINEConv + MLP as used by
+// HomoMoleculeGNN_GINE, molecule_gnn.py:240-280) on the MFMA quad-layout blocks of gvp_quad.h.
+//
+// Work unit: a tile of 16 ATOMS per wave, lane = (item i = l & 15, group g = l >> 4), channels in
+// pattern P1 (c = 16 t + 4 g + r).  A wave owns its atoms' incoming edges (dst-sorted CSR), which
+// it walks in tiles of 16 EDGES with the same lane mapping:
+//   A. edges   : e = W_e [onehot(type) | bond features] + b_e (MFMA), m = relu(x_src + e),
+//                DPP segmented sum over the sorted targets -> LDS rows agg[atom][c]
+//   B. atoms   : h = (1+eps) x + agg;  t = lrelu(W0 h + b0);  y = W1 t + b1 (MFMA chains);
+//                dy -> dt = W1^T dy -> dh = W0^T dt (transposed fragments);
+//                dW1 = dy (x) t, dW0 = dt (x) h as MFMA outer products over the 16 atoms (operands
+//                transposed on the matrix cores), biases by DPP row sums
+//   C. edges   : dm = relu'(m) dh[target]  -> float atomics into g_x[source];
+//                dW_e = dm (x) [onehot | features], db_e, d eps
+// Weight-gradient partials go to a wave-private block in LDS (AccPriv, state_dict order of the
+// layer); the workgroup sums its four blocks and writes ONE slab row.  Fragments are built from
+// the plain nn.Linear weights while staging them into LDS (the matrices are tiny), so GINE needs
+// no fragment image.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gvp_internal.h"
+#include "gvp_quad.h"
+
+using namespace gq;
+
+namespace {
+
+constexpr int WAVE = 64, TILE = 16;
+constexpr int GQ_WPB = 4, GQ_TPB = WAVE * GQ_WPB;
+constexpr int NTL = 4;                 // edge tiles per chunk (64 edges)
+
+constexpr int pad4i(int x) { return (x + 3) / 4 * 4; }
+
+__device__ __forceinline__ int opaque_lane(int lane) {     // see gvp_quad_bwd_kernels.hip
+  asm volatile("" : "+v"(lane));
+  return lane;
+}
+
+// P1 slots over W (a multiple of 16) channels of which only the first VALID exist.
+template <int W, int VALID>
+struct SegClip {
+  static_assert(W % 16 == 0, "whole 16-channel tiles");
+  static constexpr int steps = W / 4;
+  static __host__ __device__ int col(int s, int g) {
+    const int c = 16 * (s >> 2) + 4 * g + (s & 3);
+    return c < VALID ? c : -1;
+  }
+};
+
+struct GineQArgs {
+  const float* x; const int64_t* ntypes; const float* eattr; const int64_t* etypes;
+  const int32_t* rowptr; const int32_t* eperm; const int32_t* esrc; const int32_t* edst; int64_t N;
+  const float* eps; const float* we; const float* be; const float* w0; const float* b0;
+  const float* w1; const float* b1; float slope;
+  const float* mask; const float* g_out; float* g_x; float* slab;
+};
+
+template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
+struct GineQ {
+  static_assert(CHID % 16 == 0 && COUT % 16 == 0, "hidden / output widths are whole 16-channel tiles");
+  static constexpr int KE = NET + ED, XW = CIN - NT, CINP = (CIN + 15) / 16 * 16;
+  static constexpr int MI = CINP / 16, MH = CHID / 16, MO = COUT / 16;
+  // layer gradient block, state_dict order (= GineLay of gvp_kernels.hip)
+  static constexpr int L_EPS = 0, L_W0 = 1, L_B0 = L_W0 + CHID * CIN, L_W1 = L_B0 + CHID, L_B1 = L_W1 + COUT * CHID,
+                       L_WE = L_B1 + COUT, L_BE = L_WE + CIN * KE, L_SIZE = L_BE + CIN, BLK = pad4i(L_SIZE);
+  typedef SegClip<CINP, CIN> KIn;
+  typedef Seg<P1, 0, CHID> KHid;
+  typedef Seg<P1, 0, COUT> KOut;
+  typedef Seg<P2, 0, KE> KFeat;
+  static_assert(KFeat::steps <= 4, "bond one-hot + features fit one slot tile");
+  typedef Gemm<P1, CIN, KE, KFeat> GE;          // lin      [CIN][KE]
+  typedef Gemm<P1, CHID, CIN, KIn> G0;          // lins.0   [CHID][CIN]
+  typedef Gemm<P1, COUT, CHID, KHid> G1;        // lins.1   [COUT][CHID]
+  typedef GemmT<KHid, KOut, CHID> G1T;
+  typedef GemmT<KIn, KHid, CIN> G0T;
+  static constexpr int F_E = 0, F_0 = F_E + GE::NFRAG * 64, F_0T = F_0 + G0::NFRAG * 64, F_1 = F_0T + G0T::NFRAG * 64,
+                       F_1T = F_1 + G1::NFRAG * 64, F_SIZE = F_1T + G1T::NFRAG * 64;
+  static constexpr int ROWS = TILE * CINP;       // per wave: agg rows, then dh rows
+  static constexpr int LDS_FLOATS = GQ_TPB + F_SIZE + GQ_WPB * (BLK + ROWS);
+  static_assert(LDS_FLOATS * 4 <= 160 * 1024, "GINE backward LDS plan exceeds the CU");
+};
+
+template <class G>
+__device__ __forceinline__ void stage_fragments(float* lds, const float* __restrict__ W) {
+  for (int idx = threadIdx.x; idx < G::NFRAG * 64; idx += GQ_TPB) lds[idx] = G::element(W, idx);
+}
+
+template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
+__global__ __launch_bounds__(GQ_TPB) void gine_quad_bwd_kernel(GineQArgs a) {
+  typedef GineQ<CIN, CHID, COUT, NT, NET, ED> Q;
+  constexpr int KE = Q::KE, XW = Q::XW, CINP = Q::CINP, MI = Q::MI, MH = Q::MH, MO = Q::MO;
+  extern __shared__ __attribute__((aligned(16))) float lds[];       // lds[0..GQ_TPB): AccPriv::trash()
+  float* frag = lds + GQ_TPB;
+  const int lane0 = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* blocks = frag + Q::F_SIZE;
+  float* blk = blocks + w * Q::BLK;                                  // this wave's private gradient block
+  float* rows = blocks + GQ_WPB * Q::BLK + w * Q::ROWS;              // [16][CINP]
+  stage_fragments<typename Q::GE>(frag + Q::F_E, a.we);
+  stage_fragments<typename Q::G0>(frag + Q::F_0, a.w0);
+  stage_fragments<typename Q::G0T>(frag + Q::F_0T, a.w0);
+  stage_fragments<typename Q::G1>(frag + Q::F_1, a.w1);
+  stage_fragments<typename Q::G1T>(frag + Q::F_1T, a.w1);
+  for (int k = lane0; k < Q::BLK / 4; k += WAVE) reinterpret_cast<f4*>(blk)[k] = f4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  const float eps1 = 1.0f + a.eps[0];
+  float acc_eps = 0.f;
+  const int64_t ntiles = (a.N + TILE - 1) / TILE;
+  for (int64_t tile = (int64_t)blockIdx.x * GQ_WPB + w; tile < ntiles; tile += (int64_t)gridDim.x * GQ_WPB) {
+    const int64_t n0 = tile * TILE;
+    const int nn = (int)((a.N - n0 < TILE) ? (a.N - n0) : TILE);
+    const int32_t e0 = a.rowptr[n0], e1 = a.rowptr[n0 + nn];
+    for (int k = lane0; k < Q::ROWS / 4; k += WAVE) reinterpret_cast<f4*>(rows)[k] = zero;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    // Edges are taken in CHUNKS of up to 64 (4 edge tiles).  A chunk's metadata is fetched
+    // lane-parallel (lane l <- edge c0 + l) and handed to the (edge i, group g) lanes of each tile by
+    // ds_bpermute; then every load of the chunk (bond features, source rows) is in flight at once:
+    // a chunk costs ~4 dependent memory hops instead of 3 per edge tile.  Molecules have <= 64 incoming
+    // edges per 16 atoms almost always; then phase C reuses the registers and issues no loads at all.
+    int32_t c_src[NTL], c_dst[NTL];
+    float c_fs[NTL][1][4];
+    unsigned c_pos[NTL];                                   // bit 4 mt + r: message channel passed the ReLU
+    const bool single = e1 - e0 <= NTL * TILE;
+
+    auto load_chunk = [&](int32_t c0, int lane, f4 (&xj)[NTL][MI]) {
+      const int i = lane & 15, g = lane >> 4;
+      int32_t m_eid = 0, m_src = 0, m_dst = -1, m_et = 0;
+      if (c0 + lane < e1) {
+        m_eid = a.eperm[c0 + lane];
+        m_src = a.esrc[c0 + lane];
+        m_dst = a.edst[c0 + lane];
+        if (NET > 0) {
+          m_et = (int)a.etypes[m_eid];
+          m_et = m_et < 0 ? 0 : (m_et >= NET ? NET - 1 : m_et);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        const int sl = 16 * t + i;
+        const int32_t eid = __shfl(m_eid, sl), et = __shfl(m_et, sl);
+        c_src[t] = __shfl(m_src, sl);
+        c_dst[t] = __shfl(m_dst, sl);                      // -1: no such edge
+        const bool active = c_dst[t] >= 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {                       // k-slots of [onehot(type) | bond features]
+          const int idx = 4 * s + g;
+          float v = 0.f;
+          if (active) {
+            if (idx < NET) v = (et == idx) ? 1.f : 0.f;
+            else if (idx < KE) v = a.eattr[(int64_t)eid * ED + (idx - NET)];
+          }
+          c_fs[t][0][s] = v;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MI; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = 16 * mt + 4 * g + r;
+            float v = 0.f;
+            if (active && c < CIN)
+              v = c < NT ? (((int)a.ntypes[c_src[t]] == c) ? 1.f : 0.f) : a.x[(int64_t)c_src[t] * XW + (c - NT)];
+            xj[t][mt][r] = v;
+          }
+      }
+    };
+    // message pre-activation of tile t of the loaded chunk -> ReLU pattern (and the messages)
+    auto messages = [&](int t, int lane, const f4 (&xj)[NTL][MI], f4 (&m)[MI]) {
+      const int g = lane >> 4;
+      unsigned pos = 0u;
+#pragma unroll
+      for (int mt = 0; mt < MI; ++mt) {
+        f4 acc[1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * mt + 4 * g + r;
+          acc[0][r] = c < CIN ? a.be[c] : 0.f;
+        }
+        apply<typename Q::GE, 1>(frag + Q::F_E, mt, c_fs[t], acc, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float mj = xj[t][mt][r] + acc[0][r];
+          const bool on = c_dst[t] >= 0 && mj > 0.f;
+          m[mt][r] = on ? mj : 0.f;
+          pos |= on ? (1u << (4 * mt + r)) : 0u;
+        }
+      }
+      c_pos[t] = pos;
+    };
+
+    // ---- A. aggregate relu(x_src + e) over the incoming edges of the owned atoms
+    for (int32_t c0 = e0; c0 < e1; c0 += NTL * TILE) {
+      const int lane = opaque_lane(lane0), i = lane & 15, g = lane >> 4;
+      f4 xj[NTL][MI];
+      load_chunk(c0, lane, xj);
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        if (c0 + t * TILE >= e1) break;
+        f4 m[MI];
+        messages(t, lane, xj, m);
+        float xs[4 * MI];
+#pragma unroll
+        for (int mt = 0; mt < MI; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xs[4 * mt + r] = m[mt][r];
+        const int32_t dst = c_dst[t];
+        seg_scan16<4 * MI>(dst, xs);
+        const int nxt = __builtin_amdgcn_update_dpp(-1, dst, 0x100 | 1, 0xf, 0xf, false);
+        if (dst >= 0 && (i == TILE - 1 || nxt != dst)) {
+          float* row = rows + (dst - (int)n0) * CINP;
+#pragma unroll
+          for (int mt = 0; mt < MI; ++mt) {
+            f4* q = reinterpret_cast<f4*>(row + 16 * mt + 4 * g);
+            *q = *q + f4{xs[4 * mt], xs[4 * mt + 1], xs[4 * mt + 2], xs[4 * mt + 3]};
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+    }
+
+    // ---- B. the MLP of the 16 atoms, forward and backward
+    {
+      const int lane = opaque_lane(lane0), i = lane & 15, g = lane >> 4;
+      const bool valid = i < nn;
+      const int64_t n = n0 + i;
+      f4 xi[MI], h[MI];
+#pragma unroll
+      for (int mt = 0; mt < MI; ++mt) {
+        const f4 ag = *reinterpret_cast<const f4*>(rows + i * CINP + 16 * mt + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * mt + 4 * g + r;
+          float v = 0.f;
+          if (valid && c < CIN) v = c < NT ? (((int)a.ntypes[n] == c) ? 1.f : 0.f) : a.x[n * XW + (c - NT)];
+          xi[mt][r] = v;
+          h[mt][r] = fmaf(eps1, v, ag[r]);
+        }
+      }
+      float bh[1][Q::KIn::steps];
+#pragma unroll
+      for (int s = 0; s < Q::KIn::steps; ++s) bh[0][s] = h[s >> 2][s & 3];
+      f4 tpre[MH], t[MH];
+#pragma unroll
+      for (int mt = 0; mt < MH; ++mt) {
+        f4 acc[1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[0][r] = a.b0[16 * mt + 4 * g + r];
+        apply<typename Q::G0, 1>(frag + Q::F_0, mt, bh, acc, lane);
+        tpre[mt] = acc[0];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[mt][r] = acc[0][r] > 0.f ? acc[0][r] : acc[0][r] * a.slope;
+      }
+      float bt[1][Q::KHid::steps];
+#pragma unroll
+      for (int s = 0; s < Q::KHid::steps; ++s) bt[0][s] = t[s >> 2][s & 3];
+      f4 dy[MO];
+#pragma unroll
+      for (int mt = 0; mt < MO; ++mt) {
+        f4 acc[1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[0][r] = a.b1[16 * mt + 4 * g + r];
+        apply<typename Q::G1, 1>(frag + Q::F_1, mt, bt, acc, lane);
+        f4 gy = zero;
+        if (valid) {
+          gy = *reinterpret_cast<const f4*>(a.g_out + n * COUT + 16 * mt + 4 * g);
+          if (a.mask) gy = gy * *reinterpret_cast<const f4*>(a.mask + n * COUT + 16 * mt + 4 * g);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dy[mt][r] = gy[r] * (acc[0][r] > 0.f ? 1.f : a.slope);
+      }
+      float bdy[1][Q::KOut::steps];
+#pragma unroll
+      for (int s = 0; s < Q::KOut::steps; ++s) bdy[0][s] = dy[s >> 2][s & 3];
+      f4 dtp[MH];
+#pragma unroll
+      for (int mt = 0; mt < MH; ++mt) {
+        f4 acc[1] = {zero};
+        apply<typename Q::G1T, 1>(frag + Q::F_1T, mt, bdy, acc, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dtp[mt][r] = acc[0][r] * (tpre[mt][r] > 0.f ? 1.f : a.slope);
+      }
+      float bdt[1][Q::KHid::steps];
+#pragma unroll
+      for (int s = 0; s < Q::KHid::steps; ++s) bdt[0][s] = dtp[s >> 2][s & 3];
+      f4 dh[MI];
+#pragma unroll
+      for (int mt = 0; mt < MI; ++mt) {
+        f4 acc[1] = {zero};
+        apply<typename Q::G0T, 1>(frag + Q::F_0T, mt, bdt, acc, lane);
+        dh[mt] = acc[0];
+      }
+      // ---- weight gradients of the two Linear layers
+      {
+        f4 AT[MO], BT[MH], acc[MO][MH];
+        transpose_slots<Q::KOut::steps>(bdy[0], AT, lane);
+        transpose_slots<Q::KHid::steps>(bt[0], BT, lane);
+#pragma unroll
+        for (int x = 0; x < MO; ++x)
+#pragma unroll
+          for (int y = 0; y < MH; ++y) acc[x][y] = zero;
+        outer_items<MO, MH>(AT, BT, acc);
+        flush_slots<AccPriv, typename Q::KOut, typename Q::KHid, MO, MH>(blk + Q::L_W1, false, CHID, acc, lane);
+#pragma unroll
+        for (int mt = 0; mt < MO; ++mt) {
+          float tot[4];
+          float* q[4];
+          bool on[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            tot[r] = row_total(dy[mt][r]);
+            q[r] = blk + Q::L_B1 + 16 * mt + 4 * g + r;
+            on[r] = i == 15;
+          }
+          add_where<AccPriv, 4>(q, on, tot);
+        }
+      }
+      {
+        f4 AT[MH], BT[MI], acc[MH][MI];
+        transpose_slots<Q::KHid::steps>(bdt[0], AT, lane);
+        transpose_slots<Q::KIn::steps>(bh[0], BT, lane);
+#pragma unroll
+        for (int x = 0; x < MH; ++x)
+#pragma unroll
+          for (int y = 0; y < MI; ++y) acc[x][y] = zero;
+        outer_items<MH, MI>(AT, BT, acc);
+        flush_slots<AccPriv, typename Q::KHid, typename Q::KIn, MH, MI>(blk + Q::L_W0, false, CIN, acc, lane);
+#pragma unroll
+        for (int mt = 0; mt < MH; ++mt) {
+          float tot[4];
+          float* q[4];
+          bool on[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            tot[r] = row_total(dtp[mt][r]);
+            q[r] = blk + Q::L_B0 + 16 * mt + 4 * g + r;
+            on[r] = i == 15;
+          }
+          add_where<AccPriv, 4>(q, on, tot);
+        }
+      }
+      // ---- d eps, d x (self term), and dh rows for the edge phase
+#pragma unroll
+      for (int mt = 0; mt < MI; ++mt) {
+        *reinterpret_cast<f4*>(rows + i * CINP + 16 * mt + 4 * g) = dh[mt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * mt + 4 * g + r;
+          acc_eps = fmaf(dh[mt][r], xi[mt][r], acc_eps);
+          if (a.g_x && valid && c >= NT && c < CIN) atomicAdd(a.g_x + n * XW + (c - NT), eps1 * dh[mt][r]);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+
+    // ---- C. edges again: d message -> sources, lin weight gradients
+    for (int32_t c0 = e0; c0 < e1; c0 += NTL * TILE) {
+      const int lane = opaque_lane(lane0), i = lane & 15, g = lane >> 4;
+      if (!single) {                               // more than one chunk: its registers were overwritten
+        f4 xj[NTL][MI];
+        load_chunk(c0, lane, xj);
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+          if (c0 + t * TILE >= e1) break;
+          f4 m[MI];
+          messages(t, lane, xj, m);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        if (c0 + t * TILE >= e1) break;
+        const int32_t src = c_src[t], dst = c_dst[t];
+        const bool active = dst >= 0;
+        f4 dm[MI];
+        float dms[Q::KIn::steps];
+#pragma unroll
+        for (int mt = 0; mt < MI; ++mt) {
+          f4 d = zero;
+          if (active) d = *reinterpret_cast<const f4*>(rows + (dst - (int)n0) * CINP + 16 * mt + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = 16 * mt + 4 * g + r;
+            dm[mt][r] = ((c_pos[t] >> (4 * mt + r)) & 1u) ? d[r] : 0.f;
+            dms[4 * mt + r] = dm[mt][r];
+            if (a.g_x && c >= NT && c < CIN && dm[mt][r] != 0.f)
+              atomicAdd(a.g_x + (int64_t)src * XW + (c - NT), dm[mt][r]);
+          }
+        }
+        f4 AT[MI], BT[1], acc[MI][1];
+        transpose_slots<Q::KIn::steps>(dms, AT, lane);
+        transpose_slots<4>(c_fs[t][0], BT, lane);
+#pragma unroll
+        for (int x = 0; x < MI; ++x) acc[x][0] = zero;
+        outer_items<MI, 1>(AT, BT, acc);
+        flush_slots<AccPriv, typename Q::KIn, typename Q::KFeat, MI, 1>(blk + Q::L_WE, false, KE, acc, lane);
+#pragma unroll
+        for (int mt = 0; mt < MI; ++mt) {
+          float tot[4];
+          float* q[4];
+          bool on[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = 16 * mt + 4 * g + r;
+            tot[r] = row_total(dm[mt][r]);
+            q[r] = blk + Q::L_BE + c;
+            on[r] = i == 15 && c < CIN;
+          }
+          add_where<AccPriv, 4>(q, on, tot);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  // d eps: sum over the lanes of the wave, into the private block
+  for (int off = 32; off > 0; off >>= 1) acc_eps += __shfl_down(acc_eps, off);
+  if (lane0 == 0) blk[Q::L_EPS] += acc_eps;
+  // one slab row per workgroup
+  __syncthreads();
+  float* out = a.slab + (size_t)blockIdx.x * Q::L_SIZE;
+  for (int k = threadIdx.x; k < Q::L_SIZE; k += GQ_TPB) {
+    float s = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < GQ_WPB; ++ww) s += blocks[ww * Q::BLK + k];
+    out[k] = s;
+  }
+}
+
+template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
+int launch(GineQArgs& a, int* rows, int* row_len, hipStream_t st) {
+  typedef GineQ<CIN, CHID, COUT, NT, NET, ED> Q;
+  const int64_t tiles = (a.N + TILE - 1) / TILE;
+  int64_t wgs = (tiles + GQ_WPB - 1) / GQ_WPB;
+  const int G = (int)(wgs < 1 ? 1 : (wgs > quad::kGineBwdMaxGrid ? quad::kGineBwdMaxGrid : wgs));
+  const size_t lds = (size_t)Q::LDS_FLOATS * sizeof(float);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(gine_quad_bwd_kernel<CIN, CHID, COUT, NT, NET, ED>),
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((gine_quad_bwd_kernel<CIN, CHID, COUT, NT, NET, ED>), dim3(G), dim3(GQ_TPB), lds, st, a);
+  *rows = G;
+  *row_len = Q::L_SIZE;
+  return 0;
+}
+
+}  // namespace
+
+namespace quad {
+
+int gine_bwd(int cin, int chid, int cout, int nt, int net, int ed, const float* x, const int64_t* ntypes,
+             const float* eattr, const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,
+             const int32_t* esrc, const int32_t* edst, int64_t N, const cgvp_gine_w* w, float slope,
+             const float* mask, const float* g_out, float* g_x, float* slab, int* rows, int* row_len,
+             hipStream_t st) {
+  GineQArgs a{x, ntypes, eattr, etypes, rowptr, eperm, esrc, edst, N, w->eps, w->we, w->be, w->w0, w->b0,
+              w->w1, w->b1, slope, mask, g_out, g_x, slab};
+  // compiled for the layer shapes of HomoMoleculeGNN_GINE in CASTER-DTA (molecule_gnn.py:240-250)
+  if (cin == 52 && chid == 16 && cout == 16 && nt == 11 && net == 5 && ed == 9) return launch<52, 16, 16, 11, 5, 9>(a, rows, row_len, st);
+  if (cin == 16 && chid == 64 && cout == 64 && nt == 0 && net == 5 && ed == 9) return launch<16, 64, 64, 0, 5, 9>(a, rows, row_len, st);
+  if (cin == 16 && chid == 16 && cout == 16 && nt == 0 && net == 5 && ed == 9) return launch<16, 16, 16, 0, 5, 9>(a, rows, row_len, st);   // middle layers of deeper stacks
+  return CGVP_ERR_UNSUPPORTED_DIMS;
+}
+
+}  // namespace quad

@@ -13,7 +13,7 @@ struct QuadOffsets {
 };
 
 #ifndef CGVP_BWD_MAX_GRID
-#define CGVP_BWD_MAX_GRID 256       // A/B builds only (-DCGVP_BWD_MAX_GRID=...)
+#define CGVP_BWD_MAX_GRID 240       // of 256 CUs: the rest is left to the drug-side backward running beside it
 #endif
 constexpr int kBwdMaxGrid = CGVP_BWD_MAX_GRID;    // persistent workgroups of the backward kernels (one per CU) = slab rows per stage
 
@@ -43,6 +43,17 @@ int conv_bwd(int nt_edge, const float* img, const float* imgT, const float* h, c
 int node_embed_bwd(int nt_node, const float* img, const float* imgT, const float* x_s, const float* x_v,
                    const int64_t* ntypes, int64_t N, const float* g_up0, const float* g_up1, const float* g_up2,
                    float* g_x_s, float* g_x_v, float* slab, int* grid, hipStream_t st);
+// GINE layer backward on 16-atom MFMA tiles (gine_quad_kernels.hip): one slab row per workgroup
+// (`rows` x `row_len` floats, state_dict order of the layer).
+#ifndef CGVP_GINE_BWD_MAX_GRID
+#define CGVP_GINE_BWD_MAX_GRID 16   // the CUs the protein backward (kBwdMaxGrid workgroups, one per CU) leaves free
+#endif
+constexpr int kGineBwdMaxGrid = CGVP_GINE_BWD_MAX_GRID;
+int gine_bwd(int cin, int chid, int cout, int nt, int net, int ed, const float* x, const int64_t* ntypes,
+             const float* eattr, const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,
+             const int32_t* esrc, const int32_t* edst, int64_t N, const cgvp_gine_w* w, float slope,
+             const float* mask, const float* g_out, float* g_x, float* slab, int* rows, int* row_len,
+             hipStream_t st);
 int reduce_slab(const float* slab, int rows, int stride, int col0, int len, float* dst, hipStream_t st);
 int reduce_segments(const cgvp_segment* segs, int nsegs, float* grad_params, hipStream_t st);
 int bwd_block_sizes(int nt_node, int nt_edge, int* emb, int* conv_edge, int* conv_total, int* node, int* head);

@@ -1008,32 +1008,28 @@ int cgvp_bwd_reduce(const cgvp_segment* segs, int32_t nsegs, float* grad_params,
   return launch_status();
 }
 
-int64_t cgvp_gine_bwd_workspace_floats(void) { return (int64_t)GINE_BWD_MAX_GRID * GineLay<16, 64, 64, 0, 5, 9>::SIZE; }
+int64_t cgvp_gine_bwd_workspace_floats(void) { return (int64_t)quad::kGineBwdMaxGrid * GineLay<16, 64, 64, 0, 5, 9>::SIZE; }
 
 int cgvp_gine_conv_bwd(const float* x, const int64_t* ntypes, int32_t num_ntypes, const float* eattr,
                        const int64_t* etypes, int32_t num_etypes, int32_t edge_dim, const int32_t* rowptr,
-                       const int32_t* eperm, const int32_t* esrc, int64_t N, int64_t E, int32_t cin,
-                       int32_t chid, int32_t cout, const cgvp_gine_w* w, float act_slope, const float* mask,
-                       const float* g_out, float* g_x, float* grad_layer, float* workspace, void* stream) {
+                       const int32_t* eperm, const int32_t* esrc, const int32_t* edst, int64_t N, int64_t E,
+                       int32_t cin, int32_t chid, int32_t cout, const cgvp_gine_w* w, float act_slope,
+                       const float* mask, const float* g_out, float* g_x, float* grad_layer, float* workspace,
+                       void* stream) {
   if (N < 0 || E < 0 || !w || !grad_layer || !workspace) return CGVP_ERR_BAD_ARG;
   if (N == 0) return 0;
   if (!x || !g_out || !rowptr || (num_ntypes > 0 && !ntypes)) return CGVP_ERR_BAD_ARG;
-  if (E > 0 && (!eperm || !esrc || (edge_dim > 0 && !eattr) || (num_etypes > 0 && !etypes))) return CGVP_ERR_BAD_ARG;
+  if (E > 0 && (!eperm || !esrc || !edst || (edge_dim > 0 && !eattr) || (num_etypes > 0 && !etypes))) return CGVP_ERR_BAD_ARG;
+  if (((uintptr_t)g_out & 15) || ((uintptr_t)mask & 15)) return CGVP_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (g_x) {
     hipError_t err = hipMemsetAsync(g_x, 0, (size_t)N * (cin - num_ntypes) * sizeof(float), st);
     if (err != hipSuccess) return (int)err;
   }
-  GineBArgs a{x, ntypes, eattr, etypes, rowptr, eperm, esrc, N, w->eps, w->we, w->be, w->w0, w->b0, w->w1, w->b1,
-              act_slope, mask, g_out, g_x, workspace};
-  // compiled for the two layer shapes of HomoMoleculeGNN_GINE in CASTER-DTA (molecule_gnn.py:240-250)
-  if (cin == 52 && chid == 16 && cout == 16 && num_ntypes == 11 && num_etypes == 5 && edge_dim == 9)
-    gine_bwd_launch<52, 16, 16, 11, 5, 9>(a, grad_layer, st);
-  else if (cin == 16 && chid == 64 && cout == 64 && num_ntypes == 0 && num_etypes == 5 && edge_dim == 9)
-    gine_bwd_launch<16, 64, 64, 0, 5, 9>(a, grad_layer, st);
-  else if (cin == 16 && chid == 16 && cout == 16 && num_ntypes == 0 && num_etypes == 5 && edge_dim == 9)
-    gine_bwd_launch<16, 16, 16, 0, 5, 9>(a, grad_layer, st);       // middle layers of deeper stacks
-  else return CGVP_ERR_UNSUPPORTED_DIMS;
+  int rows = 0, row_len = 0;
+  if (int rc = quad::gine_bwd(cin, chid, cout, num_ntypes, num_etypes, edge_dim, x, ntypes, eattr, etypes, rowptr, eperm,
+                              esrc, edst, N, w, act_slope, mask, g_out, g_x, workspace, &rows, &row_len, st)) return rc;
+  quad::reduce_slab(workspace, rows, row_len, 0, row_len, grad_layer, st);
   return launch_status();
 }
 

@@ -693,6 +693,15 @@ __global__ __launch_bounds__(RED_COLS * RED_RG) void reduce_slab_kernel(const fl
   }
 }
 
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ slab, int rows, int stride, int col0,
+                                                          int len, float* __restrict__ dst) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= len) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += slab[(size_t)r * stride + col0 + j];
+  dst[j] += s;
+}
+
 struct SegTable { cgvp_segment s[CGVP_MAX_SEGS]; };
 __global__ __launch_bounds__(RED_COLS * RED_RG) void reduce_segments_kernel(SegTable t, float* __restrict__ grad) {
   __shared__ float part[RED_RG][RED_COLS];
@@ -743,6 +752,10 @@ int reduce_segments(const cgvp_segment* segs, int nsegs, float* grad_params, hip
 }
 
 int reduce_slab(const float* slab, int rows, int stride, int col0, int len, float* dst, hipStream_t st) {
+  if (rows <= 32) {            // a handful of rows: one thread per column, small workgroups that fit beside anything
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((len + 255) / 256), dim3(256), 0, st, slab, rows, stride, col0, len, dst);
+    return 0;
+  }
   hipLaunchKernelGGL(reduce_slab_kernel, dim3((len + RED_COLS - 1) / RED_COLS), dim3(RED_COLS * RED_RG), 0, st, slab, rows, stride, col0, len, dst);
   return 0;
 }

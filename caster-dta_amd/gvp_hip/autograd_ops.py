@@ -197,7 +197,7 @@ class _GineEncoderFn(torch.autograd.Function):
                 gw = _lib.GineW(**{k: v.data_ptr() for k, v in w.items()})
                 rc = L.cgvp_gine_conv_bwd(_ptr(hs[l]), _ptr(nt if first else None), m["num_ntypes"] if first else 0,
                                           _ptr(eattr), _ptr(et), m["num_etypes"], edge_dim, _ptr(csr.rowptr),
-                                          _ptr(csr.eperm), _ptr(csr.esrc), N, csr.num_edges, cin, cout, cout,
+                                          _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst), N, csr.num_edges, cin, cout, cout,
                                           C.byref(gw), float(m["slope"]), _ptr(masks[l]), _ptr(g), _ptr(g_x),
                                           _ptr(glayer), _ptr(wsp), _stream())
                 _lib.check(rc, "cgvp_gine_conv_bwd")

@@ -240,15 +240,18 @@ int cgvp_gine_conv_fwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
  * (NULL to skip; zeroed here, filled with float atomics) and the layer's weight
  * gradients ADDED into `grad_layer` in state_dict order
  *   eps | nn.lins.0.weight | nn.lins.0.bias | nn.lins.1.weight | nn.lins.1.bias | lin.weight | lin.bias.
- * Compiled for the CASTER-DTA layer shapes (52,16,16), (16,64,64), (16,16,16)
- * with 11 / 0 atom types, 5 bond types, 9 bond features. */
+ * Takes all four CSR tables of cgvp_csr_from_coo (the forward needs no edst).
+ * Runs on 16-atom MFMA tiles (csrc/gine_quad_kernels.hip).  Compiled for the
+ * CASTER-DTA layer shapes (52,16,16), (16,64,64), (16,16,16) with 11 / 0 atom
+ * types, 5 bond types, 9 bond features. */
 int64_t cgvp_gine_bwd_workspace_floats(void);
 int cgvp_gine_conv_bwd(const float* x, const int64_t* ntypes, int32_t num_ntypes, const float* eattr,
                        const int64_t* etypes, int32_t num_etypes, int32_t edge_dim,
                        const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
-                       int64_t num_nodes, int64_t num_edges, int32_t cin, int32_t chid, int32_t cout,
-                       const cgvp_gine_w* w, float act_slope, const float* mask, const float* g_out,
-                       float* g_x, float* grad_layer, float* workspace, void* stream);
+                       const int32_t* edst, int64_t num_nodes, int64_t num_edges, int32_t cin,
+                       int32_t chid, int32_t cout, const cgvp_gine_w* w, float act_slope,
+                       const float* mask, const float* g_out, float* g_x, float* grad_layer,
+                       float* workspace, void* stream);
 
 /* Library self-description (checked by the loader and the CPU test-suite). */
 int cgvp_abi_version(void);

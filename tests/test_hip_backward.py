@@ -173,6 +173,41 @@ def test_gine_backward_vs_oracle(molecule_params):
     assert rel_err(gx.grad, x.grad) < 2e-4
 
 
+def test_gine_backward_dense_graph(molecule_params):
+    """A graph no molecule looks like: 8-12 incoming edges per atom (more than 64 edges per 16-atom tile:
+    the multi-chunk path of the GINE backward), a few atoms without edges, a ragged last tile."""
+    from models.molecule_gnn import SelectableMoleculeModelWrapper
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))["molecule_gnn_kwargs"]
+    model = SelectableMoleculeModelWrapper(**kw)
+    model.load_state_dict({"gnn_model." + k: v for k, v in molecule_params.items()})
+    model = model.to(DEV).eval()
+    base = ds.to_torch(ds.drug_batch(5, 7))
+    gen = torch.Generator().manual_seed(5)
+    n = base["x"].shape[0] - 3                       # not a multiple of 16 for this seed's sizes
+    x, ntypes = base["x"][:n].clone(), base["ntypes"][:n].clone()
+    deg = torch.randint(8, 13, (n,), generator=gen)
+    deg[torch.randperm(n, generator=gen)[:4]] = 0     # isolated atoms
+    dst = torch.repeat_interleave(torch.arange(n), deg)
+    src = torch.randint(0, n, (int(deg.sum()),), generator=gen)
+    perm = torch.randperm(dst.numel(), generator=gen)
+    edge_index = torch.stack([src, dst])[:, perm].contiguous()
+    E = edge_index.shape[1]
+    etypes = torch.randint(0, 5, (E,), generator=gen)
+    eattr = torch.randn(E, base["eattr"].shape[1], generator=gen)
+    P = {k: v.clone().requires_grad_(True) for k, v in molecule_params.items()}
+    xr = x.clone().requires_grad_()
+    ref = O.molecule_gine_forward(P, xr, edge_index, ntypes, etypes, eattr)
+    r = torch.randn(ref.shape, generator=torch.Generator().manual_seed(2))
+    (ref * r).sum().backward()
+    gx = x.to(DEV).requires_grad_()
+    out = model(gx, edge_index.to(DEV), ntypes.to(DEV), etypes.to(DEV), eattr=eattr.to(DEV))
+    assert rel_err(out, ref) < 2e-5
+    (out * r.to(DEV)).sum().backward()
+    for name, p in model.gnn_model.named_parameters():
+        assert rel_err(p.grad, P[name].grad) < 2e-4, name
+    assert rel_err(gx.grad, xr.grad) < 2e-4
+
+
 def test_joint_model_training_step(pretrained):
     """train_model.py:548-587 in miniature: JointGNN in train() mode (dropout on),
     MSE loss, backward through head (torch) + both encoders (HIP), Adam step; the
