@@ -27,7 +27,6 @@ using namespace gq;
 namespace {
 
 constexpr int WAVE = 64, TILE = 16;
-constexpr int GQ_WPB = 4, GQ_TPB = WAVE * GQ_WPB;
 constexpr int NTL = 4;                 // edge tiles per chunk (64 edges)
 
 constexpr int pad4i(int x) { return (x + 3) / 4 * 4; }
@@ -58,7 +57,7 @@ struct GineQArgs {
 
 template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
 struct GineQ {
-  static_assert(CHID % 16 == 0 && COUT % 16 == 0, "hidden / output widths are whole 16-channel tiles");
+  static_assert(CHID % 16 == 0 && COUT % 16 == 0 && COUT <= 64, "hidden / output widths are whole 16-channel tiles (<= 4 output tiles)");
   static constexpr int KE = NET + ED, XW = CIN - NT, CINP = (CIN + 15) / 16 * 16;
   static constexpr int MI = CINP / 16, MH = CHID / 16, MO = COUT / 16;
   // layer gradient block, state_dict order (= GineLay of gvp_kernels.hip)
@@ -77,18 +76,38 @@ struct GineQ {
   static constexpr int F_E = 0, F_0 = F_E + GE::NFRAG * 64, F_0T = F_0 + G0::NFRAG * 64, F_1 = F_0T + G0T::NFRAG * 64,
                        F_1T = F_1 + G1::NFRAG * 64, F_SIZE = F_1T + G1T::NFRAG * 64;
   static constexpr int ROWS = TILE * CINP;       // per wave: agg rows, then dh rows
-  static constexpr int LDS_FLOATS = GQ_TPB + F_SIZE + GQ_WPB * (BLK + ROWS);
+  // Waves per workgroup: as many as one CU's LDS holds (the grid is capped at the 16 CUs the protein
+  // backward leaves free, so waves per CU is what sets the number of tiles a wave has to walk).
+  static constexpr int WPB = (160 * 256 - 64 * 8 - F_SIZE) / (BLK + ROWS) >= 8 ? 8 : (160 * 256 - 64 * 8 - F_SIZE) / (BLK + ROWS);
+  static_assert(WPB >= 1, "one wave's blocks must fit");
+  static constexpr int TPB = WAVE * WPB;
+  static constexpr int LDS_FLOATS = TPB + F_SIZE + WPB * (BLK + ROWS);
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "GINE backward LDS plan exceeds the CU");
 };
 
-template <class G>
+template <class G, int NTHR>
 __device__ __forceinline__ void stage_fragments(float* lds, const float* __restrict__ W) {
-  for (int idx = threadIdx.x; idx < G::NFRAG * 64; idx += GQ_TPB) lds[idx] = G::element(W, idx);
+  for (int idx = threadIdx.x; idx < G::NFRAG * 64; idx += NTHR) lds[idx] = G::element(W, idx);
+}
+
+// rows [16 X, 16 X + 16) of dW1 = dy (x) t
+template <class Q, int X>
+__device__ __forceinline__ void dw1_band(const f4 (&AT)[Q::MO], const f4 (&BT)[Q::MH], float* blk, int lane) {
+  if constexpr (X < Q::MO) {
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f4 a1[1] = {AT[X]};
+    f4 acc[1][Q::MH];
+#pragma unroll
+    for (int y = 0; y < Q::MH; ++y) acc[0][y] = zero;
+    outer_items<1, Q::MH>(a1, BT, acc);
+    flush_slots<AccPriv, Seg<P1, 16 * X, 16>, typename Q::KHid, 1, Q::MH>(blk + Q::L_W1, false, Q::KHid::steps * 4, acc, lane);
+  }
 }
 
 template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
-__global__ __launch_bounds__(GQ_TPB) void gine_quad_bwd_kernel(GineQArgs a) {
+__global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) void gine_quad_bwd_kernel(GineQArgs a) {
   typedef GineQ<CIN, CHID, COUT, NT, NET, ED> Q;
+  constexpr int GQ_WPB = Q::WPB, GQ_TPB = Q::TPB;
   constexpr int KE = Q::KE, XW = Q::XW, CINP = Q::CINP, MI = Q::MI, MH = Q::MH, MO = Q::MO;
   extern __shared__ __attribute__((aligned(16))) float lds[];       // lds[0..GQ_TPB): AccPriv::trash()
   float* frag = lds + GQ_TPB;
@@ -96,11 +115,11 @@ __global__ __launch_bounds__(GQ_TPB) void gine_quad_bwd_kernel(GineQArgs a) {
   float* blocks = frag + Q::F_SIZE;
   float* blk = blocks + w * Q::BLK;                                  // this wave's private gradient block
   float* rows = blocks + GQ_WPB * Q::BLK + w * Q::ROWS;              // [16][CINP]
-  stage_fragments<typename Q::GE>(frag + Q::F_E, a.we);
-  stage_fragments<typename Q::G0>(frag + Q::F_0, a.w0);
-  stage_fragments<typename Q::G0T>(frag + Q::F_0T, a.w0);
-  stage_fragments<typename Q::G1>(frag + Q::F_1, a.w1);
-  stage_fragments<typename Q::G1T>(frag + Q::F_1T, a.w1);
+  stage_fragments<typename Q::GE, GQ_TPB>(frag + Q::F_E, a.we);
+  stage_fragments<typename Q::G0, GQ_TPB>(frag + Q::F_0, a.w0);
+  stage_fragments<typename Q::G0T, GQ_TPB>(frag + Q::F_0T, a.w0);
+  stage_fragments<typename Q::G1, GQ_TPB>(frag + Q::F_1, a.w1);
+  stage_fragments<typename Q::G1T, GQ_TPB>(frag + Q::F_1T, a.w1);
   for (int k = lane0; k < Q::BLK / 4; k += WAVE) reinterpret_cast<f4*>(blk)[k] = f4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
@@ -297,15 +316,14 @@ __global__ __launch_bounds__(GQ_TPB) void gine_quad_bwd_kernel(GineQArgs a) {
       }
       // ---- weight gradients of the two Linear layers
       {
-        f4 AT[MO], BT[MH], acc[MO][MH];
+        f4 AT[MO], BT[MH];
         transpose_slots<Q::KOut::steps>(bdy[0], AT, lane);
         transpose_slots<Q::KHid::steps>(bt[0], BT, lane);
-#pragma unroll
-        for (int x = 0; x < MO; ++x)
-#pragma unroll
-          for (int y = 0; y < MH; ++y) acc[x][y] = zero;
-        outer_items<MO, MH>(AT, BT, acc);
-        flush_slots<AccPriv, typename Q::KOut, typename Q::KHid, MO, MH>(blk + Q::L_W1, false, CHID, acc, lane);
+        // one 16-row band of dW1 at a time: 4 accumulator tiles live instead of MO x MH
+        dw1_band<Q, 0>(AT, BT, blk, lane);
+        dw1_band<Q, 1>(AT, BT, blk, lane);
+        dw1_band<Q, 2>(AT, BT, blk, lane);
+        dw1_band<Q, 3>(AT, BT, blk, lane);
 #pragma unroll
         for (int mt = 0; mt < MO; ++mt) {
           float tot[4];
@@ -437,6 +455,7 @@ __global__ __launch_bounds__(GQ_TPB) void gine_quad_bwd_kernel(GineQArgs a) {
 template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
 int launch(GineQArgs& a, int* rows, int* row_len, hipStream_t st) {
   typedef GineQ<CIN, CHID, COUT, NT, NET, ED> Q;
+  constexpr int GQ_WPB = Q::WPB, GQ_TPB = Q::TPB;
   const int64_t tiles = (a.N + TILE - 1) / TILE;
   int64_t wgs = (tiles + GQ_WPB - 1) / GQ_WPB;
   const int G = (int)(wgs < 1 ? 1 : (wgs > quad::kGineBwdMaxGrid ? quad::kGineBwdMaxGrid : wgs));
