@@ -33,7 +33,8 @@ int node_update(const float* img_node, const float* img_head, const float* h, co
 // the number of rows to reduce.
 int node_update_bwd(const float* img_node, const float* imgT_node, const float* h, const float* dh,
                     const float* mask0, const float* mask1, const float* g_up0, const float* g_up1,
-                    const float* g_up2, int64_t N, float* g_dh, float* g_h, float* slab, int* grid, hipStream_t st);
+                    const float* g_up2, int64_t N, float* g_dh, float* g_h, float* zero_rows, float* slab, int* grid,
+                    hipStream_t st);
 int head_bwd(const float* img_head, const float* imgT_head, const float* h_out, const float* g_out, int64_t N,
              float* g_h_out, float* slab, int* grid, hipStream_t st);
 int conv_bwd(int nt_edge, const float* img, const float* imgT, const float* h, const float* e_s, const float* e_v,

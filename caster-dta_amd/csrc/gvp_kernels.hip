@@ -897,14 +897,15 @@ int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const
                          const float* h, const float* dh, const float* mask0, const float* mask1,
                          const float* h_out, const float* g_out, const float* g_up0, const float* g_up1,
                          const float* g_up2, int64_t N, int32_t with_head, float* g_dh, float* g_h,
-                         float* grad_params, float* workspace, cgvp_segment* segs, int32_t* nsegs, void* stream) {
+                         float* zero_out, float* grad_params, float* workspace, cgvp_segment* segs, int32_t* nsegs,
+                         void* stream) {
   if (int rc = check_dims(dims)) return rc;
   if (N < 0 || !layout || !image || !grad_params || !workspace) return CGVP_ERR_BAD_ARG;
   const int nc = num_convs_of(*layout);
   if (layer < 0 || layer >= nc) return CGVP_ERR_BAD_ARG;
   if (N == 0) return 0;
   if (!h || !dh || !g_dh || (with_head && (!g_out || !h_out))) return CGVP_ERR_BAD_ARG;
-  const void* al[] = {h, dh, mask0, mask1, h_out, g_out, g_up0, g_up1, g_up2, g_dh, g_h};
+  const void* al[] = {h, dh, mask0, mask1, h_out, g_out, g_up0, g_up1, g_up2, g_dh, g_h, zero_out};
   for (const void* q : al) if ((uintptr_t)q & 15) return CGVP_ERR_BAD_ARG;
   QuadOffsets o;
   if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, nc, &o)) return rc;
@@ -918,7 +919,7 @@ int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const
     g_up0 = g_dh; g_up1 = nullptr; g_up2 = nullptr;
   }
   if (int rc = quad::node_update_bwd(image + o.node0 + layer * o.layer_stride, image + o.nodeT0 + layer * o.layerT_stride,
-                                     h, dh, mask0, mask1, g_up0, g_up1, g_up2, N, g_dh, g_h, workspace, &grid, st)) return rc;
+                                     h, dh, mask0, mask1, g_up0, g_up1, g_up2, N, g_dh, g_h, zero_out, workspace, &grid, st)) return rc;
   const int node_len = conv_ff1() + LFf1::size(0) - conv_ln0();          // norm.0 .. end of ff_func.1
   cgvp_segment sg[2] = {{workspace, grid, nd, 0, node_len, layout->conv0 + layer * layout->conv_stride + conv_ln0()},
                         {head_slab, hgrid, hd, 0, layout->total - layout->ln_out, layout->ln_out}};
@@ -931,8 +932,9 @@ int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const
 int cgvp_conv_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image, int32_t layer,
                   const float* h, const float* e_s, const float* e_v, const int64_t* etypes,
                   const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc, const int32_t* edst,
-                  int64_t N, int64_t E, int32_t aggr_mean, const float* g_dh, float* g_src, float* g_dst,
-                  float* grad_params, float* workspace, cgvp_segment* segs, int32_t* nsegs, void* stream) {
+                  int64_t N, int64_t E, int32_t aggr_mean, const float* g_dh, float* g_src, int32_t g_src_zeroed,
+                  float* g_dst, float* grad_params, float* workspace, cgvp_segment* segs, int32_t* nsegs,
+                  void* stream) {
   if (int rc = check_dims(dims)) return rc;
   if (N < 0 || E < 0 || !layout || !image || !grad_params || !workspace) return CGVP_ERR_BAD_ARG;
   const int nc = num_convs_of(*layout);
@@ -947,8 +949,10 @@ int cgvp_conv_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float*
   int emb, ce, ct, nd, hd, grid = 0;
   if (int rc = quad::bwd_block_sizes(layout->nt_node, layout->nt_edge, &emb, &ce, &ct, &nd, &hd)) return rc;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t err = hipMemsetAsync(g_src, 0, (size_t)N * ROW * sizeof(float), st);
-  if (err != hipSuccess) return (int)err;
+  if (!g_src_zeroed) {
+    hipError_t err = hipMemsetAsync(g_src, 0, (size_t)N * ROW * sizeof(float), st);
+    if (err != hipSuccess) return (int)err;
+  }
   if (int rc = quad::conv_bwd(layout->nt_edge, image + o.conv0 + layer * o.layer_stride,
                               image + o.convT0 + layer * o.layerT_stride, h, e_s, e_v, etypes, rowptr, eperm, esrc,
                               edst, N, E, aggr_mean ? 1 : 0, g_dh, g_src, g_dst, workspace, &grid, st)) return rc;

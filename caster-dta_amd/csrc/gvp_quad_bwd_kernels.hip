@@ -131,7 +131,7 @@ struct NodeBArgs {
   const float* img_node; const float* imgT_node;
   const float* h; const float* dh; const float* mask0; const float* mask1;
   const float* g_up0; const float* g_up1; const float* g_up2;
-  int64_t N; float* g_dh; float* g_h; float* slab;
+  int64_t N; float* g_dh; float* g_h; float* zero_rows; float* slab;
 };
 constexpr int node_bwd_lds_floats() { return BW_TPB + Image<0, 0>::ND_SIZE + Image<0, 0>::TN_SIZE + BW_WPB * NODE_GB; }
 static_assert(node_bwd_lds_floats() * 4 <= 160 * 1024, "node backward LDS plan exceeds the CU");
@@ -262,6 +262,12 @@ __global__ __launch_bounds__(BW_TPB, 2) void node_bwd_kernel(NodeBArgs a) {
       *reinterpret_cast<f4*>(row + 4 * g) = gs[0] * m0s;
 #pragma unroll
       for (int p = 0; p < 3; ++p) row[NS + 3 * g + p] = gv[p][0] * m0v;
+      if (a.zero_rows) {          // the atomics target of the conv backward that follows: saves its memset launch
+        float* z = a.zero_rows + n * ROW;
+        *reinterpret_cast<f4*>(z + 4 * g) = zero;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) z[NS + 3 * g + p] = 0.f;
+      }
     }
   }
   STAMP(9);
@@ -762,8 +768,9 @@ int reduce_slab(const float* slab, int rows, int stride, int col0, int len, floa
 
 int node_update_bwd(const float* img_node, const float* imgT_node, const float* h, const float* dh,
                     const float* mask0, const float* mask1, const float* g_up0, const float* g_up1,
-                    const float* g_up2, int64_t N, float* g_dh, float* g_h, float* slab, int* grid, hipStream_t st) {
-  NodeBArgs a{img_node, imgT_node, h, dh, mask0, mask1, g_up0, g_up1, g_up2, N, g_dh, g_h, slab};
+                    const float* g_up2, int64_t N, float* g_dh, float* g_h, float* zero_rows, float* slab, int* grid,
+                    hipStream_t st) {
+  NodeBArgs a{img_node, imgT_node, h, dh, mask0, mask1, g_up0, g_up1, g_up2, N, g_dh, g_h, zero_rows, slab};
   const int G = grid_for((N + TILE - 1) / TILE);
   *grid = G;
   const size_t lds = (size_t)node_bwd_lds_floats() * sizeof(float);

@@ -63,9 +63,9 @@ _SIGNATURES = {
                                              _I32, _P, _P, _P]),
     "cgvp_bwd_workspace_floats": (C.c_int64, [C.POINTER(Dims), C.POINTER(Layout)]),
     "cgvp_node_update_bwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                       _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
+                                       _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cgvp_conv_bwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64,
-                                _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                _I64, _I32, _P, _P, _I32, _P, _P, _P, _P, _P, _P]),
     "cgvp_node_embed_bwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P,
                                       _P, _P, _P, _P, _P]),
     "cgvp_bwd_reduce": (C.c_int, [_P, _I32, _P, _P]),

@@ -104,20 +104,20 @@ class _LbaEncoderFn(torch.autograd.Function):
                 last = l == nc - 1
                 g_dh = torch.empty(N, ROW, **f32)
                 g_h = torch.empty(N, ROW, **f32) if masks[l][0] is not None else None
+                g_src = torch.empty(N, ROW, **f32)       # zeroed by the node stage, filled by the conv stage's atomics
                 _lib.check(L.cgvp_node_update_bwd(d, lay, I, l, _ptr(hs[l]), _ptr(dhs[l]), _ptr(masks[l][0]),
                                                   _ptr(masks[l][1]), _ptr(h_last if last else None),
                                                   _ptr(g_out if last else None), _ptr(ups[0]),
                                                   _ptr(ups[1]), _ptr(ups[2]), N, 1 if last else 0, _ptr(g_dh),
-                                                  _ptr(g_h), _ptr(gparams), _ptr(region()),
+                                                  _ptr(g_h), _ptr(g_src), _ptr(gparams), _ptr(region()),
                                                   C.byref(segs, nseg * C.sizeof(_lib.Segment)), C.byref(cnt), st),
                            "cgvp_node_update_bwd")
                 take()
-                g_src = torch.empty(N, ROW, **f32)
                 g_dst = torch.empty(N, ROW, **f32)
                 with ops._timed("conv_bwd"):
                     _lib.check(L.cgvp_conv_bwd(d, lay, I, l, _ptr(hs[l]), _ptr(e_s), _ptr(e_v), _ptr(et),
                                                _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst), N, E,
-                                               1 if m["mean"] else 0, _ptr(g_dh), _ptr(g_src), _ptr(g_dst),
+                                               1 if m["mean"] else 0, _ptr(g_dh), _ptr(g_src), 1, _ptr(g_dst),
                                                _ptr(gparams), _ptr(region()),
                                                C.byref(segs, nseg * C.sizeof(_lib.Segment)), C.byref(cnt), st),
                                "cgvp_conv_bwd")

@@ -180,26 +180,30 @@ int cgvp_bwd_reduce(const cgvp_segment* segs, int32_t nsegs, float* grad_params,
  * otherwise the SUM of up to three [N][28] buffers g_up0..2 (NULL entries
  * skipped; h_out / g_out ignored).  Writes g_dh [N][28] (= mask0 * d h) and, when
  * g_h != NULL, g_h [N][28] (the residual path; equals g_dh without dropout).
- * With the head this is two launches (head, then the layer). */
+ * With the head this is two launches (head, then the layer).  `zero_out` (optional,
+ * [N][28]) is filled with zeros on the way: pass the g_src of the cgvp_conv_bwd call
+ * that follows and set its g_src_zeroed to save that call's memset launch. */
 int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image,
                          int32_t layer, const float* h, const float* dh, const float* mask0,
                          const float* mask1, const float* h_out, const float* g_out,
                          const float* g_up0, const float* g_up1, const float* g_up2,
                          int64_t num_nodes, int32_t with_head, float* g_dh, float* g_h,
-                         float* grad_params, float* workspace, cgvp_segment* segs, int32_t* nsegs,
-                         void* stream);
+                         float* zero_out, float* grad_params, float* workspace, cgvp_segment* segs,
+                         int32_t* nsegs, void* stream);
 
 /* d/d(h, weights) of cgvp_conv_fwd given g_dh = d(loss)/d(dh).  Gradients w.r.t.
  * the node rows arrive in two buffers that the consumer sums: g_src [N][28]
- * (scatter over the unsorted sources; float atomics; zeroed by this call) and
+ * (scatter over the unsorted sources; float atomics; zeroed by this call unless
+ * g_src_zeroed != 0) and
  * g_dst [N][28] (segmented sums over the sorted targets; every row written).
  * Raw edge features receive no gradient. */
 int cgvp_conv_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image, int32_t layer,
                   const float* h, const float* e_s, const float* e_v, const int64_t* etypes,
                   const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
                   const int32_t* edst, int64_t num_nodes, int64_t num_edges, int32_t aggr_mean,
-                  const float* g_dh, float* g_src, float* g_dst, float* grad_params,
-                  float* workspace, cgvp_segment* segs, int32_t* nsegs, void* stream);
+                  const float* g_dh, float* g_src, int32_t g_src_zeroed, float* g_dst,
+                  float* grad_params, float* workspace, cgvp_segment* segs, int32_t* nsegs,
+                  void* stream);
 
 /* d/d(x_s, x_v, weights) of cgvp_node_embed_fwd; upstream = sum of g_up0..2.
  * g_x_s [N][17] / g_x_v [N][3][3] may both be NULL (inputs without gradient). */

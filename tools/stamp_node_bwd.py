@@ -30,7 +30,7 @@ for head in (0, 1):
     h.cgvp_debug_set_stamp_buffer_bwd(ctypes.c_void_p(buf.data_ptr()))
     for _ in range(3):
         rc = L.cgvp_node_update_bwd(C.byref(dims), C.byref(layout), P(image), 1 if head else 0, P(hh), P(dh), P(None), P(None),
-                                    P(hh if head else None), P(gout if head else None), P(None if head else g), P(None), P(None), N, head, P(gdh), P(None),
+                                    P(hh if head else None), P(gout if head else None), P(None if head else g), P(None), P(None), N, head, P(gdh), P(None), P(None),
                                     P(gp), P(ws), P(None), P(None), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0, rc
     torch.cuda.synchronize()
@@ -52,7 +52,7 @@ for head in (0, 1):
     for _ in range(20):
         nsegs.value = 0
         L.cgvp_node_update_bwd(C.byref(dims), C.byref(layout), P(image), 1 if head else 0, P(hh), P(dh), P(None), P(None),
-                               P(hh if head else None), P(gout if head else None), P(None if head else g), P(None), P(None), N, head, P(gdh), P(None),
+                               P(hh if head else None), P(gout if head else None), P(None if head else g), P(None), P(None), N, head, P(gdh), P(None), P(None),
                                P(gp), P(ws), segs, C.byref(nsegs), C.c_void_p(torch.cuda.current_stream().cuda_stream))
     ev1.record(); torch.cuda.synchronize()
     print(f"{'kernel alone (deferred reduce), back to back':32s} {ev0.elapsed_time(ev1)/20*1000:8.1f} us")
