@@ -456,275 +456,10 @@ __global__ __launch_bounds__(WAVE * GINE_APB) void gine_conv_kernel(GineArgs a) 
 }
 
 // ------------------------------------------------------------- GINE backward
-// One wave per target atom (persistent waves loop over atoms), one lane per
-// channel, forward recomputed.  Weight gradients accumulate in REGISTERS (lane o
-// owns row o of nn.lins.1, lane k row k of nn.lins.0, lane c row c of lin) over all
-// the atoms of the wave and are written once, in the layer's state_dict order
-//   eps | nn.lins.0.weight | nn.lins.0.bias | nn.lins.1.weight | nn.lins.1.bias | lin.weight | lin.bias
-// to the wave's slab row (summed by reduce_slab_kernel in a fixed order).
-struct GineBArgs {
-  const float* x; const int64_t* ntypes; const float* eattr; const int64_t* etypes;
-  const int32_t* rowptr; const int32_t* eperm; const int32_t* esrc; int64_t N;
-  const float* eps; const float* we; const float* be; const float* w0; const float* b0;
-  const float* w1; const float* b1; float slope;
-  const float* mask; const float* g_out; float* g_x; float* slab;
-};
-
-template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
-struct GineLay {
-  static constexpr int KE = NET + ED;
-  static constexpr int EPS = 0, W0 = 1, B0 = W0 + CHID * CIN, W1 = B0 + CHID, B1 = W1 + COUT * CHID,
-                       WE = B1 + COUT, BE = WE + CIN * KE, SIZE = BE + CIN;
-  // the same blocks with odd row strides: the layout of a wave's partial in LDS ("lane o writes row o")
-  static constexpr int P_W0 = 1, P_B0 = P_W0 + CHID * (CIN + 1), P_W1 = P_B0 + CHID, P_B1 = P_W1 + COUT * (CHID + 1),
-                       P_WE = P_B1 + COUT, P_BE = P_WE + CIN * (KE + 1), P_SIZE = P_BE + CIN;
-  static __device__ __forceinline__ int padded(int j) {          // state_dict offset -> padded offset
-    if (j < B0) return j < W0 ? j : P_W0 + ((j - W0) / CIN) * (CIN + 1) + (j - W0) % CIN;
-    if (j < W1) return P_B0 + (j - B0);
-    if (j < B1) return P_W1 + ((j - W1) / CHID) * (CHID + 1) + (j - W1) % CHID;
-    if (j < WE) return P_B1 + (j - B1);
-    if (j < BE) return P_WE + ((j - WE) / KE) * (KE + 1) + (j - WE) % KE;
-    return P_BE + (j - BE);
-  }
-};
-
-__device__ __forceinline__ float lane_bcast(float v, int k) {          // value of lane k (k uniform) as a scalar operand
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
-}
-
-template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
-__global__ __launch_bounds__(WAVE * GINE_APB) void gine_bwd_kernel(GineBArgs a) {
-  typedef GineLay<CIN, CHID, COUT, NT, NET, ED> LY;
-  constexpr int KE = NET + ED, XW = CIN - NT, S0 = CIN + 1, S1 = CHID + 1;
-  static_assert(CIN <= WAVE && CHID <= WAVE && COUT <= WAVE, "one lane per channel");
-  // The two MLP matrices go through LDS once per workgroup (odd strides: row-per-lane AND
-  // column-per-lane reads conflict free) into REGISTERS: lane o keeps row o and column o of both.
-  // The mat-vecs then broadcast the activation of lane k with v_readlane: no LDS round trips and
-  // no workgroup barriers inside the atom loop (every wave runs on its own).
-  extern __shared__ float gsm[];                 // prologue: [w0s | w1s]; epilogue: GINE_APB padded partials
-  float* w0s = gsm;
-  float* w1s = gsm + CHID * S0;
-  for (int k = threadIdx.x; k < CHID * CIN; k += WAVE * GINE_APB) w0s[(k / CIN) * S0 + k % CIN] = a.w0[k];
-  for (int k = threadIdx.x; k < COUT * CHID; k += WAVE * GINE_APB) w1s[(k / CHID) * S1 + k % CHID] = a.w1[k];
-  __syncthreads();
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int w = threadIdx.x >> 6;
-  const int wave = blockIdx.x * GINE_APB + w, nwaves = gridDim.x * GINE_APB;
-  float w0r[CIN], w0c[CHID], w1r[CHID], w1c[COUT];
-#pragma unroll
-  for (int c = 0; c < CIN; ++c) w0r[c] = lane < CHID ? w0s[lane * S0 + c] : 0.f;      // row `lane` of nn.lins.0
-#pragma unroll
-  for (int k = 0; k < CHID; ++k) w0c[k] = lane < CIN ? w0s[k * S0 + lane] : 0.f;      // column `lane`
-#pragma unroll
-  for (int k = 0; k < CHID; ++k) w1r[k] = lane < COUT ? w1s[lane * S1 + k] : 0.f;     // row `lane` of nn.lins.1
-#pragma unroll
-  for (int o = 0; o < COUT; ++o) w1c[o] = lane < CHID ? w1s[o * S1 + lane] : 0.f;     // column `lane`
-  const float b0v = lane < CHID ? a.b0[lane] : 0.f, b1v = lane < COUT ? a.b1[lane] : 0.f;
-  float acc_w1[CHID], acc_w0[CIN], acc_wa[ED > 0 ? ED : 1], acc_wt[NET > 0 ? NET : 1];
-  float acc_b1 = 0.f, acc_b0 = 0.f, acc_be = 0.f, acc_eps = 0.f;
-#pragma unroll
-  for (int k = 0; k < CHID; ++k) acc_w1[k] = 0.f;
-#pragma unroll
-  for (int c = 0; c < CIN; ++c) acc_w0[c] = 0.f;
-#pragma unroll
-  for (int k = 0; k < ED; ++k) acc_wa[k] = 0.f;
-#pragma unroll
-  for (int k = 0; k < NET; ++k) acc_wt[k] = 0.f;
-  float wa[ED > 0 ? ED : 1], wt[NET > 0 ? NET : 1];     // this channel's W_e columns: bond features, bond types
-#pragma unroll
-  for (int k = 0; k < ED; ++k) wa[k] = lane < CIN ? a.we[lane * KE + NET + k] : 0.f;
-#pragma unroll
-  for (int k = 0; k < NET; ++k) wt[k] = lane < CIN ? a.we[lane * KE + k] : 0.f;
-  const float bias_e = lane < CIN ? a.be[lane] : 0.f;
-  const float eps1 = 1.0f + a.eps[0];
-  auto xcat = [&](int64_t n) -> float {
-    if (lane < NT) return ((int)a.ntypes[n] == lane) ? 1.f : 0.f;
-    return a.x[n * XW + (lane - NT)];
-  };
-  for (int64_t i = wave; i < a.N; i += nwaves) {
-    const bool valid = true;
-    float xi = 0.f, hval = 0.f;
-    int32_t p0 = 0, p1 = 0;
-    if (valid) { p0 = a.rowptr[i]; p1 = a.rowptr[i + 1]; }
-    p0 = __builtin_amdgcn_readfirstlane(p0);
-    p1 = __builtin_amdgcn_readfirstlane(p1);
-    const int deg = p1 - p0;
-    // Up to 64 incoming edges (every molecule): edge metadata fetched lane-parallel and handed out
-    // by readlane (three dependent hops per ATOM, not per edge); the ReLU pattern of the messages is
-    // kept as a bit mask plus per-lane sums so that the edge half of the backward needs no loads.
-    const bool fast = deg <= WAVE;
-    int32_t m_eid = 0, m_src = 0, m_et = 0;
-    if (fast && lane < deg) {
-      m_eid = a.eperm[p0 + lane];
-      m_src = a.esrc[p0 + lane];
-      if (NET > 0) {
-        m_et = (int)a.etypes[m_eid];
-        m_et = m_et < 0 ? 0 : (m_et >= NET ? NET - 1 : m_et);
-      }
-    }
-    unsigned long long pos = 0ull;               // bit q: message of edge q passed the ReLU (this channel)
-    float cnt = 0.f, s_a[ED > 0 ? ED : 1], s_t[NET > 0 ? NET : 1];
-#pragma unroll
-    for (int k = 0; k < ED; ++k) s_a[k] = 0.f;
-#pragma unroll
-    for (int k = 0; k < NET; ++k) s_t[k] = 0.f;
-    if (valid && lane < CIN) {
-      xi = xcat(i);
-      float agg = 0.f;
-      if (fast) {
-#pragma unroll 4
-        for (int q = 0; q < deg; ++q) {
-          const int32_t eid = __builtin_amdgcn_readlane(m_eid, q);
-          const int32_t j = __builtin_amdgcn_readlane(m_src, q);
-          const int32_t et = __builtin_amdgcn_readlane(m_et, q);
-          float e = bias_e;
-#pragma unroll
-          for (int k = 0; k < NET; ++k) e += (k == et) ? wt[k] : 0.f;
-          const float* ea = a.eattr + (int64_t)eid * ED;
-          float eav[ED > 0 ? ED : 1];
-#pragma unroll
-          for (int k = 0; k < ED; ++k) { eav[k] = ea[k]; e = fmaf(wa[k], eav[k], e); }
-          const float mj = xcat(j) + e;
-          if (mj > 0.f) {
-            agg += mj;
-            pos |= 1ull << q;
-            cnt += 1.f;
-#pragma unroll
-            for (int k = 0; k < ED; ++k) s_a[k] += eav[k];
-#pragma unroll
-            for (int k = 0; k < NET; ++k) s_t[k] += (k == et) ? 1.f : 0.f;
-          }
-        }
-      } else {
-        for (int32_t p = p0; p < p1; ++p) {
-          const int32_t eid = a.eperm[p];
-          float e = bias_e;
-          if (NET > 0) {
-            int et = (int)a.etypes[eid];
-            et = et < 0 ? 0 : (et >= NET ? NET - 1 : et);
-            e += a.we[lane * KE + et];
-          }
-          const float* ea = a.eattr + (int64_t)eid * ED;
-#pragma unroll
-          for (int k = 0; k < ED; ++k) e = fmaf(wa[k], ea[k], e);
-          const float mj = xcat(a.esrc[p]) + e;
-          agg += mj > 0.f ? mj : 0.f;
-        }
-      }
-      hval = fmaf(eps1, xi, agg);
-    }
-    // ---- MLP forward (recomputed) and backward, activations broadcast lane -> scalar
-    float tpre = b0v;
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) tpre = fmaf(w0r[c], lane_bcast(hval, c), tpre);
-    const float tval = tpre > 0.f ? tpre : tpre * a.slope;          // lanes >= CHID: 0
-    float ypre = b1v;
-#pragma unroll
-    for (int k = 0; k < CHID; ++k) ypre = fmaf(w1r[k], lane_bcast(tval, k), ypre);
-    float dy = 0.f;
-    if (lane < COUT) {
-      dy = a.g_out[i * COUT + lane] * (ypre > 0.f ? 1.f : a.slope);
-      if (a.mask) dy *= a.mask[i * COUT + lane];
-    }
-    acc_b1 += dy;
-#pragma unroll
-    for (int k = 0; k < CHID; ++k) acc_w1[k] = fmaf(dy, lane_bcast(tval, k), acc_w1[k]);
-    float dt = 0.f;
-#pragma unroll
-    for (int o = 0; o < COUT; ++o) dt = fmaf(w1c[o], lane_bcast(dy, o), dt);
-    const float dtp = lane < CHID ? dt * (tpre > 0.f ? 1.f : a.slope) : 0.f;
-    acc_b0 += dtp;
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) acc_w0[c] = fmaf(dtp, lane_bcast(hval, c), acc_w0[c]);
-    float dh = 0.f;
-#pragma unroll
-    for (int k = 0; k < CHID; ++k) dh = fmaf(w0c[k], lane_bcast(dtp, k), dh);
-    if (valid && lane < CIN) {
-      acc_eps = fmaf(dh, xi, acc_eps);
-      if (a.g_x && lane >= NT) atomicAdd(a.g_x + i * XW + (lane - NT), eps1 * dh);
-      if (fast) {
-        acc_be = fmaf(dh, cnt, acc_be);
-#pragma unroll
-        for (int k = 0; k < NET; ++k) acc_wt[k] = fmaf(dh, s_t[k], acc_wt[k]);
-#pragma unroll
-        for (int k = 0; k < ED; ++k) acc_wa[k] = fmaf(dh, s_a[k], acc_wa[k]);
-        if (a.g_x && lane >= NT)
-          for (int q = 0; q < deg; ++q) {
-            const int32_t j = __builtin_amdgcn_readlane(m_src, q);
-            if ((pos >> q) & 1ull) atomicAdd(a.g_x + (int64_t)j * XW + (lane - NT), dh);
-          }
-      } else
-      for (int32_t p = p0; p < p1; ++p) {
-        const int32_t eid = a.eperm[p];
-        const int32_t j = a.esrc[p];
-        float e = bias_e;
-        int et = 0;
-        if (NET > 0) {
-          et = (int)a.etypes[eid];
-          et = et < 0 ? 0 : (et >= NET ? NET - 1 : et);
-          e += a.we[lane * KE + et];
-        }
-        const float* ea = a.eattr + (int64_t)eid * ED;
-#pragma unroll
-        for (int k = 0; k < ED; ++k) e = fmaf(wa[k], ea[k], e);
-        const float mj = xcat(j) + e;
-        const float dm = mj > 0.f ? dh : 0.f;
-        acc_be += dm;
-#pragma unroll
-        for (int k = 0; k < NET; ++k) acc_wt[k] += (k == et) ? dm : 0.f;
-#pragma unroll
-        for (int k = 0; k < ED; ++k) acc_wa[k] = fmaf(dm, ea[k], acc_wa[k]);
-        if (a.g_x && lane >= NT) atomicAdd(a.g_x + (int64_t)j * XW + (lane - NT), dm);
-      }
-    }
-  }
-  // ---- the workgroup's waves add up through LDS and write ONE slab row (state_dict order)
-  __syncthreads();                               // everybody is done with w0s / w1s
-  float* row = gsm + w * LY::P_SIZE;
-  float e = acc_eps;
-  for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off);
-  if (lane == 0) row[LY::EPS] = e;
-  if (lane < CHID) {
-    row[LY::P_B0 + lane] = acc_b0;
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) row[LY::P_W0 + lane * (CIN + 1) + c] = acc_w0[c];
-  }
-  if (lane < COUT) {
-    row[LY::P_B1 + lane] = acc_b1;
-#pragma unroll
-    for (int k = 0; k < CHID; ++k) row[LY::P_W1 + lane * (CHID + 1) + k] = acc_w1[k];
-  }
-  if (lane < CIN) {
-    row[LY::P_BE + lane] = acc_be;
-#pragma unroll
-    for (int k = 0; k < NET; ++k) row[LY::P_WE + lane * (KE + 1) + k] = acc_wt[k];
-#pragma unroll
-    for (int k = 0; k < ED; ++k) row[LY::P_WE + lane * (KE + 1) + NET + k] = acc_wa[k];
-  }
-  __syncthreads();
-  float* out = a.slab + (size_t)blockIdx.x * LY::SIZE;
-  for (int j = threadIdx.x; j < LY::SIZE; j += WAVE * GINE_APB) {
-    const int pj = LY::padded(j);
-    float t = 0.f;
-#pragma unroll
-    for (int ww = 0; ww < GINE_APB; ++ww) t += gsm[ww * LY::P_SIZE + pj];
-    out[j] = t;
-  }
-}
-
-constexpr int GINE_BWD_MAX_GRID = 256;          // one workgroup per CU; slab rows = workgroups
-template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
-int gine_bwd_launch(GineBArgs& a, float* grad_layer, hipStream_t st) {
-  typedef GineLay<CIN, CHID, COUT, NT, NET, ED> LY;
-  int64_t wgs = (a.N + GINE_APB - 1) / GINE_APB;
-  const int G = (int)(wgs < 1 ? 1 : (wgs > GINE_BWD_MAX_GRID ? GINE_BWD_MAX_GRID : wgs));
-  constexpr int stage = CHID * (CIN + 1) + COUT * (CHID + 1), red = GINE_APB * LY::P_SIZE;
-  const size_t lds = (size_t)(stage > red ? stage : red) * sizeof(float);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(gine_bwd_kernel<CIN, CHID, COUT, NT, NET, ED>),
-                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((gine_bwd_kernel<CIN, CHID, COUT, NT, NET, ED>), dim3(G), dim3(WAVE * GINE_APB), lds, st, a);
-  quad::reduce_slab(a.slab, G, LY::SIZE, 0, LY::SIZE, grad_layer, st);
-  return 0;
+// Runs on 16-atom MFMA tiles: gine_quad_kernels.hip.  The layer's gradient block is in state_dict
+// order  eps | nn.lins.0.weight | nn.lins.0.bias | nn.lins.1.weight | nn.lins.1.bias | lin.weight | lin.bias.
+constexpr int gine_layer_floats(int cin, int chid, int cout, int ke) {
+  return 1 + chid * cin + chid + cout * chid + cout + cin * ke + cin;
 }
 
 }  // namespace
@@ -1012,7 +747,7 @@ int cgvp_bwd_reduce(const cgvp_segment* segs, int32_t nsegs, float* grad_params,
   return launch_status();
 }
 
-int64_t cgvp_gine_bwd_workspace_floats(void) { return (int64_t)quad::kGineBwdMaxGrid * GineLay<16, 64, 64, 0, 5, 9>::SIZE; }
+int64_t cgvp_gine_bwd_workspace_floats(void) { return (int64_t)quad::kGineBwdMaxGrid * gine_layer_floats(16, 64, 64, 14); }
 
 int cgvp_gine_conv_bwd(const float* x, const int64_t* ntypes, int32_t num_ntypes, const float* eattr,
                        const int64_t* etypes, int32_t num_etypes, int32_t edge_dim, const int32_t* rowptr,
