@@ -171,7 +171,7 @@ def main():
             avg = sum(times) / len(times)
             peak = 8000.0
             kname = {"conv_fwd": "conv_quad_kernel" if ops.VARIANT == "mfma" else "conv_fwd_kernel",
-                     "conv_bwd": "conv_bwd_kernel (+ the g_src memset of the same call)"}[name]
+                     "conv_bwd": "conv_bwd_kernel"}[name]
             # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
             # separate runs, gfx950 correction applied; profiles/r01/pmc_traffic.json) -- same workload only
             traffic = None
