@@ -78,10 +78,15 @@ struct GineQ {
   static constexpr int ROWS = TILE * CINP;       // per wave: agg rows, then dh rows
   // Waves per workgroup: as many as one CU's LDS holds (the grid is capped at the 16 CUs the protein
   // backward leaves free, so waves per CU is what sets the number of tiles a wave has to walk).
-  static constexpr int WPB = (160 * 256 - 64 * 8 - F_SIZE) / (BLK + ROWS) >= 8 ? 8 : (160 * 256 - 64 * 8 - F_SIZE) / (BLK + ROWS);
+  static constexpr int AVAIL = 160 * 256 - 64 * 8 - F_SIZE;
+  static constexpr int wpb(int per_wave) { return AVAIL / per_wave >= 8 ? 8 : AVAIL / per_wave; }
+  static constexpr int WPB = wpb(BLK + ROWS);
   static_assert(WPB >= 1, "one wave's blocks must fit");
+  // operand transposes through an LDS scratch (gvp_quad.h) when that costs no wave, else on the matrix cores
+  static constexpr bool LDS_T = wpb(BLK + ROWS + TSCR_FLOATS) == WPB;
+  static constexpr int PER_WAVE = BLK + ROWS + (LDS_T ? TSCR_FLOATS : 0);
   static constexpr int TPB = WAVE * WPB;
-  static constexpr int LDS_FLOATS = TPB + F_SIZE + WPB * (BLK + ROWS);
+  static constexpr int LDS_FLOATS = TPB + F_SIZE + WPB * PER_WAVE;
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "GINE backward LDS plan exceeds the CU");
 };
 
@@ -115,6 +120,7 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
   float* blocks = frag + Q::F_SIZE;
   float* blk = blocks + w * Q::BLK;                                  // this wave's private gradient block
   float* rows = blocks + GQ_WPB * Q::BLK + w * Q::ROWS;              // [16][CINP]
+  float* const tscr = Q::LDS_T ? blocks + GQ_WPB * (Q::BLK + Q::ROWS) + w * TSCR_FLOATS : nullptr;
   stage_fragments<typename Q::GE, GQ_TPB>(frag + Q::F_E, a.we);
   stage_fragments<typename Q::G0, GQ_TPB>(frag + Q::F_0, a.w0);
   stage_fragments<typename Q::G0T, GQ_TPB>(frag + Q::F_0T, a.w0);
@@ -317,8 +323,8 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
       // ---- weight gradients of the two Linear layers
       {
         f4 AT[MO], BT[MH];
-        transpose_slots<Q::KOut::steps>(bdy[0], AT, lane);
-        transpose_slots<Q::KHid::steps>(bt[0], BT, lane);
+        transpose_slots<Q::KOut::steps>(bdy[0], AT, lane, tscr);
+        transpose_slots<Q::KHid::steps>(bt[0], BT, lane, tscr);
         // one 16-row band of dW1 at a time: 4 accumulator tiles live instead of MO x MH
         dw1_band<Q, 0>(AT, BT, blk, lane);
         dw1_band<Q, 1>(AT, BT, blk, lane);
@@ -340,8 +346,8 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
       }
       {
         f4 AT[MH], BT[MI], acc[MH][MI];
-        transpose_slots<Q::KHid::steps>(bdt[0], AT, lane);
-        transpose_slots<Q::KIn::steps>(bh[0], BT, lane);
+        transpose_slots<Q::KHid::steps>(bdt[0], AT, lane, tscr);
+        transpose_slots<Q::KIn::steps>(bh[0], BT, lane, tscr);
 #pragma unroll
         for (int x = 0; x < MH; ++x)
 #pragma unroll
@@ -412,8 +418,8 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
           }
         }
         f4 AT[MI], BT[1], acc[MI][1];
-        transpose_slots<Q::KIn::steps>(dms, AT, lane);
-        transpose_slots<4>(c_fs[t][0], BT, lane);
+        transpose_slots<Q::KIn::steps>(dms, AT, lane, tscr);
+        transpose_slots<4>(c_fs[t][0], BT, lane, tscr);
 #pragma unroll
         for (int x = 0; x < MI; ++x) acc[x][0] = zero;
         outer_items<MI, 1>(AT, BT, acc);

@@ -189,8 +189,23 @@ __device__ __forceinline__ float row_total(float x) {
 // to nn.Linear rows / columns by the segment maps when the tile is flushed.
 __device__ __forceinline__ float sel_val(int lane, int r) { return ((lane & 15) == 4 * r + (lane >> 4)) ? 1.f : 0.f; }
 
+// With a per-wave LDS scratch of TSCR_FLOATS floats (`tscr`), the same transposition is four
+// ds_write_b32 + one ds_read_b128 per 16 slots instead of four MFMAs: it takes the operand
+// transposes (~30 % of the conv backward's MFMAs) off the matrix-core pipe that two waves share.
+constexpr int TSCR_LD = 20, TSCR_FLOATS = 16 * TSCR_LD;     // [slot n][item], rows padded to 80 B
 template <int NSTEPS>
-__device__ __forceinline__ void transpose_slots(const float (&v)[NSTEPS], f4 (&out)[ceil4(NSTEPS)], int lane) {
+__device__ __forceinline__ void transpose_slots(const float (&v)[NSTEPS], f4 (&out)[ceil4(NSTEPS)], int lane,
+                                                float* tscr = nullptr) {
+  if (tscr) {
+    const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int T = 0; T < ceil4(NSTEPS); ++T) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tscr[(4 * r + g) * TSCR_LD + i] = (4 * T + r < NSTEPS) ? v[4 * T + r] : 0.f;
+      out[T] = *reinterpret_cast<const f4*>(tscr + i * TSCR_LD + 4 * g);     // lane (n = i, g') <- slot n, items 4g'..4g'+3
+    }
+    return;
+  }
   const float sel[4] = {sel_val(lane, 0), sel_val(lane, 1), sel_val(lane, 2), sel_val(lane, 3)};
 #pragma unroll
   for (int T = 0; T < ceil4(NSTEPS); ++T) {
@@ -547,7 +562,7 @@ struct GvpQ {
   template <class Acc>
   static __device__ __forceinline__ void weight_grads(float* gblk, bool first, int lane, int type, bool active,
                                                       const float (&bs)[SSTEPS], const float (&bv)[3][VSTEPS],
-                                                      const Cache& c, const Grads& gr) {
+                                                      const Cache& c, const Grads& gr, float* tscr = nullptr) {
     const int i = lane & 15, g = lane >> 4;
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
     // ---- dWs = dsp (x) [onehot | s | vn],  dbs = sum dsp
@@ -558,7 +573,7 @@ struct GvpQ {
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[4 * t + r] = active ? gr.dsp[t][r] : 0.f;
       f4 AT[OT];
-      transpose_slots<4 * OT>(a, AT, lane);
+      transpose_slots<4 * OT>(a, AT, lane, tscr);
       constexpr int NB = (NT > 0 ? NTS : 1) + SSTEPS + HR;
       float b[NB];
 #pragma unroll
@@ -568,7 +583,7 @@ struct GvpQ {
 #pragma unroll
       for (int r = 0; r < HR; ++r) b[(NT > 0 ? NTS : 1) + SSTEPS + r] = c.vn[r];
       f4 BT[ceil4(NB)];
-      transpose_slots<NB>(b, BT, lane);
+      transpose_slots<NB>(b, BT, lane, tscr);
       f4 acc[OT][ceil4(NB)];
 #pragma unroll
       for (int x = 0; x < OT; ++x)
@@ -600,8 +615,8 @@ struct GvpQ {
 #pragma unroll
         for (int r = 0; r < 4; ++r) b[4 * t + r] = c.sp[t][r];
       f4 AT[1], BT[OT], acc[1][OT];
-      transpose_slots<VOR>(a, AT, lane);
-      transpose_slots<4 * OT>(b, BT, lane);
+      transpose_slots<VOR>(a, AT, lane, tscr);
+      transpose_slots<4 * OT>(b, BT, lane, tscr);
 #pragma unroll
       for (int y = 0; y < OT; ++y) acc[0][y] = zero;
       outer_items<1, OT>(AT, BT, acc);
@@ -628,8 +643,8 @@ struct GvpQ {
 #pragma unroll
         for (int r = 0; r < HR; ++r) bh[r] = c.vh[p][r];
         f4 AV[1], BH[1];
-        transpose_slots<VOR>(av, AV, lane);
-        transpose_slots<HR>(bh, BH, lane);
+        transpose_slots<VOR>(av, AV, lane, tscr);
+        transpose_slots<HR>(bh, BH, lane, tscr);
         outer_items<1, 1>(AV, BH, accv);
       }
       flush_slots<Acc, Segs<Seg<P2, 0, (VO > 0 ? VO : 1)>>, Segs<Seg<P2, 0, H>>, 1, 1>(gblk + A::wv(NT), first, H, accv, lane);
@@ -646,8 +661,8 @@ struct GvpQ {
         for (int s = 0; s < VSTEPS; ++s) bin[s] = bv[p][s];
         f4 AH[1], BI[1];
         static_assert(VSTEPS <= 4 && HR <= 4, "vector operands fit one slot tile");
-        transpose_slots<HR>(ah, AH, lane);
-        transpose_slots<VSTEPS>(bin, BI, lane);
+        transpose_slots<HR>(ah, AH, lane, tscr);
+        transpose_slots<VSTEPS>(bin, BI, lane, tscr);
         outer_items<1, 1>(AH, BI, acch);
       }
       flush_slots<Acc, Segs<Seg<P2, 0, H>>, VSegs, 1, 1>(gblk, first, VI, acch, lane);

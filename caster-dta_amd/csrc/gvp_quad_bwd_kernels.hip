@@ -133,7 +133,7 @@ struct NodeBArgs {
   const float* g_up0; const float* g_up1; const float* g_up2;
   int64_t N; float* g_dh; float* g_h; float* zero_rows; float* slab;
 };
-constexpr int node_bwd_lds_floats() { return BW_TPB + Image<0, 0>::ND_SIZE + Image<0, 0>::TN_SIZE + BW_WPB * NODE_GB; }
+constexpr int node_bwd_lds_floats() { return BW_TPB + Image<0, 0>::ND_SIZE + Image<0, 0>::TN_SIZE + BW_WPB * (NODE_GB + TSCR_FLOATS); }
 static_assert(node_bwd_lds_floats() * 4 <= 160 * 1024, "node backward LDS plan exceeds the CU");
 
 // g_up0 may alias g_dh (the head backward leaves d h_out there): a tile's rows are read
@@ -146,6 +146,7 @@ __global__ __launch_bounds__(BW_TPB, 2) void node_bwd_kernel(NodeBArgs a) {
   float* blocks = t_node + IM::TN_SIZE;
   const int lane0 = threadIdx.x & 63, w = threadIdx.x >> 6;
   float* gblk = blocks + w * NODE_GB;                               // this wave's private gradient block
+  float* tscr = blocks + BW_WPB * NODE_GB + w * TSCR_FLOATS;        // operand-transpose scratch
   stage_slice<IM::ND_SIZE, BW_TPB>(f_node, a.img_node, threadIdx.x);
   stage_slice<IM::TN_SIZE, BW_TPB>(t_node, a.imgT_node, threadIdx.x);
   zero_block<NODE_GB>(gblk, lane0);
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(BW_TPB, 2) void node_bwd_kernel(NodeBArgs a) {
       STAMP(4);
       QFf1::backward(t_node + IM::TN_FF1, lane, c1[0], d_so, d_vo, d_hs, d_hv, gr1);
       STAMP(5);
-      QFf1::weight_grads<AccPriv>(gblk + NB_FF1, first, lane, 0, active, bs1[0], bv1[0], c1[0], gr1);
+      QFf1::weight_grads<AccPriv>(gblk + NB_FF1, first, lane, 0, active, bs1[0], bv1[0], c1[0], gr1, tscr);
     }
     {
       f4 d_so[4];
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(BW_TPB, 2) void node_bwd_kernel(NodeBArgs a) {
       STAMP(6);
       QFf0::backward(t_node + IM::TN_FF0, lane, c0[0], d_so, d_hv, d_ys, d_yv, gr0);
       STAMP(7);
-      QFf0::weight_grads<AccPriv>(gblk + NB_FF0, first, lane, 0, active, bs0[0], bv0[0], c0[0], gr0);
+      QFf0::weight_grads<AccPriv>(gblk + NB_FF0, first, lane, 0, active, bs0[0], bv0[0], c0[0], gr0, tscr);
 #pragma unroll
       for (int r = 0; r < 4; ++r) gs[0][r] += d_ys[r];
 #pragma unroll
@@ -282,7 +283,7 @@ struct HeadBArgs {
   const float* img_head; const float* imgT_head; const float* h_out; const float* g_out;
   int64_t N; float* g_h_out; float* slab;
 };
-constexpr int head_bwd_lds_floats() { return BW_TPB + Image<0, 0>::HD_SIZE + Image<0, 0>::TH_SIZE + BW_WPB * HEAD_GB; }
+constexpr int head_bwd_lds_floats() { return BW_TPB + Image<0, 0>::HD_SIZE + Image<0, 0>::TH_SIZE + BW_WPB * (HEAD_GB + TSCR_FLOATS); }
 
 __global__ __launch_bounds__(BW_TPB, 2) void head_bwd_kernel(HeadBArgs a) {
   typedef Image<0, 0> IM;
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(BW_TPB, 2) void head_bwd_kernel(HeadBArgs a) {
   float* blocks = t_head + IM::TH_SIZE;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float* gblk = blocks + w * HEAD_GB;
+  float* tscr = blocks + BW_WPB * HEAD_GB + w * TSCR_FLOATS;
   stage_slice<IM::HD_SIZE, BW_TPB>(f_head, a.img_head, threadIdx.x);
   stage_slice<IM::TH_SIZE, BW_TPB>(t_head, a.imgT_head, threadIdx.x);
   zero_block<HEAD_GB>(gblk, lane);
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(BW_TPB, 2) void head_bwd_kernel(HeadBArgs a) {
     float d_vo[3][1] = {{0.f}, {0.f}, {0.f}}, d_bs[4], d_bv[3][1];
     QHead::Grads grh;
     QHead::backward(t_head, lane, ch[0], d_o, d_vo, d_bs, d_bv, grh);
-    QHead::weight_grads<AccPriv>(gblk + HB_GVP, first, lane, 0, active, bsh[0], bvh[0], ch[0], grh);
+    QHead::weight_grads<AccPriv>(gblk + HB_GVP, first, lane, 0, active, bsh[0], bvh[0], ch[0], grh, tscr);
     f4 dws[1] = {f4{d_bs[0], d_bs[1], d_bs[2], d_bs[3]}};
     float dwv[3][1] = {{d_bv[0][0]}, {d_bv[1][0]}, {d_bv[2][0]}};
     f4 dga[1], dbe[1];
@@ -357,7 +359,8 @@ struct ConvBlk {
 // One workgroup of 8 waves per CU (2 per SIMD) owning all 160 KB of LDS:
 //   [forward slices | transposed slices | per wave: private gradient block, g_src scratch]
 constexpr int CB_WPB = BW_WPB, CB_TPB = BW_TPB, CB_MAX_GRID = BW_MAX_GRID;
-constexpr int CB_SCR = (TILE / 2) * ROW + TILE;      // half a tile of [28]-rows + 16 source ids (g_src transpose)
+constexpr int CB_SCR = TSCR_FLOATS;                  // per wave: operand-transpose scratch; also half a tile of [28]-rows + 16 ids (g_src)
+static_assert(CB_SCR >= (TILE / 2) * ROW + TILE, "g_src transpose fits the scratch");
 template <int NTE>
 constexpr int conv_bwd_lds_floats() { return BW_TPB + Image<0, NTE>::CV_SIZE + Image<0, NTE>::TC_SIZE + CB_WPB * (ConvBlk<NTE>::SIZE + CB_SCR); }
 static_assert(conv_bwd_lds_floats<1>() * 4 <= 160 * 1024 && conv_bwd_lds_floats<0>() * 4 <= 160 * 1024, "conv backward LDS plan exceeds the CU");
@@ -381,6 +384,11 @@ __global__ __launch_bounds__(CB_TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
   float* blocks = imgT + IM::TC_SIZE;
   float* gblk = blocks + w * PW;                                      // this wave's private gradient block (AccPriv)
   float* scr = gblk + B::SIZE;
+#ifdef CGVP_MFMA_TRANSPOSE
+  float* const CB_TSCR = nullptr;
+#else
+  float* const CB_TSCR = scr;
+#endif
   stage_slice<IM::CV_SIZE, CB_TPB>(img, a.img, threadIdx.x);
   stage_slice<IM::TC_SIZE, CB_TPB>(imgT, a.imgT, threadIdx.x);
   for (int k = lane0; k < B::SIZE / 4; k += WAVE) reinterpret_cast<f4*>(gblk)[k] = f4{0.f, 0.f, 0.f, 0.f};
@@ -489,7 +497,7 @@ __global__ __launch_bounds__(CB_TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
         QMsg2::Grads gr;
         QMsg2::backward(imgT + IM::TC_M2, lane, c2[0], d_so, d_vo, d_b, d_bv, gr);
         STAMP(10);
-        QMsg2::weight_grads<AccPriv>(gblk + B::M2, first, lane, 0, active, b2[0], bv2[0], c2[0], gr);
+        QMsg2::weight_grads<AccPriv>(gblk + B::M2, first, lane, 0, active, b2[0], bv2[0], c2[0], gr, CB_TSCR);
       }
       {
         f4 d_so[1] = {f4{d_b[0], d_b[1], d_b[2], d_b[3]}};
@@ -498,7 +506,7 @@ __global__ __launch_bounds__(CB_TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
         STAMP(11);
         QMsg1::backward(imgT + IM::TC_M1, lane, c1[0], d_so, d_vo, d_b, d_bv, gr);
         STAMP(12);
-        QMsg1::weight_grads<AccPriv>(gblk + B::M1, first, lane, 0, active, b1[0], bv1[0], c1[0], gr);
+        QMsg1::weight_grads<AccPriv>(gblk + B::M1, first, lane, 0, active, b1[0], bv1[0], c1[0], gr, CB_TSCR);
       }
       float d_b0[16], d_bv0[3][3];
       {
@@ -508,7 +516,7 @@ __global__ __launch_bounds__(CB_TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
         STAMP(13);
         QMsg0::backward(imgT + IM::TC_M0, lane, c0[0], d_so, d_vo, d_b0, d_bv0, gr);
         STAMP(14);
-        QMsg0::weight_grads<AccPriv>(gblk + B::M0, first, lane, 0, active, b0[0], bv0[0], c0[0], gr);
+        QMsg0::weight_grads<AccPriv>(gblk + B::M0, first, lane, 0, active, b0[0], bv0[0], c0[0], gr, CB_TSCR);
       }
       STAMP(4);
       // ---- edge embedding: LayerNorm and GVP (weight gradients only; raw edge features get none)
@@ -521,7 +529,7 @@ __global__ __launch_bounds__(CB_TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
         float d_in[8], d_inv[3][1];
         typename QEdge<NTE>::Grads gr;
         QEdge<NTE>::backward(imgT + IM::TC_EDGE, lane, ce[0], d_es, d_ev, d_in, d_inv, gr);
-        QEdge<NTE>::template weight_grads<AccPriv>(gblk + B::E_GVP, first, lane, et[0], active, bse[0], bve[0], ce[0], gr);
+        QEdge<NTE>::template weight_grads<AccPriv>(gblk + B::E_GVP, first, lane, et[0], active, bse[0], bve[0], ce[0], gr, CB_TSCR);
       }
       STAMP(5);
       // ---- d h[src]: unsorted sources -> float atomics on the zero-initialised g_src.  The rows
@@ -599,7 +607,7 @@ struct EmbBArgs {
 };
 
 template <int NTN>
-constexpr int embed_bwd_lds_floats() { return BW_TPB + Image<NTN, 0>::EMB_SIZE + Image<NTN, 0>::TE_SIZE + BW_WPB * EmbBlk<NTN>::SIZE; }
+constexpr int embed_bwd_lds_floats() { return BW_TPB + Image<NTN, 0>::EMB_SIZE + Image<NTN, 0>::TE_SIZE + BW_WPB * (EmbBlk<NTN>::SIZE + TSCR_FLOATS); }
 
 template <int NTN>
 __global__ __launch_bounds__(BW_TPB, 2) void embed_bwd_kernel(EmbBArgs a) {
@@ -612,6 +620,7 @@ __global__ __launch_bounds__(BW_TPB, 2) void embed_bwd_kernel(EmbBArgs a) {
   float* blocks = imgT + IM::TE_SIZE;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float* gblk = blocks + w * B::SIZE;                               // this wave's private gradient block
+  float* tscr = blocks + BW_WPB * B::SIZE + w * TSCR_FLOATS;
   stage_slice<IM::EMB_SIZE, BW_TPB>(img, a.img, threadIdx.x);
   stage_slice<IM::TE_SIZE, BW_TPB>(imgT, a.imgT, threadIdx.x);
   zero_block<B::SIZE>(gblk, lane);
@@ -659,7 +668,7 @@ __global__ __launch_bounds__(BW_TPB, 2) void embed_bwd_kernel(EmbBArgs a) {
     float d_bs[Q::SSTEPS], d_bv[3][1];
     typename Q::Grads gr;
     Q::backward(imgT, lane, c[0], gs, gv, d_bs, d_bv, gr);
-    Q::template weight_grads<AccPriv>(gblk + B::GVP, first, lane, type[0], active, bs[0], bv[0], c[0], gr);
+    Q::template weight_grads<AccPriv>(gblk + B::GVP, first, lane, type[0], active, bs[0], bv[0], c[0], gr, tscr);
     if (active && a.g_x_s) {
 #pragma unroll
       for (int s = 0; s < Q::SSTEPS; ++s) {
