@@ -90,9 +90,27 @@ struct GineQ {
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "GINE backward LDS plan exceeds the CU");
 };
 
+// Fragment image of one weight matrix, built while staging: eight independent (unconditional) loads in
+// flight per thread -- an element-at-a-time loop with a load under a branch costs one memory round
+// trip per element (~20 us per launch for the 64x64 layer).
 template <class G, int NTHR>
 __device__ __forceinline__ void stage_fragments(float* lds, const float* __restrict__ W) {
-  for (int idx = threadIdx.x; idx < G::NFRAG * 64; idx += NTHR) lds[idx] = G::element(W, idx);
+  constexpr int TOTAL = G::NFRAG * 64, B = 8;
+  for (int base = threadIdx.x; base < TOTAL; base += NTHR * B) {
+    int off[B];
+    float v[B];
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+      const int idx = base + k * NTHR;
+      off[k] = idx < TOTAL ? G::offset(idx) : -1;
+      v[k] = W[off[k] >= 0 ? off[k] : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+      const int idx = base + k * NTHR;
+      if (idx < TOTAL) lds[idx] = off[k] >= 0 ? v[k] : 0.f;
+    }
+  }
 }
 
 // rows [16 X, 16 X + 16) of dW1 = dy (x) t

@@ -74,12 +74,16 @@ struct Gemm {
     const int c = 4 * (m & 3) + (m >> 2);
     return c < O ? c : -1;
   }
-  // element `idx` (= frag * 64 + lane) of this GEMM's fragment image
-  static __host__ __device__ float element(const float* W, int idx) {
+  // element `idx` (= frag * 64 + lane) of this GEMM's fragment image: offset into W, or -1 (zero)
+  static __host__ __device__ int offset(int idx) {
     const int lane = idx & 63, f = idx >> 6;
     const int mt = f / NSTEPS, s = f - mt * NSTEPS;
     const int r = row(mt, lane & 15), c = KSegs::col(s, lane >> 4);
-    return (r >= 0 && c >= 0) ? W[r * LD + c] : 0.f;
+    return (r >= 0 && c >= 0) ? r * LD + c : -1;
+  }
+  static __host__ __device__ float element(const float* W, int idx) {
+    const int o = offset(idx);
+    return o >= 0 ? W[o] : 0.f;
   }
 };
 
@@ -92,13 +96,17 @@ struct GemmT {
   static constexpr int MT = ceil4(RowSegs::steps);
   static constexpr int NSTEPS = KSegs::steps;
   static constexpr int NFRAG = MT * NSTEPS;
-  static __host__ __device__ float element(const float* W, int idx) {
+  static __host__ __device__ int offset(int idx) {
     const int lane = idx & 63, f = idx >> 6;
     const int mt = f / NSTEPS, s = f - mt * NSTEPS;
     const int m = lane & 15, slot = 4 * mt + (m & 3);
     const int c_out = slot < RowSegs::steps ? RowSegs::col(slot, m >> 2) : -1;
     const int c_k = KSegs::col(s, lane >> 4);
-    return (c_out >= 0 && c_k >= 0) ? W[c_k * LD + c_out] : 0.f;
+    return (c_out >= 0 && c_k >= 0) ? c_k * LD + c_out : -1;
+  }
+  static __host__ __device__ float element(const float* W, int idx) {
+    const int o = offset(idx);
+    return o >= 0 ? W[o] : 0.f;
   }
 };
 
