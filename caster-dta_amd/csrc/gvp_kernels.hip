@@ -476,7 +476,8 @@ int cgvp_csr_from_coo(const int64_t* edge_index, int64_t N, int64_t E, int32_t* 
     return CGVP_ERR_BAD_ARG;
   if (N >= (int64_t)1 << 31 || E >= (int64_t)1 << 31) return CGVP_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t err = hipMemsetAsync(work, 0, (size_t)(N + 1) * sizeof(int32_t), s);
+  // whole 256-B multiples: the runtime splits any other size into two fill launches (body + tail)
+  hipError_t err = hipMemsetAsync(work, 0, (size_t)((N + 1 + 63) / 64 * 64) * sizeof(int32_t), s);
   if (err != hipSuccess) return (int)err;
   const int B = 256;
   if (E > 0) hipLaunchKernelGGL(csr_count_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, work);

@@ -8,9 +8,9 @@
 //                        the forward (tile mt, register r <-> forward k-slot);
 //   * weight gradients : dW = sum_items dY (x) X as MFMA outer products whose
 //                        operands are transposed through a per-wave LDS scratch;
-//                        each workgroup accumulates one arena-layout block in LDS
-//                        and writes it to its row of a slab that a small reduce
-//                        kernel sums (deterministic, no float atomics on HBM);
+//                        every wave accumulates an arena-layout block of its own in
+//                        LDS (no atomics), the workgroup sums its waves' blocks into
+//                        one slab row, one reduce launch sums the rows in a fixed order;
 //   * d h[dst]         : in-register segmented scan over the sorted edges (owned
 //                        rows, plain stores);  d h[src]: float atomics (the only
 //                        ones in the library; sources are unsorted).

@@ -78,7 +78,7 @@ def build_csr(edge_index, num_nodes):
     dev = ei.device
     i32 = dict(dtype=torch.int32, device=dev)
     rowptr = torch.empty(num_nodes + 1, **i32)
-    work = torch.empty(num_nodes + 1, **i32)
+    work = torch.empty((num_nodes + 1 + 63) // 64 * 64, **i32)       # whole 256-B units, see the header
     eperm = torch.empty(max(E, 1), **i32)
     esrc = torch.empty(max(E, 1), **i32)
     edst = torch.empty(max(E, 1), **i32)

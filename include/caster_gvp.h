@@ -79,7 +79,8 @@ typedef struct {
  *   rowptr[N+1]  first sorted-edge position of every target node
  *   eperm[E]     original edge id of every sorted position (stable in edge id)
  *   esrc[E], edst[E]  source / target node of every sorted position
- *   work[N+1]    scratch
+ *   work         scratch of N+1 ints rounded UP to a multiple of 64 (zero-filled
+ *                here in whole 256-B units: one fill launch instead of two)
  * Launches 5 small kernels on `stream`. */
 int cgvp_csr_from_coo(const int64_t* edge_index, int64_t num_nodes, int64_t num_edges,
                       int32_t* rowptr, int32_t* eperm, int32_t* esrc, int32_t* edst,
