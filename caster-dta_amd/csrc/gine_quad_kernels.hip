@@ -476,6 +476,180 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
   }
 }
 
+// ---------------------------------------------------------------- forward on the same tiles
+// out = act(W1 act(W0 ((1+eps) x + sum_edges relu(x_src + e)) + b0) + b1) [* mask]: phases A and the
+// forward half of B of the kernel above (no gradient blocks -> 8 waves per workgroup everywhere).
+struct GineFArgs {
+  const float* x; const int64_t* ntypes; const float* eattr; const int64_t* etypes;
+  const int32_t* rowptr; const int32_t* eperm; const int32_t* esrc; const int32_t* edst; int64_t N;
+  const float* eps; const float* we; const float* be; const float* w0; const float* b0;
+  const float* w1; const float* b1; float slope; const float* mask; float* out;
+};
+constexpr int GF_WPB = 4, GF_TPB = WAVE * GF_WPB;
+
+template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
+__global__ __launch_bounds__(GF_TPB) void gine_quad_fwd_kernel(GineFArgs a) {
+  typedef GineQ<CIN, CHID, COUT, NT, NET, ED> Q;
+  constexpr int KE = Q::KE, XW = Q::XW, CINP = Q::CINP, MI = Q::MI, MH = Q::MH, MO = Q::MO;
+  constexpr int FE = 0, F0 = FE + Q::GE::NFRAG * 64, F1 = F0 + Q::G0::NFRAG * 64, FSZ = F1 + Q::G1::NFRAG * 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* frag = lds;
+  const int lane0 = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* rows = frag + FSZ + w * Q::ROWS;                            // [16][CINP]
+  stage_fragments<typename Q::GE, GF_TPB>(frag + FE, a.we);
+  stage_fragments<typename Q::G0, GF_TPB>(frag + F0, a.w0);
+  stage_fragments<typename Q::G1, GF_TPB>(frag + F1, a.w1);
+  __syncthreads();
+
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  const float eps1 = 1.0f + a.eps[0];
+  const int64_t ntiles = (a.N + TILE - 1) / TILE;
+  for (int64_t tile = (int64_t)blockIdx.x * GF_WPB + w; tile < ntiles; tile += (int64_t)gridDim.x * GF_WPB) {
+    const int64_t n0 = tile * TILE;
+    const int nn = (int)((a.N - n0 < TILE) ? (a.N - n0) : TILE);
+    const int32_t e0 = a.rowptr[n0], e1 = a.rowptr[n0 + nn];
+    for (int k = lane0; k < Q::ROWS / 4; k += WAVE) reinterpret_cast<f4*>(rows)[k] = zero;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- A. messages of the incoming edges, 64 at a time (see the backward kernel)
+    for (int32_t c0 = e0; c0 < e1; c0 += NTL * TILE) {
+      const int lane = opaque_lane(lane0), i = lane & 15, g = lane >> 4;
+      int32_t m_eid = 0, m_src = 0, m_dst = -1, m_et = 0;
+      if (c0 + lane < e1) {
+        m_eid = a.eperm[c0 + lane];
+        m_src = a.esrc[c0 + lane];
+        m_dst = a.edst[c0 + lane];
+        if (NET > 0) {
+          m_et = (int)a.etypes[m_eid];
+          m_et = m_et < 0 ? 0 : (m_et >= NET ? NET - 1 : m_et);
+        }
+      }
+      int32_t c_dst[NTL];
+      float c_fs[NTL][1][4];
+      f4 xj[NTL][MI];
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        const int sl = 16 * t + i;
+        const int32_t eid = __shfl(m_eid, sl), et = __shfl(m_et, sl), src = __shfl(m_src, sl);
+        c_dst[t] = __shfl(m_dst, sl);
+        const bool active = c_dst[t] >= 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int idx = 4 * s + g;
+          float v = 0.f;
+          if (active) {
+            if (idx < NET) v = (et == idx) ? 1.f : 0.f;
+            else if (idx < KE) v = a.eattr[(int64_t)eid * ED + (idx - NET)];
+          }
+          c_fs[t][0][s] = v;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MI; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = 16 * mt + 4 * g + r;
+            float v = 0.f;
+            if (active && c < CIN) v = c < NT ? (((int)a.ntypes[src] == c) ? 1.f : 0.f) : a.x[(int64_t)src * XW + (c - NT)];
+            xj[t][mt][r] = v;
+          }
+      }
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        if (c0 + t * TILE >= e1) break;
+        float xs[4 * MI];
+#pragma unroll
+        for (int mt = 0; mt < MI; ++mt) {
+          f4 acc[1];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = 16 * mt + 4 * g + r;
+            acc[0][r] = c < CIN ? a.be[c] : 0.f;
+          }
+          apply<typename Q::GE, 1>(frag + FE, mt, c_fs[t], acc, lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float mj = xj[t][mt][r] + acc[0][r];
+            xs[4 * mt + r] = (c_dst[t] >= 0 && mj > 0.f) ? mj : 0.f;
+          }
+        }
+        const int32_t dst = c_dst[t];
+        seg_scan16<4 * MI>(dst, xs);
+        const int nxt = __builtin_amdgcn_update_dpp(-1, dst, 0x100 | 1, 0xf, 0xf, false);
+        if (dst >= 0 && (i == TILE - 1 || nxt != dst)) {
+          float* row = rows + (dst - (int)n0) * CINP;
+#pragma unroll
+          for (int mt = 0; mt < MI; ++mt) {
+            f4* q = reinterpret_cast<f4*>(row + 16 * mt + 4 * g);
+            *q = *q + f4{xs[4 * mt], xs[4 * mt + 1], xs[4 * mt + 2], xs[4 * mt + 3]};
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+    }
+    // ---- B. the MLP of the 16 atoms
+    {
+      const int lane = opaque_lane(lane0), i = lane & 15, g = lane >> 4;
+      const bool valid = i < nn;
+      const int64_t n = n0 + i;
+      float bh[1][Q::KIn::steps];
+#pragma unroll
+      for (int mt = 0; mt < MI; ++mt) {
+        const f4 ag = *reinterpret_cast<const f4*>(rows + i * CINP + 16 * mt + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * mt + 4 * g + r;
+          float v = 0.f;
+          if (valid && c < CIN) v = c < NT ? (((int)a.ntypes[n] == c) ? 1.f : 0.f) : a.x[n * XW + (c - NT)];
+          bh[0][4 * mt + r] = fmaf(eps1, v, ag[r]);
+        }
+      }
+      float bt[1][Q::KHid::steps];
+#pragma unroll
+      for (int mt = 0; mt < MH; ++mt) {
+        f4 acc[1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[0][r] = a.b0[16 * mt + 4 * g + r];
+        apply<typename Q::G0, 1>(frag + F0, mt, bh, acc, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bt[0][4 * mt + r] = acc[0][r] > 0.f ? acc[0][r] : acc[0][r] * a.slope;
+      }
+#pragma unroll
+      for (int mt = 0; mt < MO; ++mt) {
+        f4 acc[1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[0][r] = a.b1[16 * mt + 4 * g + r];
+        apply<typename Q::G1, 1>(frag + F1, mt, bt, acc, lane);
+        f4 y;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = acc[0][r] > 0.f ? acc[0][r] : acc[0][r] * a.slope;
+        if (valid) {
+          if (a.mask) y = y * *reinterpret_cast<const f4*>(a.mask + n * COUT + 16 * mt + 4 * g);
+          *reinterpret_cast<f4*>(a.out + n * COUT + 16 * mt + 4 * g) = y;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+}
+
+template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
+int launch_fwd(GineFArgs& a, hipStream_t st) {
+  typedef GineQ<CIN, CHID, COUT, NT, NET, ED> Q;
+  const int64_t tiles = (a.N + TILE - 1) / TILE;
+  int64_t wgs = (tiles + GF_WPB - 1) / GF_WPB;
+  const int G = (int)(wgs < 1 ? 1 : (wgs > 1024 ? 1024 : wgs));
+  const size_t lds = (size_t)((Q::GE::NFRAG + Q::G0::NFRAG + Q::G1::NFRAG) * 64 + GF_WPB * Q::ROWS) * sizeof(float);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(gine_quad_fwd_kernel<CIN, CHID, COUT, NT, NET, ED>),
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((gine_quad_fwd_kernel<CIN, CHID, COUT, NT, NET, ED>), dim3(G), dim3(GF_TPB), lds, st, a);
+  return 0;
+}
+
 template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
 int launch(GineQArgs& a, int* rows, int* row_len, hipStream_t st) {
   typedef GineQ<CIN, CHID, COUT, NT, NET, ED> Q;
@@ -508,6 +682,20 @@ int gine_bwd(int cin, int chid, int cout, int nt, int net, int ed, const float* 
   if (cin == 16 && chid == 64 && cout == 64 && nt == 0 && net == 5 && ed == 9) return launch<16, 64, 64, 0, 5, 9>(a, rows, row_len, st);
   if (cin == 16 && chid == 16 && cout == 16 && nt == 0 && net == 5 && ed == 9) return launch<16, 16, 16, 0, 5, 9>(a, rows, row_len, st);   // middle layers of deeper stacks
   return CGVP_ERR_UNSUPPORTED_DIMS;
+}
+
+// Forward on tiles for the compiled layer shapes; returns 1 when the shape is not compiled (the
+// caller then uses the generic one-wave-per-atom kernel).
+int gine_fwd(int cin, int chid, int cout, int nt, int net, int ed, const float* x, const int64_t* ntypes,
+             const float* eattr, const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,
+             const int32_t* esrc, const int32_t* edst, int64_t N, const cgvp_gine_w* w, float slope,
+             const float* mask, float* out, hipStream_t st) {
+  GineFArgs a{x, ntypes, eattr, etypes, rowptr, eperm, esrc, edst, N, w->eps, w->we, w->be, w->w0, w->b0,
+              w->w1, w->b1, slope, mask, out};
+  if (cin == 52 && chid == 16 && cout == 16 && nt == 11 && net == 5 && ed == 9) return launch_fwd<52, 16, 16, 11, 5, 9>(a, st);
+  if (cin == 16 && chid == 64 && cout == 64 && nt == 0 && net == 5 && ed == 9) return launch_fwd<16, 64, 64, 0, 5, 9>(a, st);
+  if (cin == 16 && chid == 16 && cout == 16 && nt == 0 && net == 5 && ed == 9) return launch_fwd<16, 16, 16, 0, 5, 9>(a, st);
+  return 1;
 }
 
 }  // namespace quad

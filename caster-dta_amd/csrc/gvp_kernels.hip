@@ -724,9 +724,9 @@ int cgvp_node_embed_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
 
 int cgvp_gine_conv_fwd(const float* x, const int64_t* ntypes, int32_t num_ntypes, const float* eattr,
                        const int64_t* etypes, int32_t num_etypes, int32_t edge_dim,
-                       const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc, int64_t N,
-                       int64_t E, int32_t cin, int32_t chid, int32_t cout, const cgvp_gine_w* w,
-                       float act_slope, const float* mask, float* out, void* stream) {
+                       const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc, const int32_t* edst,
+                       int64_t N, int64_t E, int32_t cin, int32_t chid, int32_t cout, const cgvp_gine_w* w,
+                       float act_slope, const float* mask, int32_t variant, float* out, void* stream) {
   if (N < 0 || E < 0 || !w) return CGVP_ERR_BAD_ARG;
   if (num_ntypes < 0 || num_etypes < 0 || edge_dim < 0 || cin <= num_ntypes) return CGVP_ERR_BAD_ARG;
   if (cin > WAVE || chid > WAVE || cout > WAVE || chid < 1 || cout < 1 || num_etypes + edge_dim > GINE_MAXKE)
@@ -734,6 +734,13 @@ int cgvp_gine_conv_fwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
   if (N == 0) return 0;
   if (!x || !out || !rowptr || (num_ntypes > 0 && !ntypes)) return CGVP_ERR_BAD_ARG;
   if (E > 0 && (!eperm || !esrc || (edge_dim > 0 && !eattr) || (num_etypes > 0 && !etypes))) return CGVP_ERR_BAD_ARG;
+  // variant 0: 16-atom MFMA tiles when the layer shape is compiled (needs edst and 16-B aligned
+  // out / mask); variant 1 or any other shape: generic one-wave-per-atom kernel
+  if (variant == 0 && edst && !((uintptr_t)out & 15) && !((uintptr_t)mask & 15)) {
+    const int rc = quad::gine_fwd(cin, chid, cout, num_ntypes, num_etypes, edge_dim, x, ntypes, eattr, etypes, rowptr,
+                                  eperm, esrc, edst, N, w, act_slope, mask, out, (hipStream_t)stream);
+    if (rc <= 0) return rc < 0 ? rc : launch_status();
+  }
   GineArgs a{x, ntypes, num_ntypes, eattr, etypes, num_etypes, edge_dim, rowptr, eperm, esrc, N, cin,
              chid, cout, w->eps, w->we, w->be, w->w0, w->b0, w->w1, w->b1, act_slope, out, mask};
   const size_t lds = (size_t)(chid * (cin + 1) + cout * (chid + 1) + 2 * GINE_APB * WAVE) * sizeof(float);

@@ -69,8 +69,8 @@ _SIGNATURES = {
     "cgvp_node_embed_bwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P,
                                       _P, _P, _P, _P, _P]),
     "cgvp_bwd_reduce": (C.c_int, [_P, _I32, _P, _P]),
-    "cgvp_gine_conv_fwd": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _I64, _I64, _I32, _I32,
-                                     _I32, C.POINTER(GineW), C.c_float, _P, _P, _P]),
+    "cgvp_gine_conv_fwd": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32,
+                                     _I32, C.POINTER(GineW), C.c_float, _P, _I32, _P, _P]),
     "cgvp_gine_bwd_workspace_floats": (C.c_int64, []),
     "cgvp_gine_conv_bwd": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32,
                                      C.POINTER(GineW), C.c_float, _P, _P, _P, _P, _P, _P]),

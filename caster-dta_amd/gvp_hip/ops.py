@@ -221,7 +221,8 @@ def gine_conv_forward(x, ntypes, num_ntypes, eattr, etypes, num_etypes, csr, w, 
     out = torch.empty(N, cout, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         rc = L.cgvp_gine_conv_fwd(_ptr(x), _ptr(nt), num_ntypes, _ptr(eattr), _ptr(et), num_etypes, edge_dim,
-                                  _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), N, csr.num_edges,
-                                  cin, chid, cout, C.byref(gw), float(slope), _ptr(mask), _ptr(out), _stream())
+                                  _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst), N, csr.num_edges,
+                                  cin, chid, cout, C.byref(gw), float(slope), _ptr(mask),
+                                  0 if VARIANT == "mfma" else 1, _ptr(out), _stream())
     _lib.check(rc, "cgvp_gine_conv_fwd")
     return out

@@ -221,7 +221,11 @@ int cgvp_node_embed_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
  * `x` is [N][cin] when `ntypes` is NULL; for the first layer pass the raw atom
  * features [N][cin - num_ntypes] and `ntypes`, and the one-hot columns are
  * synthesised on the fly (molecule_gnn.py:127-140).  cin <= 64, chid <= 64,
- * cout <= 64, edge_dim + num_etypes <= 16. */
+ * cout <= 64, edge_dim + num_etypes <= 16.
+ * variant 0 (production): 16-atom MFMA tiles (csrc/gine_quad_kernels.hip) for the
+ * compiled CASTER-DTA layer shapes -- needs `edst` as well -- and the generic kernel for
+ * any other shape; variant 1: always the generic one-wave-per-atom kernel (`edst` may
+ * be NULL), kept as the independent second implementation for cross-checks. */
 typedef struct {
   const float* eps;     /* [1]                conv_list.l.eps            */
   const float* we;      /* [cin][net+edge_dim] conv_list.l.lin.weight     */
@@ -235,9 +239,10 @@ typedef struct {
 int cgvp_gine_conv_fwd(const float* x, const int64_t* ntypes, int32_t num_ntypes,
                        const float* eattr, const int64_t* etypes, int32_t num_etypes,
                        int32_t edge_dim, const int32_t* rowptr, const int32_t* eperm,
-                       const int32_t* esrc, int64_t num_nodes, int64_t num_edges, int32_t cin,
-                       int32_t chid, int32_t cout, const cgvp_gine_w* w, float act_slope,
-                       const float* mask, float* out, void* stream);
+                       const int32_t* esrc, const int32_t* edst, int64_t num_nodes,
+                       int64_t num_edges, int32_t cin, int32_t chid, int32_t cout,
+                       const cgvp_gine_w* w, float act_slope, const float* mask, int32_t variant,
+                       float* out, void* stream);
 
 /* Backward of cgvp_gine_conv_fwd.  `mask` (optional, [N][cout]) is the dropout
  * mask molecule_gnn.py:262 applies to the layer output during training (also an
