@@ -201,10 +201,14 @@ __device__ __forceinline__ float sel_val(int lane, int r) { return ((lane & 15) 
 // ds_write_b32 + one ds_read_b128 per 16 slots instead of four MFMAs: it takes the operand
 // transposes (~30 % of the conv backward's MFMAs) off the matrix-core pipe that two waves share.
 constexpr int TSCR_LD = 20, TSCR_FLOATS = 16 * TSCR_LD;     // [slot n][item], rows padded to 80 B
+#ifndef CGVP_TSCR_MIN_STEPS
+#define CGVP_TSCR_MIN_STEPS 0
+#endif
+constexpr int TSCR_MIN_STEPS = CGVP_TSCR_MIN_STEPS;         // operands of at most this many slots stay on the MFMA path
 template <int NSTEPS>
 __device__ __forceinline__ void transpose_slots(const float (&v)[NSTEPS], f4 (&out)[ceil4(NSTEPS)], int lane,
                                                 float* tscr = nullptr) {
-  if (tscr) {
+  if (tscr && NSTEPS > TSCR_MIN_STEPS) {
     const int i = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int T = 0; T < ceil4(NSTEPS); ++T) {
