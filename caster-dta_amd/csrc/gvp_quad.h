@@ -51,6 +51,13 @@ struct Seg {
   }
 };
 
+// STEPS k-steps that map to nothing (padding inside a Segs list).
+template <int STEPS>
+struct SegNone {
+  static constexpr int steps = STEPS;
+  static __host__ __device__ int col(int, int) { return -1; }
+};
+
 template <class... S>
 struct Segs {
   static constexpr int steps = (S::steps + ... + 0);
@@ -571,6 +578,7 @@ struct GvpQ {
   static constexpr int WG_SCRATCH = 0;
   static constexpr int NTS = ceil4(NT);                 // k-steps of the one-hot type columns
   typedef Segs<Seg<P2, 0, (NT > 0 ? NT : 1)>, SSegs, Seg<P2, NT + SI, H>> WsCols;   // [types | scalars | norms]
+  static constexpr bool PACK_V = VO > 0 && VOR + HR <= 4 && HR + VSTEPS <= 4;   // dWv and dWh fit one block
   template <class Acc>
   static __device__ __forceinline__ void weight_grads(float* gblk, bool first, int lane, int type, bool active,
                                                       const float (&bs)[SSTEPS], const float (&bv)[3][VSTEPS],
@@ -645,24 +653,50 @@ struct GvpQ {
         }
         add_where<Acc, VOR>(q, on, tot);
       }
-      // ---- dWv = sum_planes dvp (x) vh
-      f4 accv[1][1] = {{zero}};
+      // ---- dWv = sum_planes dvp (x) vh   (alone only when it cannot share a block with dWh, below)
+      if constexpr (!PACK_V) {
+        f4 accv[1][1] = {{zero}};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          float av[VOR], bh[HR];
+#pragma unroll
+          for (int r = 0; r < VOR; ++r) av[r] = active ? gr.dvp[p][r] : 0.f;
+#pragma unroll
+          for (int r = 0; r < HR; ++r) bh[r] = c.vh[p][r];
+          f4 AV[1], BH[1];
+          transpose_slots<VOR>(av, AV, lane, tscr);
+          transpose_slots<HR>(bh, BH, lane, tscr);
+          outer_items<1, 1>(AV, BH, accv);
+        }
+        flush_slots<Acc, Segs<Seg<P2, 0, (VO > 0 ? VO : 1)>>, Segs<Seg<P2, 0, H>>, 1, 1>(gblk + A::wv(NT), first, H, accv, lane);
+      }
+    }
+    if constexpr (PACK_V) {
+      // ---- dWv and dWh share one 16x16 block: rows [dvp slots | dvh slots], columns [vh slots | V_in
+      // slots]; its two diagonal sub-blocks are the two gradients (the off-diagonal ones are dropped).
+      // Half the outer-product MFMAs and half the operand transposes of the vector part.
+      f4 acc2[1][1] = {{zero}};
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
-        float av[VOR], bh[HR];
+        float a2[VOR + HR], b2[HR + VSTEPS];
 #pragma unroll
-        for (int r = 0; r < VOR; ++r) av[r] = active ? gr.dvp[p][r] : 0.f;
+        for (int r = 0; r < VOR; ++r) a2[r] = active ? gr.dvp[p][r] : 0.f;
 #pragma unroll
-        for (int r = 0; r < HR; ++r) bh[r] = c.vh[p][r];
-        f4 AV[1], BH[1];
-        transpose_slots<VOR>(av, AV, lane, tscr);
-        transpose_slots<HR>(bh, BH, lane, tscr);
-        outer_items<1, 1>(AV, BH, accv);
+        for (int r = 0; r < HR; ++r) a2[VOR + r] = active ? gr.dvh[p][r] : 0.f;
+#pragma unroll
+        for (int r = 0; r < HR; ++r) b2[r] = c.vh[p][r];
+#pragma unroll
+        for (int s_ = 0; s_ < VSTEPS; ++s_) b2[HR + s_] = bv[p][s_];
+        f4 A2[1], B2[1];
+        transpose_slots<VOR + HR>(a2, A2, lane, tscr);
+        transpose_slots<HR + VSTEPS>(b2, B2, lane, tscr);
+        outer_items<1, 1>(A2, B2, acc2);
       }
-      flush_slots<Acc, Segs<Seg<P2, 0, (VO > 0 ? VO : 1)>>, Segs<Seg<P2, 0, H>>, 1, 1>(gblk + A::wv(NT), first, H, accv, lane);
-    }
-    // ---- dWh = sum_planes dvh (x) V_in
-    {
+      flush_slots<Acc, Segs<Seg<P2, 0, (VO > 0 ? VO : 1)>, SegNone<HR>>, Segs<Seg<P2, 0, H>, SegNone<VSTEPS>>, 1, 1>(
+          gblk + A::wv(NT), first, H, acc2, lane);
+      flush_slots<Acc, Segs<SegNone<VOR>, Seg<P2, 0, H>>, Segs<SegNone<HR>, VSegs>, 1, 1>(gblk, first, VI, acc2, lane);
+    } else {
+      // ---- dWh = sum_planes dvh (x) V_in
       f4 acch[1][1] = {{zero}};
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
