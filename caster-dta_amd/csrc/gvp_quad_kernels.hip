@@ -338,11 +338,18 @@ __global__ __launch_bounds__(TPB) void conv_quad_kernel(ConvQArgs a) {
       // lane i closes a segment when its right neighbour has another target (or is past the end)
       const int nxt = __builtin_amdgcn_update_dpp(-1, dst[j], 0x100 | 1 /* row_shl:1 */, 0xf, 0xf, false);
       if (active[j] && (i == TILE - 1 || nxt != dst[j])) {
+        // wave-private rows, and within a tile every (row, channel) has exactly one closing lane: plain
+        // read-add-write (LDS float atomics retire ~1 lane per 3 cycles per CU)
         float* row = acc + (dst[j] - (int)n0) * ROW;
+        f4* qs = reinterpret_cast<f4*>(row + 4 * g);
+        *qs = *qs + f4{x[0], x[1], x[2], x[3]};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(row + 4 * g + r, x[r]);     // ds_add_f32, wave-private rows
-#pragma unroll
-        for (int d = 0; d < 3; ++d) atomicAdd(row + NS + 3 * g + d, x[4 + d]);
+        for (int d = 0; d < 3; ++d) row[NS + 3 * g + d] += x[4 + d];
+      }
+      if (CTN > 1) {                     // the next lockstep tile may continue this tile's last target
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       }
     }
   }
