@@ -269,3 +269,49 @@ def test_large_batch_linearity(protein_params):
     for gb_, ga_, gb2_ in zip(g_big, g_a, g_b):
         ref = ga_ + gb2_
         assert float((gb_ - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-6 * scale
+
+
+def test_backward_without_edges(protein_params, molecule_params):
+    """Degenerate batches the reference handles (nothing to aggregate): graphs with no edges at all, a single
+    node.  Forward and every gradient against the oracle; exercises the empty-segment paths of every kernel."""
+    from models.molecule_gnn import SelectableMoleculeModelWrapper
+    # protein: 5 isolated residues
+    gb = ds.protein_batch(1, 9, length=5)
+    d = ds.to_torch(gb)
+    keep = torch.zeros(d["edge_index"].shape[1], dtype=torch.bool)
+    d = dict(d, edge_index=d["edge_index"][:, keep], etypes=d["etypes"][keep],
+             eattr=(d["eattr"][0][keep], d["eattr"][1][keep]))
+    P = {k: v.clone().requires_grad_(True) for k, v in protein_params.items()}
+    ref = O.protein_lba_forward(P, d["x"], d["edge_index"], d["ntypes"], d["etypes"], d["eattr"])
+    r = torch.randn(ref.shape, generator=torch.Generator().manual_seed(3))
+    (ref * r).sum().backward()
+    model = _encoder(protein_params).eval()
+    dd = _to(d)
+    out = model(dd["x"], dd["edge_index"], dd["ntypes"], dd["etypes"], eattr=dd["eattr"])
+    assert rel_err(out, ref) < 2e-5
+    (out * r.to(DEV)).sum().backward()
+    assert _check_grads(model, {k: v.grad for k, v in P.items() if v.grad is not None}) >= 40
+    # drug: one molecule's atoms, no bonds
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))["molecule_gnn_kwargs"]
+    mol = SelectableMoleculeModelWrapper(**kw)
+    mol.load_state_dict({"gnn_model." + k: v for k, v in molecule_params.items()})
+    mol = mol.to(DEV).eval()
+    m = ds.to_torch(ds.drug_batch(1, 4))
+    ei = m["edge_index"][:, :0]
+    et, ea = m["etypes"][:0], m["eattr"][:0]
+    Q = {k: v.clone().requires_grad_(True) for k, v in molecule_params.items()}
+    xr = m["x"].clone().requires_grad_()
+    mref = O.molecule_gine_forward(Q, xr, ei, m["ntypes"], et, ea)
+    r2 = torch.randn(mref.shape, generator=torch.Generator().manual_seed(4))
+    (mref * r2).sum().backward()
+    gx = m["x"].to(DEV).requires_grad_()
+    mout = mol(gx, ei.to(DEV), m["ntypes"].to(DEV), et.to(DEV), eattr=ea.to(DEV))
+    assert rel_err(mout, mref) < 2e-5
+    (mout * r2.to(DEV)).sum().backward()
+    for name, p in mol.gnn_model.named_parameters():
+        g = Q[name].grad
+        if g is None or float(g.abs().max()) == 0.0:        # lin.* gets no gradient without edges
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+        else:
+            assert rel_err(p.grad, g) < 2e-4, name
+    assert rel_err(gx.grad, xr.grad) < 2e-4
