@@ -24,7 +24,8 @@ int node_embed(int nt_node, const float* img, const float* x_s, const float* x_v
                int64_t N, float* h, hipStream_t st);
 int conv(int nt_edge, const float* img, const float* h, const float* e_s, const float* e_v,
          const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
-         const int32_t* edst, int64_t N, int64_t E, int mean, float* dh, hipStream_t st);
+         const int32_t* edst, int64_t N, int64_t E, int mean, float* dh, int fuse, const float* img_node,
+         const float* img_head, float* h_out, float* out, const float* mask0, const float* mask1, hipStream_t st);
 int node_update(const float* img_node, const float* img_head, const float* h, const float* dh, int64_t N,
                 int with_head, float* h_out, float* out, const float* mask0, const float* mask1, hipStream_t st);
 

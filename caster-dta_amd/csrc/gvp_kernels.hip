@@ -557,7 +557,8 @@ int cgvp_conv_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float*
     QuadOffsets o;
     if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
     if (int rc = quad::conv(layout->nt_edge, image + o.conv0 + layer * o.layer_stride, h, e_s, e_v, etypes, rowptr,
-                            eperm, esrc, edst, N, E, aggr_mean ? 1 : 0, dh, (hipStream_t)stream)) return rc;
+                            eperm, esrc, edst, N, E, aggr_mean ? 1 : 0, dh, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                            nullptr, (hipStream_t)stream)) return rc;
     return launch_status();
   }
   // target nodes per workgroup: aim at ~48 of the 64 edge lanes per chunk
@@ -574,6 +575,28 @@ int cgvp_conv_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float*
     case 1: hipLaunchKernelGGL(conv_fwd_kernel<1>, grid, dim3(WAVE), 0, st, a); break;
     default: return CGVP_ERR_UNSUPPORTED_DIMS;
   }
+  return launch_status();
+}
+
+int cgvp_conv_layer_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image, int32_t layer,
+                        const float* h, const float* e_s, const float* e_v, const int64_t* etypes,
+                        const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc, const int32_t* edst,
+                        int64_t N, int64_t E, int32_t aggr_mean, const float* mask0, const float* mask1,
+                        int32_t with_head, float* dh, float* h_out, float* out, void* stream) {
+  if (int rc = check_dims(dims)) return rc;
+  if (N < 0 || E < 0 || !layout || !image) return CGVP_ERR_BAD_ARG;
+  if (layer < 0 || layer >= num_convs_of(*layout)) return CGVP_ERR_BAD_ARG;
+  if (N == 0) return 0;
+  if (!h || !rowptr || (with_head ? !out : !h_out)) return CGVP_ERR_BAD_ARG;
+  if (E > 0 && (!e_s || !e_v || !eperm || !esrc || !edst || (layout->nt_edge > 0 && !etypes))) return CGVP_ERR_BAD_ARG;
+  const void* al[] = {h, e_s, dh, h_out, out, mask0, mask1};
+  for (const void* q : al) if ((uintptr_t)q & 15) return CGVP_ERR_BAD_ARG;
+  QuadOffsets o;
+  if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
+  if (int rc = quad::conv(layout->nt_edge, image + o.conv0 + layer * o.layer_stride, h, e_s, e_v, etypes, rowptr, eperm,
+                          esrc, edst, N, E, aggr_mean ? 1 : 0, dh, with_head ? 2 : 1,
+                          image + o.node0 + layer * o.layer_stride, image + o.head, h_out, out, mask0, mask1,
+                          (hipStream_t)stream)) return rc;
   return launch_status();
 }
 

@@ -154,12 +154,127 @@ __global__ __launch_bounds__(TPB) void embed_quad_kernel(EmbedQArgs a) {
   }
 }
 
+// ------------------------------------------------------------------ node update
+// mask0 / mask1: optional dropout masks [N][20] = 16 scalar-channel + 4 vector-channel
+// factors (0 or 1/(1-p); a vector channel's xyz share one factor, gvp_layers.py:187-198),
+// applied to dh before the first residual and to the feed-forward output before the second.
+struct NodeQArgs {
+  const float* img_node; const float* img_head;
+  const float* h; const float* dh; int64_t N; float* h_out; float* out;
+  const float* mask0; const float* mask1;
+};
+constexpr int MROW = NS + NV;
+
+// Rest of GVPConvLayer.forward for one tile of 16 residues, from s/v = h + mask0 * dh (lane (i, g)
+// holds scalars 4g..4g+3 and vector channel g): LN0, feed-forward GVPs, residual, LN1 -> h_out
+// (optional with the head), then gvp_norm_before_scalar + gvp_to_scalar -> out.
+template <bool HEAD>
+__device__ __forceinline__ void node_tile(const float* nd, const float* hd, int lane, bool active, int64_t n,
+                                          f4 (&s)[1], float (&v)[3][1], f4 m1s, float m1v, float* h_out,
+                                          float* out) {
+  typedef Image<0, 0> IM;
+  const int g = lane >> 4;
+  const int zt[1] = {0};
+  ln_quad<NS, NV>(nd + IM::ND_LN0, lane, s, v);
+  {
+    f4 hs[1][4], s2[1][1];
+    float hv[1][3][2], v2[1][3][1];
+    {
+      float bs[1][4], bv[1][3][1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bs[0][r] = s[0][r];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bv[0][p][0] = v[p][0];
+      QFf0::Cache c[1];
+      QFf0::forward<1>(nd + IM::ND_FF0, lane, zt, bs, bv, hs, hv, c);
+    }
+    {
+      float bs[1][16], bv[1][3][2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bs[0][4 * t + r] = hs[0][t][r];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) { bv[0][p][0] = hv[0][p][0]; bv[0][p][1] = hv[0][p][1]; }
+      QFf1::Cache c[1];
+      QFf1::forward<1>(nd + IM::ND_FF1, lane, zt, bs, bv, s2, v2, c);
+    }
+    s[0] += s2[0][0] * m1s;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) v[p][0] += v2[0][p][0] * m1v;
+  }
+  ln_quad<NS, NV>(nd + IM::ND_LN1, lane, s, v);
+  if (active && (!HEAD || h_out)) {          // with the head h_out is optional (training saves it for the backward)
+    float* row = h_out + n * ROW;
+    *reinterpret_cast<f4*>(row + 4 * g) = s[0];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) row[NS + 3 * g + p] = v[p][0];
+  }
+  if (!HEAD) return;
+  ln_quad<NS, NV>(hd + IM::HD_LN, lane, s, v);
+  float bs[1][4], bv[1][3][1], dummy[1][3][1];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bs[0][r] = s[0][r];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) bv[0][p][0] = v[p][0];
+  f4 o[1][4];
+  QHead::Cache c[1];
+  QHead::forward<1>(hd + IM::HD_GVP, lane, zt, bs, bv, o, dummy, c);
+  if (active) {
+    float* row = out + n * OUT;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *reinterpret_cast<f4*>(row + 16 * t + 4 * g) = o[0][t];
+  }
+}
+
+// s/v = h[n] + mask0 * dh_row for lane (i, g); dh_row points at the node's [28] aggregated message
+__device__ __forceinline__ void node_inputs(const NodeQArgs& a, int lane, bool active, int64_t n, const float* dr,
+                                            f4 (&s)[1], float (&v)[3][1], f4& m1s, float& m1v) {
+  const int g = lane >> 4;
+  s[0] = f4{0.f, 0.f, 0.f, 0.f};
+  v[0][0] = v[1][0] = v[2][0] = 0.f;
+  m1s = f4{1.f, 1.f, 1.f, 1.f};
+  m1v = 1.f;
+  if (!active) return;
+  const float* hr = a.h + n * ROW;
+  f4 ds = *reinterpret_cast<const f4*>(dr + 4 * g);
+  float dv[3] = {dr[NS + 3 * g], dr[NS + 3 * g + 1], dr[NS + 3 * g + 2]};
+  if (a.mask0) {
+    ds *= *reinterpret_cast<const f4*>(a.mask0 + n * MROW + 4 * g);
+    const float mv = a.mask0[n * MROW + NS + g];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) dv[p] *= mv;
+  }
+  if (a.mask1) { m1s = *reinterpret_cast<const f4*>(a.mask1 + n * MROW + 4 * g); m1v = a.mask1[n * MROW + NS + g]; }
+  s[0] = *reinterpret_cast<const f4*>(hr + 4 * g) + ds;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) v[p][0] = hr[NS + 3 * g + p] + dv[p];
+}
+
+template <bool HEAD>
+__global__ __launch_bounds__(TPB) void node_quad_kernel(NodeQArgs a) {
+  typedef Image<0, 0> IM;
+  __shared__ __attribute__((aligned(16))) float lds[IM::ND_SIZE + (HEAD ? IM::HD_SIZE : 0)];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = lane & 15;
+  const int64_t n = ((int64_t)blockIdx.x * WPB + w) * TILE + i;
+  const bool active = n < a.N;
+  f4 s[1], m1s;
+  float v[3][1], m1v;
+  node_inputs(a, lane, active, n, a.dh + n * ROW, s, v, m1s, m1v);     // row loads fly while the image is staged
+  stage_slice<IM::ND_SIZE>(lds, a.img_node, threadIdx.x);
+  if (HEAD) stage_slice<IM::HD_SIZE>(lds + IM::ND_SIZE, a.img_head, threadIdx.x);
+  __syncthreads();
+  node_tile<HEAD>(lds, lds + IM::ND_SIZE, lane, active, n, s, v, m1s, m1v, a.h_out, a.out);
+}
+
 // ------------------------------------------------------------------ conv
 struct ConvQArgs {
   const float* img;   // this layer's conv slice
   const float* h; const float* e_s; const float* e_v; const int64_t* etypes;
   const int32_t* rowptr; const int32_t* eperm; const int32_t* esrc; const int32_t* edst;
   int64_t N; int npw; int mean; float* dh;
+  NodeQArgs node;     // FUSE > 0: the node update of the same layer runs on the wave's own targets (h = this->h)
 };
 
 constexpr int CTN = 2;                 // edge tiles processed in lockstep per pass (32 edges)
@@ -299,14 +414,18 @@ __device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, i
 // no LDS traffic, no barrier) and lets the last lane of each segment add the
 // segment total into the wave's private LDS accumulator.  Ownership makes the
 // result independent of scheduling: no atomics on HBM, bitwise reproducible.
-template <int NTE>
+// FUSE: 0 = conv only; 1 = + node update; 2 = + node update with the output head
+template <int NTE, int FUSE>
 __global__ __launch_bounds__(TPB) void conv_quad_kernel(ConvQArgs a) {
   typedef Image<0, NTE> IM;
+  typedef Image<0, 0> IMN;
   constexpr int ACC = WAVE * ROW;
+  constexpr int ND_FLOATS = FUSE == 0 ? 0 : IMN::ND_SIZE + (FUSE == 2 ? IMN::HD_SIZE : 0);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* img = lds;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float* acc = lds + IM::CV_SIZE + w * ACC;
+  float* nd_img = lds + IM::CV_SIZE;
+  float* acc = nd_img + ND_FLOATS + w * ACC;
   STAMP(0);
   const int64_t n0 = ((int64_t)blockIdx.x * WPB + w) * a.npw;
   const int nn = n0 < a.N ? (int)((a.N - n0 < a.npw) ? (a.N - n0) : a.npw) : 0;
@@ -316,6 +435,8 @@ __global__ __launch_bounds__(TPB) void conv_quad_kernel(ConvQArgs a) {
   ConvIn in;
   conv_gather<NTE>(a, e0, e1, lane, in);
   stage_slice<IM::CV_SIZE>(img, a.img, threadIdx.x);
+  if (FUSE > 0) stage_slice<IMN::ND_SIZE>(nd_img, a.node.img_node, threadIdx.x);
+  if (FUSE == 2) stage_slice<IMN::HD_SIZE>(nd_img + IMN::ND_SIZE, a.node.img_head, threadIdx.x);
   for (int k = lane; k < nn * ROW; k += WAVE) acc[k] = 0.f;
   STAMP(1);
   __syncthreads();                                  // image staged, accumulators cleared
@@ -357,113 +478,33 @@ __global__ __launch_bounds__(TPB) void conv_quad_kernel(ConvQArgs a) {
   __syncthreads();
   STAMP(8);
   if (nn > 0) {
-    float* out = a.dh + n0 * ROW;
+    float* out = a.dh ? a.dh + n0 * ROW : nullptr;
     for (int k = lane; k < nn * ROW; k += WAVE) {
       float v = acc[k];
       if (a.mean) {
         const int nd = k / ROW;
         const int deg = a.rowptr[n0 + nd + 1] - a.rowptr[n0 + nd];
         v = v / (float)(deg > 1 ? deg : 1);
+        if (FUSE > 0) acc[k] = v;
       }
-      out[k] = v;
+      if (out) out[k] = v;            // kept for the backward pass; inference passes no dh buffer when fused
     }
   }
   STAMP(9);
-}
-
-// ------------------------------------------------------------------ node update
-// mask0 / mask1: optional dropout masks [N][20] = 16 scalar-channel + 4 vector-channel
-// factors (0 or 1/(1-p); a vector channel's xyz share one factor, gvp_layers.py:187-198),
-// applied to dh before the first residual and to the feed-forward output before the second.
-struct NodeQArgs {
-  const float* img_node; const float* img_head;
-  const float* h; const float* dh; int64_t N; float* h_out; float* out;
-  const float* mask0; const float* mask1;
-};
-constexpr int MROW = NS + NV;
-
-template <bool HEAD>
-__global__ __launch_bounds__(TPB) void node_quad_kernel(NodeQArgs a) {
-  typedef Image<0, 0> IM;
-  __shared__ __attribute__((aligned(16))) float lds[IM::ND_SIZE + (HEAD ? IM::HD_SIZE : 0)];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int i = lane & 15, g = lane >> 4;
-  const int64_t n = ((int64_t)blockIdx.x * WPB + w) * TILE + i;
-  const bool active = n < a.N;
-  f4 s[1] = {{0.f, 0.f, 0.f, 0.f}};
-  float v[3][1] = {{0.f}, {0.f}, {0.f}};
-  f4 m1s = {1.f, 1.f, 1.f, 1.f};
-  float m1v = 1.f;
-  if (active) {                                  // row loads fly while the image is staged
-    const float* hr = a.h + n * ROW;
-    const float* dr = a.dh + n * ROW;
-    f4 ds = *reinterpret_cast<const f4*>(dr + 4 * g);
-    float dv[3] = {dr[NS + 3 * g], dr[NS + 3 * g + 1], dr[NS + 3 * g + 2]};
-    if (a.mask0) {
-      ds *= *reinterpret_cast<const f4*>(a.mask0 + n * MROW + 4 * g);
-      const float mv = a.mask0[n * MROW + NS + g];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) dv[p] *= mv;
+  if (FUSE > 0) {
+    // the node update of the wave's own targets, 16 at a time, straight from the LDS rows
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int t0 = 0; t0 < nn; t0 += TILE) {
+      const int k = t0 + i;
+      const bool act = k < nn;
+      const int64_t n = n0 + k;
+      f4 s[1], m1s;
+      float v[3][1], m1v;
+      node_inputs(a.node, lane, act, n, acc + (act ? k : 0) * ROW, s, v, m1s, m1v);
+      node_tile<FUSE == 2>(nd_img, nd_img + IMN::ND_SIZE, lane, act, n, s, v, m1s, m1v, a.node.h_out, a.node.out);
     }
-    if (a.mask1) { m1s = *reinterpret_cast<const f4*>(a.mask1 + n * MROW + 4 * g); m1v = a.mask1[n * MROW + NS + g]; }
-    s[0] = *reinterpret_cast<const f4*>(hr + 4 * g) + ds;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) v[p][0] = hr[NS + 3 * g + p] + dv[p];
-  }
-  stage_slice<IM::ND_SIZE>(lds, a.img_node, threadIdx.x);
-  if (HEAD) stage_slice<IM::HD_SIZE>(lds + IM::ND_SIZE, a.img_head, threadIdx.x);
-  __syncthreads();
-  const int zt[1] = {0};
-  ln_quad<NS, NV>(lds + IM::ND_LN0, lane, s, v);
-  {
-    f4 hs[1][4], s2[1][1];
-    float hv[1][3][2], v2[1][3][1];
-    {
-      float bs[1][4], bv[1][3][1];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bs[0][r] = s[0][r];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) bv[0][p][0] = v[p][0];
-      QFf0::Cache c[1];
-      QFf0::forward<1>(lds + IM::ND_FF0, lane, zt, bs, bv, hs, hv, c);
-    }
-    {
-      float bs[1][16], bv[1][3][2];
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bs[0][4 * t + r] = hs[0][t][r];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) { bv[0][p][0] = hv[0][p][0]; bv[0][p][1] = hv[0][p][1]; }
-      QFf1::Cache c[1];
-      QFf1::forward<1>(lds + IM::ND_FF1, lane, zt, bs, bv, s2, v2, c);
-    }
-    s[0] += s2[0][0] * m1s;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) v[p][0] += v2[0][p][0] * m1v;
-  }
-  ln_quad<NS, NV>(lds + IM::ND_LN1, lane, s, v);
-  if (active && (!HEAD || a.h_out)) {       // with the head h_out is optional (training saves it for the backward)
-    float* row = a.h_out + n * ROW;
-    *reinterpret_cast<f4*>(row + 4 * g) = s[0];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) row[NS + 3 * g + p] = v[p][0];
-  }
-  if (!HEAD) return;
-  const float* hd = lds + IM::ND_SIZE;
-  ln_quad<NS, NV>(hd + IM::HD_LN, lane, s, v);
-  float bs[1][4], bv[1][3][1], dummy[1][3][1];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) bs[0][r] = s[0][r];
-#pragma unroll
-  for (int p = 0; p < 3; ++p) bv[0][p][0] = v[p][0];
-  f4 o[1][4];
-  QHead::Cache c[1];
-  QHead::forward<1>(hd + IM::HD_GVP, lane, zt, bs, bv, o, dummy, c);
-  if (active) {
-    float* row = a.out + n * OUT;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) *reinterpret_cast<f4*>(row + 16 * t + 4 * g) = o[0][t];
   }
 }
 
@@ -529,26 +570,35 @@ int node_embed(int nt_node, const float* img, const float* x_s, const float* x_v
   return 0;
 }
 
+template <int NTE, int FUSE>
+void conv_launch(const ConvQArgs& a, dim3 grid, hipStream_t st) {
+  const size_t lds = (size_t)(Image<0, NTE>::CV_SIZE + (FUSE == 0 ? 0 : Image<0, 0>::ND_SIZE + (FUSE == 2 ? Image<0, 0>::HD_SIZE : 0)) +
+                              WPB * WAVE * ROW) * sizeof(float);
+  if (lds > 64 * 1024)
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_quad_kernel<NTE, FUSE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((conv_quad_kernel<NTE, FUSE>), grid, dim3(TPB), lds, st, a);
+}
+
+// fuse: 0 = conv only (dh required); 1 / 2 = the layer's node update (2: with the output head) in the same launch
 int conv(int nt_edge, const float* img, const float* h, const float* e_s, const float* e_v,
          const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
-         const int32_t* edst, int64_t N, int64_t E, int mean, float* dh, hipStream_t st) {
+         const int32_t* edst, int64_t N, int64_t E, int mean, float* dh, int fuse, const float* img_node,
+         const float* img_head, float* h_out, float* out, const float* mask0, const float* mask1, hipStream_t st) {
   // target nodes per wave: one pass of CTN lockstep 16-edge tiles (~30 edges) per wave
   int64_t deg = N > 0 ? (E + N - 1) / N : 1;
   if (deg < 1) deg = 1;
   int npw = (int)((CTN * TILE - 2) / deg);
   npw = npw < 1 ? 1 : (npw > WAVE ? WAVE : npw);
-  ConvQArgs a{img, h, e_s, e_v, etypes, rowptr, eperm, esrc, edst, N, npw, mean, dh};
+  ConvQArgs a{img, h, e_s, e_v, etypes, rowptr, eperm, esrc, edst, N, npw, mean, dh,
+              NodeQArgs{img_node, img_head, h, nullptr, N, h_out, out, mask0, mask1}};
   const int64_t groups = (N + npw - 1) / npw;
   const dim3 grid((unsigned)((groups + WPB - 1) / WPB));
-  const size_t per_wave = (size_t)(WAVE * ROW) * sizeof(float);
+  if (nt_edge != 0 && nt_edge != 1) return CGVP_ERR_UNSUPPORTED_DIMS;
+  if (fuse < 0 || fuse > 2) return CGVP_ERR_BAD_ARG;
   if (nt_edge == 0) {
-    const size_t lds = Image<0, 0>::CV_SIZE * sizeof(float) + WPB * per_wave;
-    hipLaunchKernelGGL(conv_quad_kernel<0>, grid, dim3(TPB), lds, st, a);
-  } else if (nt_edge == 1) {
-    const size_t lds = Image<0, 1>::CV_SIZE * sizeof(float) + WPB * per_wave;
-    hipLaunchKernelGGL(conv_quad_kernel<1>, grid, dim3(TPB), lds, st, a);
+    if (fuse == 0) conv_launch<0, 0>(a, grid, st); else if (fuse == 1) conv_launch<0, 1>(a, grid, st); else conv_launch<0, 2>(a, grid, st);
   } else {
-    return CGVP_ERR_UNSUPPORTED_DIMS;
+    if (fuse == 0) conv_launch<1, 0>(a, grid, st); else if (fuse == 1) conv_launch<1, 1>(a, grid, st); else conv_launch<1, 2>(a, grid, st);
   }
   return 0;
 }

@@ -59,6 +59,8 @@ _SIGNATURES = {
                                 _P, _I64, _I64, _I32, _P, _P]),
     "cgvp_node_update_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _I32, _P, _P, _I64, _I32,
                                        _P, _P, _P]),
+    "cgvp_conv_layer_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64,
+                                      _I64, _I32, _P, _P, _I32, _P, _P, _P, _P]),
     "cgvp_node_update_fwd_train": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _P, _P, _I64,
                                              _I32, _P, _P, _P]),
     "cgvp_bwd_workspace_floats": (C.c_int64, [C.POINTER(Dims), C.POINTER(Layout)]),

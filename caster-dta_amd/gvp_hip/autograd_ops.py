@@ -49,11 +49,20 @@ class _LbaEncoderFn(torch.autograd.Function):
             _lib.check(L.cgvp_node_embed_fwd(d, lay, P, I, _ptr(x_s), _ptr(x_v), _ptr(nt), N, _ptr(hs[0]), st),
                        "cgvp_node_embed_fwd")
             for l in range(nc):
+                last = l == nc - 1
+                if ops.FUSE_LAYER:
+                    with ops._timed("conv_fwd"):
+                        _lib.check(L.cgvp_conv_layer_fwd(d, lay, I, l, _ptr(hs[l]), _ptr(e_s), _ptr(e_v), _ptr(et),
+                                                         _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc),
+                                                         _ptr(csr.edst), N, E, 1 if m["mean"] else 0,
+                                                         _ptr(masks[l][0]), _ptr(masks[l][1]), 1 if last else 0,
+                                                         _ptr(dhs[l]), _ptr(h_last if last else hs[l + 1]), _ptr(out),
+                                                         st), "cgvp_conv_layer_fwd")
+                    continue
                 with ops._timed("conv_fwd"):
                     _lib.check(L.cgvp_conv_fwd(d, lay, P, I, l, _ptr(hs[l]), _ptr(e_s), _ptr(e_v), _ptr(et),
                                                _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst),
                                                N, E, 1 if m["mean"] else 0, _ptr(dhs[l]), st), "cgvp_conv_fwd")
-                last = l == nc - 1
                 _lib.check(L.cgvp_node_update_fwd_train(d, lay, I, l, _ptr(hs[l]), _ptr(dhs[l]), _ptr(masks[l][0]),
                                                         _ptr(masks[l][1]), N, 1 if last else 0,
                                                         _ptr(h_last if last else hs[l + 1]), _ptr(out), st),

@@ -93,6 +93,8 @@ CSR_CACHE_ENABLED = True
 # "mfma": 16-item MFMA tiles fed from the fragment image (production path);
 # "simt": one item per lane straight from the arena (cross-check / A-B timing).
 VARIANT = os.environ.get("CGVP_VARIANT", "mfma")
+# MFMA path: conv + node update of a layer in one launch (CGVP_FUSE_LAYER=0: two launches, for A/B timing)
+FUSE_LAYER = os.environ.get("CGVP_FUSE_LAYER", "1") != "0"
 # bench.py's roofline leg: when this is a list, every conv launch appends a
 # (start, end) pair of timing events recorded on the launch stream.
 KERNEL_EVENTS = None
@@ -184,6 +186,19 @@ def lba_encoder_forward(params, layout, dims, num_convs, x_s, x_v, ntypes, e_s, 
         if return_stages:
             stages["node_embed"] = h.clone()
         for layer in range(num_convs):
+            if FUSE_LAYER and VARIANT == "mfma" and not return_stages:
+                # one launch per GVPConvLayer: conv + node update (+ output head); no dh buffer in inference
+                last = layer == num_convs - 1
+                with _timed("conv_fwd"):
+                    _lib.check(L.cgvp_conv_layer_fwd(d, lay, I, layer, _ptr(h), _ptr(e_s), _ptr(e_v), _ptr(et),
+                                                     _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc),
+                                                     _ptr(csr.edst), N, E, 1 if aggr_mean else 0, C.c_void_p(0),
+                                                     C.c_void_p(0), 1 if last else 0, C.c_void_p(0),
+                                                     _ptr(None if last else h2), _ptr(out), st),
+                               "cgvp_conv_layer_fwd")
+                if not last:
+                    h, h2 = h2, h
+                continue
             with _timed("conv_fwd"):
                 _lib.check(L.cgvp_conv_fwd(d, lay, P, I, layer, _ptr(h), _ptr(e_s), _ptr(e_v), _ptr(et),
                                            _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst),

@@ -135,6 +135,20 @@ int cgvp_node_update_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const
                          int64_t num_nodes, int32_t with_head, float* h_out, float* out,
                          void* stream);
 
+/* ONE launch for a whole GVPConvLayer.forward (gvp_layers.py:400-415), MFMA kernels
+ * only: cgvp_conv_fwd followed, on each wave's own target nodes and straight from
+ * its LDS rows, by cgvp_node_update_fwd[_train].  `dh` is optional (the aggregated
+ * messages, needed by the backward pass only); mask0 / mask1 as in
+ * cgvp_node_update_fwd_train (NULL in eval mode); with_head as in
+ * cgvp_node_update_fwd (h_out then optional). */
+int cgvp_conv_layer_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image,
+                        int32_t layer, const float* h, const float* e_s, const float* e_v,
+                        const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,
+                        const int32_t* esrc, const int32_t* edst, int64_t num_nodes,
+                        int64_t num_edges, int32_t aggr_mean, const float* mask0,
+                        const float* mask1, int32_t with_head, float* dh, float* h_out, float* out,
+                        void* stream);
+
 /* Training-mode variant of cgvp_node_update_fwd (MFMA kernels only): `mask0` /
  * `mask1` are the dropout masks of gvp_layers.Dropout (gvp_layers.py:187-219) for
  * dropout[0] (on dh) and dropout[1] (on the feed-forward output), one row
