@@ -50,7 +50,7 @@ class _LbaEncoderFn(torch.autograd.Function):
                        "cgvp_node_embed_fwd")
             for l in range(nc):
                 last = l == nc - 1
-                if ops.FUSE_LAYER:
+                if ops.fuse_layer(N, E):
                     with ops._timed("conv_fwd"):
                         _lib.check(L.cgvp_conv_layer_fwd(d, lay, I, l, _ptr(hs[l]), _ptr(e_s), _ptr(e_v), _ptr(et),
                                                          _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc),

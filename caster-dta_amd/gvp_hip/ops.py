@@ -95,6 +95,13 @@ CSR_CACHE_ENABLED = True
 VARIANT = os.environ.get("CGVP_VARIANT", "mfma")
 # MFMA path: conv + node update of a layer in one launch (CGVP_FUSE_LAYER=0: two launches, for A/B timing)
 FUSE_LAYER = os.environ.get("CGVP_FUSE_LAYER", "1") != "0"
+
+
+def fuse_layer(num_nodes, num_edges):
+    """The fused launch runs the node update on each conv wave's own targets (~30 / in-degree of them per
+    16-lane tile): a win for radius graphs (3-4 edges per residue), a loss for dense kNN graphs where a
+    wave owns one or two targets and would run a nearly empty node tile."""
+    return FUSE_LAYER and num_edges <= 4 * num_nodes
 # bench.py's roofline leg: when this is a list, every conv launch appends a
 # (start, end) pair of timing events recorded on the launch stream.
 KERNEL_EVENTS = None
@@ -186,7 +193,7 @@ def lba_encoder_forward(params, layout, dims, num_convs, x_s, x_v, ntypes, e_s, 
         if return_stages:
             stages["node_embed"] = h.clone()
         for layer in range(num_convs):
-            if FUSE_LAYER and VARIANT == "mfma" and not return_stages:
+            if fuse_layer(N, E) and VARIANT == "mfma" and not return_stages:
                 # one launch per GVPConvLayer: conv + node update (+ output head); no dh buffer in inference
                 last = layer == num_convs - 1
                 with _timed("conv_fwd"):

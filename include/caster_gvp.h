@@ -140,7 +140,9 @@ int cgvp_node_update_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const
  * its LDS rows, by cgvp_node_update_fwd[_train].  `dh` is optional (the aggregated
  * messages, needed by the backward pass only); mask0 / mask1 as in
  * cgvp_node_update_fwd_train (NULL in eval mode); with_head as in
- * cgvp_node_update_fwd (h_out then optional). */
+ * cgvp_node_update_fwd (h_out then optional).  Pays off when a conv wave owns many
+ * targets (about 30 / average in-degree of them share one 16-lane node tile): the
+ * host code uses it for num_edges <= 4 * num_nodes and the two-launch form otherwise. */
 int cgvp_conv_layer_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image,
                         int32_t layer, const float* h, const float* e_s, const float* e_v,
                         const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,
