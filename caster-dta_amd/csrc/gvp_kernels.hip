@@ -88,15 +88,29 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int32_t* __restrict__ cn
   int32_t sum = 0;
   if (in_lds) { for (int64_t i = lo; i < hi; ++i) sum += sbuf[i]; }      // two loops: keeps LDS / global
   else { for (int64_t i = lo; i < hi; ++i) sum += cnt[i]; }              // addressing explicit (no flat)
-  part[t] = sum;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    int32_t v = (t >= off) ? part[t - off] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
+  // inclusive scan of the 1024 per-thread sums: shuffles inside each wave, the 16 wave totals through
+  // LDS (2 barriers instead of the 20 of a block-wide Hillis-Steele)
+  int32_t inc = sum;
+#pragma unroll
+  for (int off = 1; off < WAVE; off <<= 1) {
+    const int32_t v = __shfl_up(inc, off);
+    if ((t & (WAVE - 1)) >= off) inc += v;
   }
-  int32_t run = part[t] - sum;   // exclusive prefix of this thread's chunk
+  if ((t & (WAVE - 1)) == WAVE - 1) part[t >> 6] = inc;
+  __syncthreads();
+  if (t < 16) {
+    int32_t w = part[t];
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const int32_t v = __shfl_up(w, off, 16);
+      if (t >= off) w += v;
+    }
+    part[16 + t] = w;            // inclusive totals of waves 0..t
+  }
+  __syncthreads();
+  const int32_t wave_base = (t >> 6) > 0 ? part[16 + (t >> 6) - 1] : 0;
+  const int32_t total = part[31];
+  int32_t run = wave_base + inc - sum;   // exclusive prefix of this thread's chunk
   if (in_lds) {
     for (int64_t i = lo; i < hi; ++i) { const int32_t c = sbuf[i]; sbuf[i] = run; run += c; }
     __syncthreads();
@@ -104,7 +118,7 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int32_t* __restrict__ cn
   } else {
     for (int64_t i = lo; i < hi; ++i) { const int32_t c = cnt[i]; rowptr[i] = run; cnt[i] = run; run += c; }
   }
-  if (t == 1023) rowptr[N] = part[1023];
+  if (t == 1023) rowptr[N] = total;
 }
 
 __global__ void csr_fill_kernel(const int64_t* __restrict__ ei, int64_t N, int64_t E,
