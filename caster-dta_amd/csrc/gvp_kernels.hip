@@ -152,6 +152,31 @@ __global__ void csr_finish_kernel(const int64_t* __restrict__ ei, int64_t N, int
   }
 }
 
+// Batch CSR by CONCATENATION of per-graph CSRs (a dataset's few hundred unique
+// graphs are sorted once; a batch is their blocks shifted by node / edge offsets).  One workgroup
+// per batch slot; `sel[b]` is the slot's graph in the store, whose tables hold LOCAL indices.
+struct CsrCollateArgs {
+  const int32_t* st_rowptr; const int32_t* st_eperm; const int32_t* st_esrc; const int32_t* st_edst;
+  const int64_t* st_node_off; const int64_t* st_edge_off;      // [G+1] prefix sums over the store's graphs
+  const int64_t* sel; const int64_t* b_node_off; const int64_t* b_edge_off;   // [B], [B+1], [B+1]
+  int64_t B; int32_t* rowptr; int32_t* eperm; int32_t* esrc; int32_t* edst;
+};
+__global__ __launch_bounds__(256) void csr_collate_kernel(CsrCollateArgs a) {
+  const int64_t b = blockIdx.x;
+  const int64_t g = a.sel[b];
+  const int64_t sn = a.st_node_off[g], se = a.st_edge_off[g];
+  const int64_t n = a.st_node_off[g + 1] - sn, e = a.st_edge_off[g + 1] - se;
+  const int64_t bn = a.b_node_off[b], be = a.b_edge_off[b];
+  const int32_t* rp = a.st_rowptr + sn + g;                     // every graph stores n + 1 row pointers
+  for (int64_t k = threadIdx.x; k < n; k += 256) a.rowptr[bn + k] = (int32_t)(be + rp[k]);
+  if (b == a.B - 1 && threadIdx.x == 0) a.rowptr[bn + n] = (int32_t)(be + e);
+  for (int64_t k = threadIdx.x; k < e; k += 256) {
+    a.eperm[be + k] = (int32_t)(be + a.st_eperm[se + k]);
+    a.esrc[be + k] = (int32_t)(bn + a.st_esrc[se + k]);
+    a.edst[be + k] = (int32_t)(bn + a.st_edst[se + k]);
+  }
+}
+
 // Launder the arena pointer through an empty asm so the optimiser cannot hoist
 // (loop-invariant) weight addresses / constant-space loads out of a loop body
 // and then spill them: weights are re-read from the scalar cache per iteration.
@@ -498,6 +523,19 @@ int cgvp_csr_from_coo(const int64_t* edge_index, int64_t N, int64_t E, int32_t* 
   hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), (size_t)((N <= SCAN_LDS ? N : 0) + 1024) * sizeof(int32_t), s, work, N, rowptr);
   if (E > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, work, eperm);
   if (N > 0 && E > 0) hipLaunchKernelGGL(csr_finish_kernel, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, rowptr, eperm, esrc, edst);
+  return launch_status();
+}
+
+int cgvp_csr_collate(const int32_t* st_rowptr, const int32_t* st_eperm, const int32_t* st_esrc,
+                     const int32_t* st_edst, const int64_t* st_node_off, const int64_t* st_edge_off,
+                     const int64_t* sel, const int64_t* b_node_off, const int64_t* b_edge_off, int64_t B,
+                     int32_t* rowptr, int32_t* eperm, int32_t* esrc, int32_t* edst, void* stream) {
+  if (B < 0 || !rowptr) return CGVP_ERR_BAD_ARG;
+  if (B == 0) return 0;
+  if (!st_rowptr || !st_node_off || !st_edge_off || !sel || !b_node_off || !b_edge_off) return CGVP_ERR_BAD_ARG;
+  CsrCollateArgs a{st_rowptr, st_eperm, st_esrc, st_edst, st_node_off, st_edge_off, sel, b_node_off, b_edge_off, B,
+                   rowptr, eperm, esrc, edst};
+  hipLaunchKernelGGL(csr_collate_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 

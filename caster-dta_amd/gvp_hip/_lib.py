@@ -51,6 +51,7 @@ _SIGNATURES = {
     "cgvp_abi_version": (C.c_int, []),
     "cgvp_build_info": (C.c_char_p, []),
     "cgvp_csr_from_coo": (C.c_int, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P]),
+    "cgvp_csr_collate": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P]),
     "cgvp_lba_layout": (C.c_int, [C.POINTER(Dims), _I32, _I32, _I32, C.POINTER(Layout)]),
     "cgvp_lba_image_floats": (C.c_int64, [C.POINTER(Dims), C.POINTER(Layout)]),
     "cgvp_lba_prepare": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _P]),

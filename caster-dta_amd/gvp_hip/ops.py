@@ -89,6 +89,55 @@ def build_csr(edge_index, num_nodes):
     return Csr(rowptr, eperm, esrc, edst, num_nodes, E)
 
 
+class CsrStore:
+    """Per-graph CSR tables of a dataset's UNIQUE graphs, sorted once, and batches assembled from them by
+    concatenation (the reference stores unique protein / drug graphs and lets pairs index
+    into them, dataset/dual_dataset.py:123-125).  `collate(ids, attach_to=edge_index)` builds the batch
+    tables in one small launch and memoises them on the batch's edge_index tensor, where the encoders'
+    `cached_csr` finds them -- the models need no other change."""
+
+    def __init__(self, edge_indices, num_nodes):
+        """edge_indices: list of [2, E_g] int64 CUDA tensors with LOCAL node ids; num_nodes: list of ints."""
+        csrs = [build_csr(ei, n) for ei, n in zip(edge_indices, num_nodes)]
+        dev = edge_indices[0].device
+        self.device = dev
+        self.nodes = [int(n) for n in num_nodes]
+        self.edges = [c.num_edges for c in csrs]
+        self.rowptr = torch.cat([c.rowptr for c in csrs])
+        self.eperm = torch.cat([c.eperm[:c.num_edges] for c in csrs] + [torch.zeros(1, dtype=torch.int32, device=dev)])
+        self.esrc = torch.cat([c.esrc[:c.num_edges] for c in csrs] + [torch.zeros(1, dtype=torch.int32, device=dev)])
+        self.edst = torch.cat([c.edst[:c.num_edges] for c in csrs] + [torch.zeros(1, dtype=torch.int32, device=dev)])
+        self.node_off = torch.tensor([0] + list(torch.tensor(self.nodes).cumsum(0)), dtype=torch.int64, device=dev)
+        self.edge_off = torch.tensor([0] + list(torch.tensor(self.edges).cumsum(0)), dtype=torch.int64, device=dev)
+
+    def plan(self, ids):
+        """Device-side description of a batch (graph ids in batch order): reusable across steps."""
+        n = torch.tensor([self.nodes[i] for i in ids]).cumsum(0)
+        e = torch.tensor([self.edges[i] for i in ids]).cumsum(0)
+        dev = self.device
+        return dict(sel=torch.tensor(list(ids), dtype=torch.int64, device=dev),
+                    node_off=torch.cat([torch.zeros(1, dtype=torch.int64), n]).to(dev),
+                    edge_off=torch.cat([torch.zeros(1, dtype=torch.int64), e]).to(dev),
+                    N=int(n[-1]), E=int(e[-1]), B=len(ids))
+
+    def collate(self, plan, attach_to=None):
+        dev = self.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        N, E = plan["N"], plan["E"]
+        rowptr = torch.empty(N + 1, **i32)
+        eperm, esrc, edst = (torch.empty(max(E, 1), **i32) for _ in range(3))
+        with torch.cuda.device(dev):
+            rc = _lib.lib().cgvp_csr_collate(_ptr(self.rowptr), _ptr(self.eperm), _ptr(self.esrc), _ptr(self.edst),
+                                             _ptr(self.node_off), _ptr(self.edge_off), _ptr(plan["sel"]),
+                                             _ptr(plan["node_off"]), _ptr(plan["edge_off"]), plan["B"], _ptr(rowptr),
+                                             _ptr(eperm), _ptr(esrc), _ptr(edst), _stream())
+        _lib.check(rc, "cgvp_csr_collate")
+        csr = Csr(rowptr, eperm, esrc, edst, N, E)
+        if attach_to is not None:
+            attach_to._cgvp_csr = (attach_to._version, csr)
+        return csr
+
+
 CSR_CACHE_ENABLED = True
 # "mfma": 16-item MFMA tiles fed from the fragment image (production path);
 # "simt": one item per lane straight from the arena (cross-check / A-B timing).

@@ -86,6 +86,21 @@ int cgvp_csr_from_coo(const int64_t* edge_index, int64_t num_nodes, int64_t num_
                       int32_t* rowptr, int32_t* eperm, int32_t* esrc, int32_t* edst,
                       int32_t* work, void* stream);
 
+/* The same tables for a batch assembled from graphs whose CSR is already known (the
+ * reference's datasets reuse a few hundred unique protein / drug graphs across tens of
+ * thousands of pairs, dataset/dual_dataset.py:123-125): a STORE holds the per-graph
+ * tables back to back with LOCAL node / edge indices (graph g: st_node_off[g+1] -
+ * st_node_off[g] nodes and as many + 1 row pointers at st_rowptr + st_node_off[g] + g;
+ * its edges at st_edge_off[g]); batch slot b takes graph sel[b] and places it at node
+ * offset b_node_off[b], edge offset b_edge_off[b] (all offset arrays are device int64
+ * prefix sums).  Equivalent to cgvp_csr_from_coo on the concatenated edge_index
+ * (PyG Batch.from_data_list order), in ONE small launch instead of a memset and four. */
+int cgvp_csr_collate(const int32_t* st_rowptr, const int32_t* st_eperm, const int32_t* st_esrc,
+                     const int32_t* st_edst, const int64_t* st_node_off, const int64_t* st_edge_off,
+                     const int64_t* sel, const int64_t* b_node_off, const int64_t* b_edge_off,
+                     int64_t batch_graphs, int32_t* rowptr, int32_t* eperm, int32_t* esrc,
+                     int32_t* edst, void* stream);
+
 /* Fill `out` with the arena layout for the given one-hot widths and depth.
  * Host-only, no GPU work. */
 int cgvp_lba_layout(const cgvp_dims* dims, int32_t num_ntypes, int32_t num_etypes,

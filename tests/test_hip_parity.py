@@ -189,3 +189,24 @@ def test_unsupported_dims_fail_loudly(protein_params):
         _run_lba(protein_params, bad)
     with pytest.raises(RuntimeError):
         ops.build_csr(d["edge_index"], gb.num_nodes)      # CPU tensor: no CPU path
+
+
+def test_csr_collate_equals_from_coo():
+    """Batch CSR assembled from per-graph CSRs (one launch) == CSR built from the concatenated edge_index."""
+    gb = ds.protein_batch(7, 21, lengths=[1, 40, 300, 2, 129, 64, 33])
+    ptr, eptr = [int(v) for v in gb.ptr], [int(v) for v in gb.eptr]
+    ei = torch.as_tensor(gb.edge_index, dtype=torch.int64)
+    graphs = [(ei[:, eptr[g]:eptr[g + 1]] - ptr[g]).contiguous().to(DEV) for g in range(gb.num_graphs)]
+    sizes = [ptr[g + 1] - ptr[g] for g in range(gb.num_graphs)]
+    store = ops.CsrStore(graphs, sizes)
+    order = [3, 0, 6, 2, 2, 5, 1, 4]                       # a batch may repeat a graph and reorder them
+    batch_ei = torch.cat([graphs[g] + off for g, off in zip(order, [0] + list(torch.tensor([sizes[g] for g in order]).cumsum(0)[:-1]))], dim=1)
+    plan = store.plan(order)
+    got = store.collate(plan, attach_to=batch_ei)
+    ref = ops.build_csr(batch_ei, plan["N"])
+    assert plan["E"] == ref.num_edges
+    for name in ("rowptr", "eperm", "esrc", "edst"):
+        a, b = getattr(got, name), getattr(ref, name)
+        n = plan["N"] + 1 if name == "rowptr" else plan["E"]
+        assert torch.equal(a[:n].cpu(), b[:n].cpu()), name
+    assert ops.cached_csr(batch_ei, plan["N"]) is got      # the encoders pick the attached tables up
