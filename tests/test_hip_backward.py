@@ -67,12 +67,14 @@ def test_backward_golden(lba_small, protein_params):
     assert rel_err(xv.grad, g["gin_x_v"]) < 2e-4
 
 
-@pytest.mark.parametrize("case", ["c1_davis16_sum", "knn_mean", "depth4_ragged"])
+@pytest.mark.parametrize("case", ["c1_davis16_sum", "knn_mean", "radius_mean", "depth4_ragged"])
 def test_backward_vs_oracle_autograd(protein_params, case):
     if case == "c1_davis16_sum":
         gb, nc, aggr, state = ds.protein_batch(16, 1), 2, "sum", protein_params
     elif case == "knn_mean":
         gb, nc, aggr, state = ds.protein_batch(2, 2, length=150, thresh=20, thresh_type="num"), 2, "mean", protein_params
+    elif case == "radius_mean":                # sparse graph: the fused conv + node-update launch, with aggr='mean'
+        gb, nc, aggr, state = ds.protein_batch(3, 7, lengths=[40, 77, 120]), 2, "mean", protein_params
     else:
         gb, nc, aggr, state = ds.protein_batch(4, 3, lengths=[1, 17, 64, 33], thresh=7.0), 4, "sum", None
     model = _encoder(state, nc, aggr, seed=5).eval()
