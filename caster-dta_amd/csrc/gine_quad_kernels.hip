@@ -656,7 +656,8 @@ int launch(GineQArgs& a, int* rows, int* row_len, hipStream_t st) {
   constexpr int GQ_WPB = Q::WPB, GQ_TPB = Q::TPB;
   const int64_t tiles = (a.N + TILE - 1) / TILE;
   int64_t wgs = (tiles + GQ_WPB - 1) / GQ_WPB;
-  const int G = (int)(wgs < 1 ? 1 : (wgs > quad::kGineBwdMaxGrid ? quad::kGineBwdMaxGrid : wgs));
+  const int cap = quad::gine_bwd_grid(0);
+  const int G = (int)(wgs < 1 ? 1 : (wgs > cap ? cap : wgs));
   const size_t lds = (size_t)Q::LDS_FLOATS * sizeof(float);
   hipFuncSetAttribute(reinterpret_cast<const void*>(gine_quad_bwd_kernel<CIN, CHID, COUT, NT, NET, ED>),
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -669,6 +670,12 @@ int launch(GineQArgs& a, int* rows, int* row_len, hipStream_t st) {
 }  // namespace
 
 namespace quad {
+
+int gine_bwd_grid(int set_to) {
+  static int cap = kGineBwdDefaultGrid;
+  if (set_to > 0) cap = set_to > kGineBwdMaxGrid ? kGineBwdMaxGrid : set_to;
+  return cap;
+}
 
 int gine_bwd(int cin, int chid, int cout, int nt, int net, int ed, const float* x, const int64_t* ntypes,
              const float* eattr, const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,

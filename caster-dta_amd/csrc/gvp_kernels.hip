@@ -832,6 +832,8 @@ int cgvp_bwd_reduce(const cgvp_segment* segs, int32_t nsegs, float* grad_params,
 
 int64_t cgvp_gine_bwd_workspace_floats(void) { return (int64_t)quad::kGineBwdMaxGrid * gine_layer_floats(16, 64, 64, 14); }
 
+int cgvp_gine_bwd_workgroups(int32_t set_to) { return quad::gine_bwd_grid(set_to); }
+
 int cgvp_gine_conv_bwd(const float* x, const int64_t* ntypes, int32_t num_ntypes, const float* eattr,
                        const int64_t* etypes, int32_t num_etypes, int32_t edge_dim, const int32_t* rowptr,
                        const int32_t* eperm, const int32_t* esrc, const int32_t* edst, int64_t N, int64_t E,

@@ -75,6 +75,7 @@ _SIGNATURES = {
     "cgvp_gine_conv_fwd": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32,
                                      _I32, C.POINTER(GineW), C.c_float, _P, _I32, _P, _P]),
     "cgvp_gine_bwd_workspace_floats": (C.c_int64, []),
+    "cgvp_gine_bwd_workgroups": (C.c_int, [_I32]),
     "cgvp_gine_conv_bwd": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32,
                                      C.POINTER(GineW), C.c_float, _P, _P, _P, _P, _P, _P]),
 }

@@ -286,6 +286,11 @@ int cgvp_gine_conv_fwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
  * CASTER-DTA layer shapes (52,16,16), (16,64,64), (16,16,16) with 11 / 0 atom
  * types, 5 bond types, 9 bond features. */
 int64_t cgvp_gine_bwd_workspace_floats(void);
+/* Cap on the workgroups (= CUs) of cgvp_gine_conv_bwd.  Default 16: inside CASTER-DTA the
+ * drug backward runs beside the protein backward, whose kernels own 240 of the 256 CUs.
+ * A caller that trains the molecule encoder alone raises it (<= 256).  set_to <= 0 only
+ * queries; returns the value in force.  Process-wide, not thread-safe. */
+int cgvp_gine_bwd_workgroups(int32_t set_to);
 int cgvp_gine_conv_bwd(const float* x, const int64_t* ntypes, int32_t num_ntypes, const float* eattr,
                        const int64_t* etypes, int32_t num_etypes, int32_t edge_dim,
                        const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
