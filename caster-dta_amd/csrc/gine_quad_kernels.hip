@@ -644,23 +644,24 @@ int launch_fwd(GineFArgs& a, hipStream_t st) {
   int64_t wgs = (tiles + GF_WPB - 1) / GF_WPB;
   const int G = (int)(wgs < 1 ? 1 : (wgs > 1024 ? 1024 : wgs));
   const size_t lds = (size_t)((Q::GE::NFRAG + Q::G0::NFRAG + Q::G1::NFRAG) * 64 + GF_WPB * Q::ROWS) * sizeof(float);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(gine_quad_fwd_kernel<CIN, CHID, COUT, NT, NET, ED>),
-                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(gine_quad_fwd_kernel<CIN, CHID, COUT, NT, NET, ED>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+    return (int)err;
   hipLaunchKernelGGL((gine_quad_fwd_kernel<CIN, CHID, COUT, NT, NET, ED>), dim3(G), dim3(GF_TPB), lds, st, a);
   return 0;
 }
 
 template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
-int launch(GineQArgs& a, int* rows, int* row_len, hipStream_t st) {
+int launch(GineQArgs& a, int cap, int* rows, int* row_len, hipStream_t st) {
   typedef GineQ<CIN, CHID, COUT, NT, NET, ED> Q;
   constexpr int GQ_WPB = Q::WPB, GQ_TPB = Q::TPB;
   const int64_t tiles = (a.N + TILE - 1) / TILE;
   int64_t wgs = (tiles + GQ_WPB - 1) / GQ_WPB;
-  const int cap = quad::gine_bwd_grid(0);
   const int G = (int)(wgs < 1 ? 1 : (wgs > cap ? cap : wgs));
   const size_t lds = (size_t)Q::LDS_FLOATS * sizeof(float);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(gine_quad_bwd_kernel<CIN, CHID, COUT, NT, NET, ED>),
-                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(gine_quad_bwd_kernel<CIN, CHID, COUT, NT, NET, ED>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+    return (int)err;
   hipLaunchKernelGGL((gine_quad_bwd_kernel<CIN, CHID, COUT, NT, NET, ED>), dim3(G), dim3(GQ_TPB), lds, st, a);
   *rows = G;
   *row_len = Q::L_SIZE;
@@ -671,23 +672,18 @@ int launch(GineQArgs& a, int* rows, int* row_len, hipStream_t st) {
 
 namespace quad {
 
-int gine_bwd_grid(int set_to) {
-  static int cap = kGineBwdDefaultGrid;
-  if (set_to > 0) cap = set_to > kGineBwdMaxGrid ? kGineBwdMaxGrid : set_to;
-  return cap;
-}
-
 int gine_bwd(int cin, int chid, int cout, int nt, int net, int ed, const float* x, const int64_t* ntypes,
              const float* eattr, const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,
              const int32_t* esrc, const int32_t* edst, int64_t N, const cgvp_gine_w* w, float slope,
-             const float* mask, const float* g_out, float* g_x, float* slab, int* rows, int* row_len,
-             hipStream_t st) {
+             const float* mask, const float* g_out, float* g_x, float* slab, int max_workgroups, int* rows,
+             int* row_len, hipStream_t st) {
+  const int cap = max_workgroups <= 0 ? kGineBwdDefaultGrid : (max_workgroups > kGineBwdMaxGrid ? kGineBwdMaxGrid : max_workgroups);
   GineQArgs a{x, ntypes, eattr, etypes, rowptr, eperm, esrc, edst, N, w->eps, w->we, w->be, w->w0, w->b0,
               w->w1, w->b1, slope, mask, g_out, g_x, slab};
   // compiled for the layer shapes of HomoMoleculeGNN_GINE in CASTER-DTA (molecule_gnn.py:240-250)
-  if (cin == 52 && chid == 16 && cout == 16 && nt == 11 && net == 5 && ed == 9) return launch<52, 16, 16, 11, 5, 9>(a, rows, row_len, st);
-  if (cin == 16 && chid == 64 && cout == 64 && nt == 0 && net == 5 && ed == 9) return launch<16, 64, 64, 0, 5, 9>(a, rows, row_len, st);
-  if (cin == 16 && chid == 16 && cout == 16 && nt == 0 && net == 5 && ed == 9) return launch<16, 16, 16, 0, 5, 9>(a, rows, row_len, st);   // middle layers of deeper stacks
+  if (cin == 52 && chid == 16 && cout == 16 && nt == 11 && net == 5 && ed == 9) return launch<52, 16, 16, 11, 5, 9>(a, cap, rows, row_len, st);
+  if (cin == 16 && chid == 64 && cout == 64 && nt == 0 && net == 5 && ed == 9) return launch<16, 64, 64, 0, 5, 9>(a, cap, rows, row_len, st);
+  if (cin == 16 && chid == 16 && cout == 16 && nt == 0 && net == 5 && ed == 9) return launch<16, 16, 16, 0, 5, 9>(a, cap, rows, row_len, st);   // middle layers of deeper stacks
   return CGVP_ERR_UNSUPPORTED_DIMS;
 }
 

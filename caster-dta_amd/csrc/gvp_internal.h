@@ -49,12 +49,11 @@ int node_embed_bwd(int nt_node, const float* img, const float* imgT, const float
 // (`rows` x `row_len` floats, state_dict order of the layer).
 constexpr int kGineBwdMaxGrid = 256;      // upper bound (workspace sizing)
 constexpr int kGineBwdDefaultGrid = 16;   // the CUs the protein backward (kBwdMaxGrid workgroups, one per CU) leaves free
-int gine_bwd_grid(int set_to);            // current cap on the GINE backward's workgroups; set_to > 0 changes it
 int gine_bwd(int cin, int chid, int cout, int nt, int net, int ed, const float* x, const int64_t* ntypes,
              const float* eattr, const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,
              const int32_t* esrc, const int32_t* edst, int64_t N, const cgvp_gine_w* w, float slope,
-             const float* mask, const float* g_out, float* g_x, float* slab, int* rows, int* row_len,
-             hipStream_t st);
+             const float* mask, const float* g_out, float* g_x, float* slab, int max_workgroups, int* rows,
+             int* row_len, hipStream_t st);
 int gine_fwd(int cin, int chid, int cout, int nt, int net, int ed, const float* x, const int64_t* ntypes,
              const float* eattr, const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,
              const int32_t* esrc, const int32_t* edst, int64_t N, const cgvp_gine_w* w, float slope,

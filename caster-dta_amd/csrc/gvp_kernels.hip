@@ -832,14 +832,12 @@ int cgvp_bwd_reduce(const cgvp_segment* segs, int32_t nsegs, float* grad_params,
 
 int64_t cgvp_gine_bwd_workspace_floats(void) { return (int64_t)quad::kGineBwdMaxGrid * gine_layer_floats(16, 64, 64, 14); }
 
-int cgvp_gine_bwd_workgroups(int32_t set_to) { return quad::gine_bwd_grid(set_to); }
-
 int cgvp_gine_conv_bwd(const float* x, const int64_t* ntypes, int32_t num_ntypes, const float* eattr,
                        const int64_t* etypes, int32_t num_etypes, int32_t edge_dim, const int32_t* rowptr,
                        const int32_t* eperm, const int32_t* esrc, const int32_t* edst, int64_t N, int64_t E,
                        int32_t cin, int32_t chid, int32_t cout, const cgvp_gine_w* w, float act_slope,
                        const float* mask, const float* g_out, float* g_x, float* grad_layer, float* workspace,
-                       void* stream) {
+                       int32_t max_workgroups, void* stream) {
   if (N < 0 || E < 0 || !w || !grad_layer || !workspace) return CGVP_ERR_BAD_ARG;
   if (N == 0) return 0;
   if (!x || !g_out || !rowptr || (num_ntypes > 0 && !ntypes)) return CGVP_ERR_BAD_ARG;
@@ -852,7 +850,7 @@ int cgvp_gine_conv_bwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
   }
   int rows = 0, row_len = 0;
   if (int rc = quad::gine_bwd(cin, chid, cout, num_ntypes, num_etypes, edge_dim, x, ntypes, eattr, etypes, rowptr, eperm,
-                              esrc, edst, N, w, act_slope, mask, g_out, g_x, workspace, &rows, &row_len, st)) return rc;
+                              esrc, edst, N, w, act_slope, mask, g_out, g_x, workspace, max_workgroups, &rows, &row_len, st)) return rc;
   quad::reduce_slab(workspace, rows, row_len, 0, row_len, grad_layer, st);
   return launch_status();
 }

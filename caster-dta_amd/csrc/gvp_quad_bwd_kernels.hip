@@ -783,7 +783,7 @@ int node_update_bwd(const float* img_node, const float* imgT_node, const float* 
   const int G = grid_for((N + TILE - 1) / TILE);
   *grid = G;
   const size_t lds = (size_t)node_bwd_lds_floats() * sizeof(float);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(node_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(node_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return (int)err;
   hipLaunchKernelGGL(node_bwd_kernel, dim3(G), dim3(BW_TPB), lds, st, a);
   return 0;
 }
@@ -794,7 +794,7 @@ int head_bwd(const float* img_head, const float* imgT_head, const float* h_out, 
   const int G = grid_for((N + TILE - 1) / TILE);
   *grid = G;
   const size_t lds = (size_t)head_bwd_lds_floats() * sizeof(float);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(head_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(head_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return (int)err;
   hipLaunchKernelGGL(head_bwd_kernel, dim3(G), dim3(BW_TPB), lds, st, a);
   return 0;
 }
@@ -807,7 +807,7 @@ int conv_bwd_impl(ConvBArgs& a, int* grid, hipStream_t st) {
   const int G = (int)(cwg < 1 ? 1 : (cwg > CB_MAX_GRID ? CB_MAX_GRID : cwg));     // one workgroup per CU, one slab row each
   *grid = G;
   const size_t lds = (size_t)conv_bwd_lds_floats<NTE>() * sizeof(float);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_kernel<NTE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_kernel<NTE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return (int)err;
   hipLaunchKernelGGL(conv_bwd_kernel<NTE>, dim3(G), dim3(CB_TPB), lds, st, a);
   return 0;
 }
@@ -831,7 +831,7 @@ int embed_bwd_impl(EmbBArgs& a, int* grid, hipStream_t st) {
   const int G = grid_for((a.N + TILE - 1) / TILE);
   *grid = G;
   const size_t lds = (size_t)embed_bwd_lds_floats<NTN>() * sizeof(float);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel<NTN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel<NTN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return (int)err;
   hipLaunchKernelGGL(embed_bwd_kernel<NTN>, dim3(G), dim3(BW_TPB), lds, st, a);
   return 0;
 }

@@ -574,8 +574,8 @@ template <int NTE, int FUSE>
 void conv_launch(const ConvQArgs& a, dim3 grid, hipStream_t st) {
   const size_t lds = (size_t)(Image<0, NTE>::CV_SIZE + (FUSE == 0 ? 0 : Image<0, 0>::ND_SIZE + (FUSE == 2 ? Image<0, 0>::HD_SIZE : 0)) +
                               WPB * WAVE * ROW) * sizeof(float);
-  if (lds > 64 * 1024)
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_quad_kernel<NTE, FUSE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 64 * 1024)      // a failure here resurfaces as the launch error launch_status() reports
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_quad_kernel<NTE, FUSE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((conv_quad_kernel<NTE, FUSE>), grid, dim3(TPB), lds, st, a);
 }
 

@@ -224,6 +224,18 @@ def drug_batch(n_graphs, seed, n_atoms=None, num_ntypes=11):
     return collate([drug_graph(rng, n_atoms, num_ntypes) for _ in range(n_graphs)])
 
 
+def real_lengths(dataset, n, seed):
+    """`n` protein lengths drawn (seeded, with replacement) from the sequence lengths of the reference's
+    Davis / KIBA protein tables (data/deepdta_data/{davis,kiba}/proteins.txt; only the integer lengths are
+    kept, in tests/golden/protein_lengths.json -- generator: tests/golden/make_length_stats.py)."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                        "protein_lengths.json")
+    table = np.asarray(json.load(open(path))[dataset])
+    return [int(v) for v in np.random.default_rng(seed).choice(table, size=n, replace=True)]
+
+
 def pair_batch(n_pairs, seed, length=300, thresh=4.0, thresh_type="dist", lengths=None):
     """One batch of protein/drug pairs (the unit of the graph-pairs/sec metric)."""
     return (protein_batch(n_pairs, seed, length, thresh, thresh_type, lengths),

@@ -15,7 +15,11 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CGVP_LIB_PATH: A/B builds of the same ABI (diagnostics); the default is the in-tree library
 LIB_PATH = os.environ.get("CGVP_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libcaster_gvp.so")
-ABI_VERSION = 6
+ABI_VERSION = 14
+# sha256 of include/caster_gvp.h with comments, blank space and the CGVP_ABI_VERSION line removed, as
+# `abi_header_digest()` computes it.  tests/test_abi.py fails when the header's declarations change
+# without CGVP_ABI_VERSION, ABI_VERSION and this digest being updated together.
+ABI_HEADER_SHA256 = "d3742d08cd34b44890e21bb3102362066447fc91a4dc006ac27ca31039704869"
 
 
 class HipLibraryError(RuntimeError):
@@ -75,12 +79,24 @@ _SIGNATURES = {
     "cgvp_gine_conv_fwd": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32,
                                      _I32, C.POINTER(GineW), C.c_float, _P, _I32, _P, _P]),
     "cgvp_gine_bwd_workspace_floats": (C.c_int64, []),
-    "cgvp_gine_bwd_workgroups": (C.c_int, [_I32]),
     "cgvp_gine_conv_bwd": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32,
-                                     C.POINTER(GineW), C.c_float, _P, _P, _P, _P, _P, _P]),
+                                     C.POINTER(GineW), C.c_float, _P, _P, _P, _P, _P, _I32, _P]),
 }
 
 _lib = None
+
+
+def abi_header_digest(path=None):
+    """Digest of the declarations in include/caster_gvp.h (comments / whitespace / the version define do not
+    count)."""
+    import hashlib
+    import re
+    path = path or os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "caster_gvp.h")
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    text = "\n".join(l for l in text.splitlines() if "CGVP_ABI_VERSION" not in l)
+    return hashlib.sha256(re.sub(r"\s+", "", text).encode()).hexdigest()
 
 
 def exported_symbols():

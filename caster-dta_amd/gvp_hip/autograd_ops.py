@@ -208,7 +208,7 @@ class _GineEncoderFn(torch.autograd.Function):
                                           _ptr(eattr), _ptr(et), m["num_etypes"], edge_dim, _ptr(csr.rowptr),
                                           _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst), N, csr.num_edges, cin, cout, cout,
                                           C.byref(gw), float(m["slope"]), _ptr(masks[l]), _ptr(g), _ptr(g_x),
-                                          _ptr(glayer), _ptr(wsp), _stream())
+                                          _ptr(glayer), _ptr(wsp), int(m.get("bwd_workgroups", 0)), _stream())
                 _lib.check(rc, "cgvp_gine_conv_bwd")
                 off = 0
                 for j, k in enumerate(_GINE_KEYS):
@@ -218,7 +218,7 @@ class _GineEncoderFn(torch.autograd.Function):
         return (None, g if ctx.needs_input_grad[1] else None, None) + tuple(grads)
 
 
-def gine_encoder(model, x, ntypes, eattr, etypes, csr, slope, train_dropout):
+def gine_encoder(model, x, ntypes, eattr, etypes, csr, slope, train_dropout, bwd_workgroups=0):
     """HomoMoleculeGNN_GINE.forward with autograd (and inter-layer dropout when training)."""
     if eattr.requires_grad:
         raise NotImplementedError("gradients w.r.t. bond features are not produced by the backward kernels")
@@ -228,5 +228,5 @@ def gine_encoder(model, x, ntypes, eattr, etypes, csr, slope, train_dropout):
         params += [kw[k] for k in _GINE_KEYS]
     meta = dict(widths=model._widths, ntypes=ntypes, etypes=etypes, num_ntypes=model.num_ntypes,
                 num_etypes=model.num_etypes, csr=csr, slope=slope,
-                dropout=float(model.dropout_rate) if train_dropout else 0.0)
+                dropout=float(model.dropout_rate) if train_dropout else 0.0, bwd_workgroups=bwd_workgroups)
     return _GineEncoderFn.apply(meta, x, eattr, *params)

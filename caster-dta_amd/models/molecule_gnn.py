@@ -149,6 +149,9 @@ class HomoMoleculeGNN_GINE(BaseMoleculeGNN):
             GINEConv(MLP([a, b, b]), gin_trainable_eps, edge_w, a, aggr=self.aggr)
             for a, b in zip(widths[:-1], widths[1:])])
         self._widths = widths
+        # cap on the CUs of the GINE backward (0 = the library default of 16, sized to run beside the protein
+        # backward inside JointGNN); a caller training this encoder alone may raise it (<= 256)
+        self.bwd_workgroups = 0
 
     def forward(self, x, edge_index, ntypes, etypes, eattr=None, batch=None):
         slope = activation_slope(self.activation)
@@ -165,7 +168,8 @@ class HomoMoleculeGNN_GINE(BaseMoleculeGNN):
         train_dropout = self.training and self.dropout_rate > 0 and self.num_convs > 1
         if needs_grad or train_dropout:
             from gvp_hip import autograd_ops
-            return autograd_ops.gine_encoder(self, x, ntypes, eattr, etypes, csr, slope, train_dropout)
+            return autograd_ops.gine_encoder(self, x, ntypes, eattr, etypes, csr, slope, train_dropout,
+                                             bwd_workgroups=self.bwd_workgroups)
         h = x
         for l, conv in enumerate(self.conv_list):
             first = l == 0

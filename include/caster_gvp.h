@@ -27,14 +27,14 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 6
+#define CGVP_ABI_VERSION 14
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
 /* PARAMETER ARENA.  All weights of VectorProteinGNN_LBAModel live in ONE
  * contiguous fp32 buffer, in the reference's state_dict order with the
  * zero-size dummy_params skipped (protein_gnn.py:325-358; key list in
- * pretrained_model_downstream/*.pt):
+ * the .pt checkpoint in pretrained_model_downstream/):
  *
  *   gvp_node.0 {wh.weight, ws.weight, ws.bias, wv.weight, wsv.weight, wsv.bias}
  *   gvp_node.1 {scalar_norm.weight, scalar_norm.bias}
@@ -286,18 +286,17 @@ int cgvp_gine_conv_fwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
  * CASTER-DTA layer shapes (52,16,16), (16,64,64), (16,16,16) with 11 / 0 atom
  * types, 5 bond types, 9 bond features. */
 int64_t cgvp_gine_bwd_workspace_floats(void);
-/* Cap on the workgroups (= CUs) of cgvp_gine_conv_bwd.  Default 16: inside CASTER-DTA the
- * drug backward runs beside the protein backward, whose kernels own 240 of the 256 CUs.
- * A caller that trains the molecule encoder alone raises it (<= 256).  set_to <= 0 only
- * queries; returns the value in force.  Process-wide, not thread-safe. */
-int cgvp_gine_bwd_workgroups(int32_t set_to);
+/* `max_workgroups`: cap on the workgroups (= CUs) the backward may occupy; <= 0 selects the
+ * default of 16: inside CASTER-DTA the drug backward runs beside the protein backward, whose
+ * kernels own 240 of the 256 CUs.  A caller that trains the molecule encoder alone passes up
+ * to 256.  (A call argument, not library state: the library keeps no global state.) */
 int cgvp_gine_conv_bwd(const float* x, const int64_t* ntypes, int32_t num_ntypes, const float* eattr,
                        const int64_t* etypes, int32_t num_etypes, int32_t edge_dim,
                        const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
                        const int32_t* edst, int64_t num_nodes, int64_t num_edges, int32_t cin,
                        int32_t chid, int32_t cout, const cgvp_gine_w* w, float act_slope,
                        const float* mask, const float* g_out, float* g_x, float* grad_layer,
-                       float* workspace, void* stream);
+                       float* workspace, int32_t max_workgroups, void* stream);
 
 /* Library self-description (checked by the loader and the CPU test-suite). */
 int cgvp_abi_version(void);

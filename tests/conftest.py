@@ -54,6 +54,11 @@ def lba_small():
 
 
 @pytest.fixture(scope="session")
+def lba_sparse():
+    return load_npz("lba_sparse.npz")
+
+
+@pytest.fixture(scope="session")
 def gvp_units():
     return load_npz("gvp_units.npz")
 

@@ -25,6 +25,8 @@ fixtures is therefore the reference's own code executing on CPU (fp32, plus an
 fp64 run for tolerance budgeting), with the pretrained BindingDB checkpoint
 loaded through ``torch.load(weights_only=True)``.
 """
+import argparse
+import importlib.util
 import inspect
 import json
 import os
@@ -38,8 +40,21 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 sys.dont_write_bytecode = True
-sys.path.insert(0, os.path.join(REPO, "caster-dta_amd"))
-import davis_synth as ds  # noqa: E402
+OUT = HERE          # --out-dir overrides (the CPU test-suite regenerates into a temp dir and compares)
+
+
+def _load_by_path(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# The synthetic-input generator is loaded BY FILE PATH: caster-dta_amd/ must never be on sys.path here,
+# because its `models/` is a regular package and would shadow the reference's namespace package
+# `models/` regardless of path order (then this script would pin the product against itself).
+ds = _load_by_path("davis_synth", os.path.join(REPO, "caster-dta_amd", "davis_synth.py"))
 
 
 def install_standins():
@@ -86,11 +101,56 @@ def np_(t):
     return t.detach().cpu().numpy()
 
 
+def lba_fixture(model, m64, gb, r_seed):
+    """Run the reference LBA encoder on batch `gb`: output, fp64 output, per-stage intermediates and
+    reference-autograd gradients of sum(out * r) w.r.t. every weight and the float inputs."""
+    d = ds.to_torch(gb)
+    xs, xv = d["x"]
+    es, ev = d["eattr"]
+    xs.requires_grad_(True); xv.requires_grad_(True); es.requires_grad_(True); ev.requires_grad_(True)
+    stages = {}
+    lba = model.gnn_model
+    hooks = [lba.gvp_node.register_forward_hook(lambda m, i, o: stages.__setitem__("node_embed", o)),
+             lba.gvp_edge.register_forward_hook(lambda m, i, o: stages.__setitem__("edge_embed", o))]
+    for l, conv in enumerate(lba.conv_list):
+        hooks.append(conv.register_forward_hook(lambda m, i, o, l=l: stages.__setitem__(f"conv{l}", o)))
+        hooks.append(conv.conv.register_forward_hook(lambda m, i, o, l=l: stages.__setitem__(f"conv{l}_dh", o)))
+    model.zero_grad(set_to_none=True)
+    out = model((xs, xv), d["edge_index"], d["ntypes"], d["etypes"], eattr=(es, ev), batch=d["batch"])
+    for h in hooks:
+        h.remove()
+    r = torch.from_numpy(np.random.default_rng(r_seed).normal(size=tuple(out.shape)).astype(np.float32))
+    (out * r).sum().backward()
+    grads = {"g_" + n.replace("gnn_model.", ""): np_(p.grad) for n, p in model.named_parameters() if p.numel()}
+    out64 = m64((xs.detach().double(), xv.detach().double()), d["edge_index"], d["ntypes"], d["etypes"],
+                eattr=(es.detach().double(), ev.detach().double()))
+    arrays = dict(
+        x_s=gb.x_s, x_v=gb.x_v, edge_index=gb.edge_index, e_s=gb.e_s, e_v=gb.e_v, ntypes=gb.ntypes,
+        etypes=gb.etypes, batch=gb.batch, ptr=gb.ptr, out=np_(out), out64=np_(out64), r=np_(r),
+        gin_x_s=np_(xs.grad), gin_x_v=np_(xv.grad), gin_e_s=np_(es.grad), gin_e_v=np_(ev.grad),
+        **{f"stage_{k}_s": np_(v[0]) for k, v in stages.items()},
+        **{f"stage_{k}_v": np_(v[1]) for k, v in stages.items()}, **grads)
+    return arrays, (d, xs, xv, es, ev, out, out64)
+
+
 def main():
+    global OUT
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out-dir", default=HERE)
+    ap.add_argument("--only", default=None, help="comma-separated subset of {state,lba_small,lba_sparse,gvp_units}")
+    args = ap.parse_args()
+    OUT = args.out_dir
+    want = set(args.only.split(",")) if args.only else {"state", "lba_small", "lba_sparse", "gvp_units"}
+    os.makedirs(OUT, exist_ok=True)
     install_standins()
+    assert not any(os.path.abspath(p or ".").startswith(os.path.join(REPO, "caster-dta_amd")) for p in sys.path), \
+        "caster-dta_amd must not be importable here (its models/ package shadows the reference)"
     sys.path.insert(0, REF)
     import models.gvp_layers as gvp                      # reference, unmodified
+    import models.protein_gnn as ref_protein_gnn
     from models.protein_gnn import SelectableProteinModelWrapper
+    for mod in (gvp, ref_protein_gnn):
+        assert os.path.abspath(mod.__file__).startswith(REF + "/"), f"{mod.__name__} was imported from {mod.__file__}"
 
     ckpt = torch.load(os.path.join(REF, "pretrained_model_downstream",
                                    "bestvalmodel_bindingdb_val0.6889_epoch01011.pt"),
@@ -102,48 +162,39 @@ def main():
         pk[k] = tuple(pk[k])
 
     # ---- weights as data: encoder slices (+ the full state dict for the head) ----
-    np.savez_compressed(os.path.join(HERE, "pretrained_state.npz"), **{k: np_(v) for k, v in ckpt.items()})
+    if "state" in want:
+        np.savez_compressed(os.path.join(OUT, "pretrained_state.npz"), **{k: np_(v) for k, v in ckpt.items()})
 
     model = SelectableProteinModelWrapper(**pk).eval()
     psd = {k[len("protein_gnn."):]: v for k, v in ckpt.items() if k.startswith("protein_gnn.")}
     print("load_state_dict:", model.load_state_dict(psd, strict=True))
+    m64 = SelectableProteinModelWrapper(**pk).double().eval()
+    m64.load_state_dict({k: v.double() for k, v in psd.items()})
 
     # ---- (4)/(6)/(7): full LBA model on a ragged 3-graph batch (incl. kNN graph) ----
     rng = np.random.default_rng(11)
     graphs = [ds.protein_graph(24, rng, 4.0, "dist"), ds.protein_graph(37, rng, 10.0, "dist"),
               ds.protein_graph(19, rng, 6, "num")]
     gb = ds.collate(graphs)
-    d = ds.to_torch(gb)
-    xs, xv = d["x"]
-    es, ev = d["eattr"]
-    xs.requires_grad_(True); xv.requires_grad_(True); es.requires_grad_(True); ev.requires_grad_(True)
-
-    stages = {}
-    lba = model.gnn_model
-    hooks = [lba.gvp_node.register_forward_hook(lambda m, i, o: stages.__setitem__("node_embed", o)),
-             lba.gvp_edge.register_forward_hook(lambda m, i, o: stages.__setitem__("edge_embed", o))]
-    for l, conv in enumerate(lba.conv_list):
-        hooks.append(conv.register_forward_hook(lambda m, i, o, l=l: stages.__setitem__(f"conv{l}", o)))
-        hooks.append(conv.conv.register_forward_hook(lambda m, i, o, l=l: stages.__setitem__(f"conv{l}_dh", o)))
-    out = model((xs, xv), d["edge_index"], d["ntypes"], d["etypes"], eattr=(es, ev), batch=d["batch"])
-    for h in hooks:
-        h.remove()
-    r = torch.from_numpy(np.random.default_rng(5).normal(size=tuple(out.shape)).astype(np.float32))
-    (out * r).sum().backward()
-    grads = {"g_" + n.replace("gnn_model.", ""): np_(p.grad) for n, p in model.named_parameters() if p.numel()}
-    m64 = SelectableProteinModelWrapper(**pk).double().eval()
-    m64.load_state_dict({k: v.double() for k, v in psd.items()})
-    out64 = m64((xs.detach().double(), xv.detach().double()), d["edge_index"], d["ntypes"], d["etypes"],
-                eattr=(es.detach().double(), ev.detach().double()))
-    np.savez_compressed(
-        os.path.join(HERE, "lba_small.npz"),
-        x_s=gb.x_s, x_v=gb.x_v, edge_index=gb.edge_index, e_s=gb.e_s, e_v=gb.e_v, ntypes=gb.ntypes,
-        etypes=gb.etypes, batch=gb.batch, ptr=gb.ptr, out=np_(out), out64=np_(out64), r=np_(r),
-        gin_x_s=np_(xs.grad), gin_x_v=np_(xv.grad), gin_e_s=np_(es.grad), gin_e_v=np_(ev.grad),
-        **{f"stage_{k}_s": np_(v[0]) for k, v in stages.items()},
-        **{f"stage_{k}_v": np_(v[1]) for k, v in stages.items()}, **grads)
+    arrays, (d, xs, xv, es, ev, out, out64) = lba_fixture(model, m64, gb, 5)
+    if "lba_small" in want:
+        np.savez_compressed(os.path.join(OUT, "lba_small.npz"), **arrays)
     print("lba_small: N", gb.num_nodes, "E", gb.num_edges, "out", tuple(out.shape),
           "fp32 vs fp64 max-abs/max", float((out.double() - out64).abs().max() / out64.abs().max()))
+
+    # ---- the shipped default graph density (4 A radius + self loops, ~3 edges / residue, E <= 4N): this is
+    # the regime in which the product takes its ONE-launch-per-layer kernel (cgvp_conv_layer_fwd) and the
+    # backward behind it, so the reference's numbers reach those kernels directly ----
+    if "lba_sparse" in want:
+        rng = np.random.default_rng(23)
+        gs = ds.collate([ds.protein_graph(L, rng, 4.0, "dist") for L in (45, 70, 33)])
+        assert gs.num_edges <= 4 * gs.num_nodes
+        sp_arrays, (_, _, _, _, _, so, so64) = lba_fixture(model, m64, gs, 6)
+        np.savez_compressed(os.path.join(OUT, "lba_sparse.npz"), **sp_arrays)
+        print("lba_sparse: N", gs.num_nodes, "E", gs.num_edges, "out", tuple(so.shape),
+              "fp32 vs fp64 max-abs/max", float((so.double() - so64).abs().max() / so64.abs().max()))
+    if "gvp_units" not in want:
+        return
 
     # ---- (1)/(2): standalone GVP / LayerNorm instances, every dim signature of the path ----
     import torch.nn.functional as F
@@ -214,7 +265,7 @@ def main():
                 units[f"{key}_{nm}"] = np_(t)
             for k, p in layer.state_dict().items():
                 units[f"{key}_w_{k}"] = np_(p)
-    np.savez_compressed(os.path.join(HERE, "gvp_units.npz"), **units)
+    np.savez_compressed(os.path.join(OUT, "gvp_units.npz"), **units)
     print("gvp_units:", len(units), "arrays")
 
     # ---- invariances measured on the reference ----

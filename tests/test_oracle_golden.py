@@ -57,6 +57,13 @@ def test_conv_layer_unit(gvp_units, aggr, tag, gate, va):
     assert rel_err(o[0], u[key + "_out_s"]) < TOL and rel_err(o[1], u[key + "_out_v"]) < TOL
 
 
+@pytest.fixture(params=["lba_small", "lba_sparse"])
+def lba_gold(request):
+    """Both reference batches: `lba_small` (ragged, incl. a kNN graph, E > 4N) and `lba_sparse` (the shipped
+    4 A radius density, E <= 4N: the regime of the product's one-launch-per-layer kernels)."""
+    return request.getfixturevalue(request.param)
+
+
 def _lba_inputs(g, dtype=torch.float32, grad=False):
     xs, xv = T(g["x_s"]).to(dtype), T(g["x_v"]).to(dtype)
     es, ev = T(g["e_s"]).to(dtype), T(g["e_v"]).to(dtype)
@@ -66,8 +73,8 @@ def _lba_inputs(g, dtype=torch.float32, grad=False):
     return xs, xv, es, ev
 
 
-def test_lba_forward_and_stages(lba_small, protein_params):
-    g = lba_small
+def test_lba_forward_and_stages(lba_gold, protein_params):
+    g = lba_gold
     xs, xv, es, ev = _lba_inputs(g)
     out, st = O.protein_lba_forward(protein_params, (xs, xv), T(g["edge_index"]), T(g["ntypes"]),
                                     T(g["etypes"]), (es, ev), return_stages=True)
@@ -78,10 +85,10 @@ def test_lba_forward_and_stages(lba_small, protein_params):
         assert rel_err(st[name][1], g[f"stage_{name}_v"]) < TOL, name
 
 
-def test_lba_fp64_budget(lba_small, protein_params):
+def test_lba_fp64_budget(lba_gold, protein_params):
     """fp64 oracle == fp64 reference to ~1e-15; fp32 sits ~2e-7 away: the 1e-4
     parity target has more than two orders of magnitude of headroom."""
-    g = lba_small
+    g = lba_gold
     xs, xv, es, ev = _lba_inputs(g, torch.float64)
     P = {k: v.double() for k, v in protein_params.items()}
     out = O.protein_lba_forward(P, (xs, xv), T(g["edge_index"]), T(g["ntypes"]), T(g["etypes"]), (es, ev))
@@ -89,9 +96,9 @@ def test_lba_fp64_budget(lba_small, protein_params):
     assert rel_err(g["out"], g["out64"]) < 1e-6
 
 
-def test_lba_gradients(lba_small, protein_params):
+def test_lba_gradients(lba_gold, protein_params):
     """Autograd through the oracle == reference autograd (weights and inputs)."""
-    g = lba_small
+    g = lba_gold
     xs, xv, es, ev = _lba_inputs(g, grad=True)
     P = {k: v.clone().requires_grad_(v.numel() > 0) for k, v in protein_params.items()}
     out = O.protein_lba_forward(P, (xs, xv), T(g["edge_index"]), T(g["ntypes"]), T(g["etypes"]), (es, ev))
