@@ -1,232 +1,427 @@
-"""torch.autograd integration of the HIP kernels (training path).
+"""The encoders as `torch.library` custom ops (namespace ``caster_gvp``).
 
-`lba_encoder` / `gine_encoder` run the same forward kernels as inference while
-saving each stage's INPUTS (node rows h_l, aggregated messages dh_l, dropout
-masks); the backward launches the hand-written backward kernels, which
-recompute their stage and emit data gradients plus an arena of weight gradients
-whose views are handed back to autograd, one per nn.Parameter.  No PyTorch
-arithmetic is involved besides drawing dropout masks.
+Why custom ops and not a bare ``torch.autograd.Function`` around ctypes calls: the reference wraps its model in
+``torch.compile(model, dynamic=True)`` (train_model.py:422), runs the forward under ``torch.autocast``
+(:561) and back-propagates a ``GradScaler``-scaled loss (:478, :570-587).  With the registrations below all three
+work unchanged:
+
+  * ``register_fake``      -- shape/dtype propagation for Dynamo / AOTAutograd (dynamic N, E);
+  * ``register_autograd``  -- the backward is itself a custom op (``*_backward``), so AOTAutograd can trace it;
+  * ``register_autocast``  -- float inputs are cast to fp32 (the kernels are fp32 storage / fp32 accumulate);
+  * the real kernels are opaque to the compiler: each op is the C-ABI launch sequence of one encoder pass.
+
+Ops
+  caster_gvp::lba_encoder            VectorProteinGNN_LBAModel.forward (protein_gnn.py:361-388)
+  caster_gvp::lba_encoder_backward   what autograd derives from it in the reference
+  caster_gvp::gine_encoder           HomoMoleculeGNN_GINE.forward (molecule_gnn.py:254-268)
+  caster_gvp::gine_encoder_backward
+
+The forward ops save each stage's INPUTS (node rows h_l, aggregated messages dh_l, dropout masks) as extra outputs;
+the backward ops launch the hand-written backward kernels, which recompute their stage and emit data gradients plus
+an arena of weight gradients.  No PyTorch arithmetic is involved besides drawing dropout masks.
 """
 from __future__ import annotations
 
 import ctypes as C
+from typing import List, Tuple
 
 import torch
+from torch import Tensor
 
 from . import _lib, ops
 from .ops import ROW, _f32, _i64, _ptr, _stream
 
 MROW = 20   # dropout mask row: 16 scalar-channel + 4 vector-channel factors
+# `cfg` argument of the LBA ops: the nine cgvp_dims fields, then these
+_CFG_FIELDS = ("node_in_s", "node_in_v", "edge_in_s", "edge_in_v", "hidden_s", "hidden_v", "edge_hidden_s",
+               "edge_hidden_v", "out_s")
+CFG_NTN, CFG_NTE, CFG_NC, CFG_MEAN, CFG_LEN = 9, 10, 11, 12, 13
 
 
-def _dropout_mask(n, p, device):
+def _dropout_masks(count, n, p, device):
+    """`count` masks of gvp_layers.Dropout (gvp_layers.py:187-219) in one draw: [count, n, 16 scalar-channel +
+    4 vector-channel factors], each 0 or 1/(1-p) (a vector channel's factor is shared by its xyz components)."""
     keep = 1.0 - p
-    return (torch.rand(n, MROW, device=device) < keep).to(torch.float32).div_(keep)
+    return (torch.rand(count, n, MROW, device=device) < keep).to(torch.float32).div_(keep)
 
 
-class _LbaEncoderFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, meta, x_s, x_v, e_s, e_v, *params):
-        L = _lib.lib()
-        m = meta
-        dims, layout, image, csr = m["dims"], m["layout"], m["image"], m["csr"]
-        x_s, x_v, e_s, e_v = _f32(x_s, "x_s"), _f32(x_v, "x_v"), _f32(e_s, "eattr_s"), _f32(e_v, "eattr_v")
-        N, E = int(x_s.shape[0]), int(e_s.shape[0])
-        nt = _i64(m["ntypes"], "ntypes") if layout.nt_node > 0 else None
-        et = _i64(m["etypes"], "etypes") if layout.nt_edge > 0 else None
-        dev = x_s.device
-        nc = m["num_convs"]
-        hs = [torch.empty(N, ROW, dtype=torch.float32, device=dev) for _ in range(nc)]
-        dhs = [torch.empty(N, ROW, dtype=torch.float32, device=dev) for _ in range(nc)]
-        masks = [(None, None)] * nc
-        if m["dropout"] > 0:
-            masks = [(_dropout_mask(N, m["dropout"], dev), _dropout_mask(N, m["dropout"], dev)) for _ in range(nc)]
-        out = torch.empty(N, dims.out_s, dtype=torch.float32, device=dev)
-        h_last = torch.empty(N, ROW, dtype=torch.float32, device=dev)     # input of the head, saved for its backward
-        with torch.cuda.device(dev):
-            st = _stream()
-            d, lay, P, I = C.byref(dims), C.byref(layout), _ptr(m["params"]), _ptr(image)
-            _lib.check(L.cgvp_node_embed_fwd(d, lay, P, I, _ptr(x_s), _ptr(x_v), _ptr(nt), N, _ptr(hs[0]), st),
-                       "cgvp_node_embed_fwd")
-            for l in range(nc):
-                last = l == nc - 1
-                if ops.fuse_layer(N, E):
-                    with ops._timed("conv_fwd"):
-                        _lib.check(L.cgvp_conv_layer_fwd(d, lay, I, l, _ptr(hs[l]), _ptr(e_s), _ptr(e_v), _ptr(et),
-                                                         _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc),
-                                                         _ptr(csr.edst), N, E, 1 if m["mean"] else 0,
-                                                         _ptr(masks[l][0]), _ptr(masks[l][1]), 1 if last else 0,
-                                                         _ptr(dhs[l]), _ptr(h_last if last else hs[l + 1]), _ptr(out),
-                                                         st), "cgvp_conv_layer_fwd")
-                    continue
-                with ops._timed("conv_fwd"):
-                    _lib.check(L.cgvp_conv_fwd(d, lay, P, I, l, _ptr(hs[l]), _ptr(e_s), _ptr(e_v), _ptr(et),
-                                               _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst),
-                                               N, E, 1 if m["mean"] else 0, _ptr(dhs[l]), st), "cgvp_conv_fwd")
-                _lib.check(L.cgvp_node_update_fwd_train(d, lay, I, l, _ptr(hs[l]), _ptr(dhs[l]), _ptr(masks[l][0]),
-                                                        _ptr(masks[l][1]), N, 1 if last else 0,
-                                                        _ptr(h_last if last else hs[l + 1]), _ptr(out), st),
-                           "cgvp_node_update_fwd_train")
-        ctx.meta = m
-        ctx.saved = (x_s, x_v, e_s, e_v, nt, et, hs, dhs, masks, h_last)
-        ctx.n_params = len(params)
-        return out
-
-    @staticmethod
-    def backward(ctx, g_out):
-        L = _lib.lib()
-        m = ctx.meta
-        dims, layout, image, csr = m["dims"], m["layout"], m["image"], m["csr"]
-        x_s, x_v, e_s, e_v, nt, et, hs, dhs, masks, h_last = ctx.saved
-        N, E = int(x_s.shape[0]), int(e_s.shape[0])
-        dev = x_s.device
-        nc = m["num_convs"]
-        g_out = _f32(g_out, "grad_output")
-        f32 = dict(dtype=torch.float32, device=dev)
-        gparams = torch.zeros(layout.total, **f32)
-        # every stage writes its per-workgroup partial weight-gradient blocks into its own region of
-        # one workspace; a single reduce launch at the end sums them all in a fixed order
-        wsz = int(L.cgvp_bwd_workspace_floats(C.byref(dims), C.byref(layout)))
-        nstage = 2 * nc + 1
-        ws_all = torch.empty(nstage * wsz, **f32)
-        segs = (_lib.Segment * (2 * nstage))()
-        nseg, stage = 0, 0
-        cnt = C.c_int32(0)
-
-        def region():
-            nonlocal stage
-            r = ws_all[stage * wsz:(stage + 1) * wsz]
-            stage += 1
-            return r
-
-        def take():
-            nonlocal nseg
-            nseg += cnt.value
-        need_x = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
-        g_x_s = torch.empty(N, dims.node_in_s, **f32) if need_x else None
-        g_x_v = torch.empty(N, dims.node_in_v, 3, **f32) if need_x else None
-        with torch.cuda.device(dev):
-            st = _stream()
-            d, lay, I = C.byref(dims), C.byref(layout), _ptr(image)
-            ups = (None, None, None)        # gradient w.r.t. the output of layer l (sum of up to 3 buffers)
-            for l in reversed(range(nc)):
-                last = l == nc - 1
-                g_dh = torch.empty(N, ROW, **f32)
-                g_h = torch.empty(N, ROW, **f32) if masks[l][0] is not None else None
-                g_src = torch.empty(N, ROW, **f32)       # zeroed by the node stage, filled by the conv stage's atomics
-                _lib.check(L.cgvp_node_update_bwd(d, lay, I, l, _ptr(hs[l]), _ptr(dhs[l]), _ptr(masks[l][0]),
-                                                  _ptr(masks[l][1]), _ptr(h_last if last else None),
-                                                  _ptr(g_out if last else None), _ptr(ups[0]),
-                                                  _ptr(ups[1]), _ptr(ups[2]), N, 1 if last else 0, _ptr(g_dh),
-                                                  _ptr(g_h), _ptr(g_src), _ptr(gparams), _ptr(region()),
-                                                  C.byref(segs, nseg * C.sizeof(_lib.Segment)), C.byref(cnt), st),
-                           "cgvp_node_update_bwd")
-                take()
-                g_dst = torch.empty(N, ROW, **f32)
-                with ops._timed("conv_bwd"):
-                    _lib.check(L.cgvp_conv_bwd(d, lay, I, l, _ptr(hs[l]), _ptr(e_s), _ptr(e_v), _ptr(et),
-                                               _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst), N, E,
-                                               1 if m["mean"] else 0, _ptr(g_dh), _ptr(g_src), 1, _ptr(g_dst),
-                                               _ptr(gparams), _ptr(region()),
-                                               C.byref(segs, nseg * C.sizeof(_lib.Segment)), C.byref(cnt), st),
-                               "cgvp_conv_bwd")
-                take()
-                ups = (g_h if g_h is not None else g_dh, g_src, g_dst)
-            _lib.check(L.cgvp_node_embed_bwd(d, lay, I, _ptr(x_s), _ptr(x_v), _ptr(nt), N, _ptr(ups[0]), _ptr(ups[1]),
-                                             _ptr(ups[2]), _ptr(g_x_s), _ptr(g_x_v), _ptr(gparams), _ptr(region()),
-                                             C.byref(segs, nseg * C.sizeof(_lib.Segment)), C.byref(cnt), st),
-                       "cgvp_node_embed_bwd")
-            take()
-            _lib.check(L.cgvp_bwd_reduce(segs, nseg, _ptr(gparams), st), "cgvp_bwd_reduce")
-        grads = m["arena"].split(gparams)
-        return (None, g_x_s, g_x_v, None, None) + tuple(grads)
+def make_cfg(dims, num_ntypes, num_etypes, num_convs, aggr_mean):
+    return [int(getattr(dims, f)) for f in _CFG_FIELDS] + [int(num_ntypes), int(num_etypes), int(num_convs),
+                                                           1 if aggr_mean else 0]
 
 
-def lba_encoder(model, params, layout, dims, x_s, x_v, ntypes, e_s, e_v, etypes, csr, train_dropout):
-    """VectorProteinGNN_LBAModel.forward with autograd (and dropout when training)."""
-    if ops.VARIANT != "mfma":
+def _dims_layout(cfg):
+    dims = ops.make_dims(**{f: cfg[i] for i, f in enumerate(_CFG_FIELDS)})
+    return dims, ops.lba_layout(dims, cfg[CFG_NTN], cfg[CFG_NTE], cfg[CFG_NC])
+
+
+def flat_arena(params):
+    """The arena-ordered parameter list as ONE flat fp32 buffer: zero-copy when the tensors are consecutive
+    views of one storage (what gvp_hip.arena.ParamArena maintains), one `cat` otherwise."""
+    p0 = params[0]
+    st, off = p0.untyped_storage(), p0.storage_offset()
+    o = off
+    for p in params:
+        if p.untyped_storage().data_ptr() != st.data_ptr() or p.storage_offset() != o or not p.is_contiguous():
+            return torch.cat([q.detach().reshape(-1) for q in params])
+        o += p.numel()
+    return torch.empty(0, dtype=p0.dtype, device=p0.device).set_(st, off, (o - off,), (1,))
+
+
+_IMAGES = {}        # arena data_ptr -> (sum of parameter versions, fragment image)
+
+
+def fragment_image(params, flat, layout, dims):
+    """Fragment image of the current weights (one ~5 us launch), cached on the parameters' version counters."""
+    key, ver = flat.data_ptr(), sum(p._version for p in params)
+    hit = _IMAGES.get(key)
+    if hit is not None and hit[0] == ver and hit[1].device == flat.device:
+        return hit[1]
+    image = ops.prepare_image(flat, layout, dims)
+    if len(_IMAGES) > 16:
+        _IMAGES.clear()
+    _IMAGES[key] = (ver, image)
+    return image
+
+
+# ===================================================================================== protein encoder
+@torch.library.custom_op("caster_gvp::lba_encoder", mutates_args=(), device_types="cuda")
+def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tensor, e_s: Tensor, e_v: Tensor,
+                   etypes: Tensor, edge_index: Tensor, cfg: List[int], dropout_p: float,
+                   save_state: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    """-> (out [N, out_s], state [2 L + 1, N, 28] = h_0..h_{L-1}, dh_0..dh_{L-1}, head input, masks [2 L, N, 20]).
+    save_state=False is the inference launch sequence (state / masks come back empty)."""
+    if ops.VARIANT != "mfma" and save_state:
         raise NotImplementedError("training / gradients need the MFMA kernels (CGVP_VARIANT=mfma)")
+    L = _lib.lib()
+    dims, layout = _dims_layout(cfg)
+    nc, mean = cfg[CFG_NC], bool(cfg[CFG_MEAN])
+    x_s, x_v, e_s, e_v = _f32(x_s, "x_s"), _f32(x_v, "x_v"), _f32(e_s, "eattr_s"), _f32(e_v, "eattr_v")
+    N, E = int(x_s.shape[0]), int(e_s.shape[0])
+    dev = x_s.device
+    flat = flat_arena(params)
+    if flat.numel() != layout.total:
+        raise RuntimeError(f"parameter arena has {flat.numel()} floats, kernels expect {layout.total}")
+    image = fragment_image(params, flat, layout, dims) if ops.VARIANT == "mfma" else None
+    csr = ops.csr_for_forward(edge_index, N)
+    f32 = dict(dtype=torch.float32, device=dev)
+    if not save_state:
+        out = ops.lba_encoder_forward(flat, layout, dims, nc, x_s, x_v, ntypes, e_s, e_v, etypes, csr,
+                                      aggr_mean=mean, image=image)
+        return out, torch.empty(0, **f32), torch.empty(0, **f32)
+    if tuple(x_s.shape) != (N, dims.node_in_s) or tuple(x_v.shape) != (N, dims.node_in_v, 3) or \
+            tuple(e_s.shape) != (E, dims.edge_in_s) or tuple(e_v.shape) != (E, dims.edge_in_v, 3):
+        raise NotImplementedError("feature shapes do not match the compiled CASTER-DTA configuration")
+    nt = _i64(ntypes, "ntypes") if layout.nt_node > 0 else None
+    et = _i64(etypes, "etypes") if layout.nt_edge > 0 else None
+    state = torch.empty(2 * nc + 1, N, ROW, **f32)
+    hs, dhs, h_last = [state[l] for l in range(nc)], [state[nc + l] for l in range(nc)], state[2 * nc]
+    if dropout_p > 0:
+        masks = _dropout_masks(2 * nc, N, dropout_p, dev)
+        mk = [(masks[2 * l], masks[2 * l + 1]) for l in range(nc)]
+    else:
+        masks, mk = torch.empty(0, **f32), [(None, None)] * nc
+    out = torch.empty(N, dims.out_s, **f32)
+    with torch.cuda.device(dev):
+        st = _stream()
+        d, lay, P, I = C.byref(dims), C.byref(layout), _ptr(flat), _ptr(image)
+        _lib.check(L.cgvp_node_embed_fwd(d, lay, P, I, _ptr(x_s), _ptr(x_v), _ptr(nt), N, _ptr(hs[0]), st),
+                   "cgvp_node_embed_fwd")
+        for l in range(nc):
+            last = l == nc - 1
+            if ops.fuse_layer(N, E):
+                with ops._timed("conv_fwd"):
+                    _lib.check(L.cgvp_conv_layer_fwd(d, lay, I, l, _ptr(hs[l]), _ptr(e_s), _ptr(e_v), _ptr(et),
+                                                     _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc),
+                                                     _ptr(csr.edst), N, E, 1 if mean else 0,
+                                                     _ptr(mk[l][0]), _ptr(mk[l][1]), 1 if last else 0,
+                                                     _ptr(dhs[l]), _ptr(h_last if last else hs[l + 1]), _ptr(out),
+                                                     st), "cgvp_conv_layer_fwd")
+                continue
+            with ops._timed("conv_fwd"):
+                _lib.check(L.cgvp_conv_fwd(d, lay, P, I, l, _ptr(hs[l]), _ptr(e_s), _ptr(e_v), _ptr(et),
+                                           _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst),
+                                           N, E, 1 if mean else 0, _ptr(dhs[l]), st), "cgvp_conv_fwd")
+            _lib.check(L.cgvp_node_update_fwd_train(d, lay, I, l, _ptr(hs[l]), _ptr(dhs[l]), _ptr(mk[l][0]),
+                                                    _ptr(mk[l][1]), N, 1 if last else 0,
+                                                    _ptr(h_last if last else hs[l + 1]), _ptr(out), st),
+                       "cgvp_node_update_fwd_train")
+    return out, state, masks
+
+
+@lba_encoder_op.register_fake
+def _(params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, cfg, dropout_p, save_state):
+    N, nc = x_s.shape[0], cfg[CFG_NC]
+    out = x_s.new_empty((N, cfg[8]), dtype=torch.float32)
+    if not save_state:
+        return out, x_s.new_empty((0,), dtype=torch.float32), x_s.new_empty((0,), dtype=torch.float32)
+    masks = x_s.new_empty((2 * nc, N, MROW), dtype=torch.float32) if dropout_p > 0 else \
+        x_s.new_empty((0,), dtype=torch.float32)
+    return out, x_s.new_empty((2 * nc + 1, N, ROW), dtype=torch.float32), masks
+
+
+@torch.library.custom_op("caster_gvp::lba_encoder_backward", mutates_args=(), device_types="cuda")
+def lba_encoder_backward_op(g_out: Tensor, params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tensor,
+                            e_s: Tensor, e_v: Tensor, etypes: Tensor, edge_index: Tensor, state: Tensor,
+                            masks: Tensor, cfg: List[int], need_x: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    """-> (grad arena [layout.total], g_x_s [N, 17], g_x_v [N, 3, 3]) (the latter two empty unless need_x)."""
+    L = _lib.lib()
+    dims, layout = _dims_layout(cfg)
+    nc, mean = cfg[CFG_NC], bool(cfg[CFG_MEAN])
+    x_s, x_v, e_s, e_v = _f32(x_s, "x_s"), _f32(x_v, "x_v"), _f32(e_s, "eattr_s"), _f32(e_v, "eattr_v")
+    N, E = int(x_s.shape[0]), int(e_s.shape[0])
+    dev = x_s.device
+    nt = _i64(ntypes, "ntypes") if layout.nt_node > 0 else None
+    et = _i64(etypes, "etypes") if layout.nt_edge > 0 else None
+    flat = flat_arena(params)
+    image = fragment_image(params, flat, layout, dims)
+    csr = ops.csr_for_backward(edge_index, N)
+    hs, dhs, h_last = [state[l] for l in range(nc)], [state[nc + l] for l in range(nc)], state[2 * nc]
+    mk = [(masks[2 * l], masks[2 * l + 1]) for l in range(nc)] if masks.numel() else [(None, None)] * nc
+    g_out = _f32(g_out, "grad_output")
+    f32 = dict(dtype=torch.float32, device=dev)
+    gparams = torch.zeros(layout.total, **f32)
+    # every stage writes its per-workgroup partial weight-gradient blocks into its own region of
+    # one workspace; a single reduce launch at the end sums them all in a fixed order
+    wsz = int(L.cgvp_bwd_workspace_floats(C.byref(dims), C.byref(layout)))
+    nstage = 2 * nc + 1
+    ws_all = torch.empty(nstage * wsz, **f32)
+    segs = (_lib.Segment * (2 * nstage))()
+    nseg, stage = 0, 0
+    cnt = C.c_int32(0)
+
+    def region():
+        nonlocal stage
+        r = ws_all[stage * wsz:(stage + 1) * wsz]
+        stage += 1
+        return r
+
+    def take():
+        nonlocal nseg
+        nseg += cnt.value
+    g_x_s = torch.empty(N, dims.node_in_s, **f32) if need_x else None
+    g_x_v = torch.empty(N, dims.node_in_v, 3, **f32) if need_x else None
+    with torch.cuda.device(dev):
+        st = _stream()
+        d, lay, I = C.byref(dims), C.byref(layout), _ptr(image)
+        ups = (None, None, None)        # gradient w.r.t. the output of layer l (sum of up to 3 buffers)
+        for l in reversed(range(nc)):
+            last = l == nc - 1
+            g_dh = torch.empty(N, ROW, **f32)
+            g_h = torch.empty(N, ROW, **f32) if mk[l][0] is not None else None
+            g_src = torch.empty(N, ROW, **f32)       # zeroed by the node stage, filled by the conv stage's atomics
+            _lib.check(L.cgvp_node_update_bwd(d, lay, I, l, _ptr(hs[l]), _ptr(dhs[l]), _ptr(mk[l][0]),
+                                              _ptr(mk[l][1]), _ptr(h_last if last else None),
+                                              _ptr(g_out if last else None), _ptr(ups[0]),
+                                              _ptr(ups[1]), _ptr(ups[2]), N, 1 if last else 0, _ptr(g_dh),
+                                              _ptr(g_h), _ptr(g_src), _ptr(gparams), _ptr(region()),
+                                              C.byref(segs, nseg * C.sizeof(_lib.Segment)), C.byref(cnt), st),
+                       "cgvp_node_update_bwd")
+            take()
+            g_dst = torch.empty(N, ROW, **f32)
+            with ops._timed("conv_bwd"):
+                _lib.check(L.cgvp_conv_bwd(d, lay, I, l, _ptr(hs[l]), _ptr(e_s), _ptr(e_v), _ptr(et),
+                                           _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst), N, E,
+                                           1 if mean else 0, _ptr(g_dh), _ptr(g_src), 1, _ptr(g_dst),
+                                           _ptr(gparams), _ptr(region()),
+                                           C.byref(segs, nseg * C.sizeof(_lib.Segment)), C.byref(cnt), st),
+                           "cgvp_conv_bwd")
+            take()
+            ups = (g_h if g_h is not None else g_dh, g_src, g_dst)
+        _lib.check(L.cgvp_node_embed_bwd(d, lay, I, _ptr(x_s), _ptr(x_v), _ptr(nt), N, _ptr(ups[0]), _ptr(ups[1]),
+                                         _ptr(ups[2]), _ptr(g_x_s), _ptr(g_x_v), _ptr(gparams), _ptr(region()),
+                                         C.byref(segs, nseg * C.sizeof(_lib.Segment)), C.byref(cnt), st),
+                   "cgvp_node_embed_bwd")
+        take()
+        _lib.check(L.cgvp_bwd_reduce(segs, nseg, _ptr(gparams), st), "cgvp_bwd_reduce")
+    return gparams, (g_x_s if need_x else torch.empty(0, **f32)), (g_x_v if need_x else torch.empty(0, **f32))
+
+
+@lba_encoder_backward_op.register_fake
+def _(g_out, params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, cfg, need_x):
+    total = sum(p.numel() for p in params)
+    gp = x_s.new_empty((total,), dtype=torch.float32)
+    if need_x:
+        return gp, x_s.new_empty(x_s.shape, dtype=torch.float32), x_v.new_empty(x_v.shape, dtype=torch.float32)
+    return gp, x_s.new_empty((0,), dtype=torch.float32), x_s.new_empty((0,), dtype=torch.float32)
+
+
+def _lba_setup(ctx, inputs, output):
+    params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, cfg, dropout_p, save_state = inputs
+    out, state, masks = output
+    if not save_state:
+        raise RuntimeError("caster_gvp::lba_encoder was run with save_state=False; gradients need save_state=True")
+    ctx.cfg = cfg
+    ctx.shapes = [tuple(p.shape) for p in params]
+    ctx.save_for_backward(x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, *params)
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= s
+    return n
+
+
+def _lba_backward(ctx, g_out, g_state, g_masks):
+    x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, *params = ctx.saved_tensors
+    need_x = bool(ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+    gflat, g_x_s, g_x_v = torch.ops.caster_gvp.lba_encoder_backward(
+        g_out.contiguous(), params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, ctx.cfg, need_x)
+    grads = [g.view(s) for g, s in zip(torch.split(gflat, [_numel(s) for s in ctx.shapes]), ctx.shapes)]
+    return (grads, g_x_s if need_x else None, g_x_v if need_x else None, None, None, None, None, None, None, None,
+            None)
+
+
+torch.library.register_autograd("caster_gvp::lba_encoder", _lba_backward, setup_context=_lba_setup)
+torch.library.register_autocast("caster_gvp::lba_encoder", "cuda", torch.float32)
+
+
+def lba_encoder(model, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, train_dropout, save_state):
+    """VectorProteinGNN_LBAModel.forward through the custom op (autograd, dropout when training)."""
     if e_s.requires_grad or e_v.requires_grad:
         raise NotImplementedError("gradients w.r.t. raw edge features are not produced by the backward kernels")
-    meta = dict(dims=dims, layout=layout, image=model._fragment_image(params, layout, dims), csr=csr,
-                params=params, arena=model._arena, ntypes=ntypes, etypes=etypes, num_convs=model.num_convs,
-                mean=(model.aggr == "mean"), dropout=float(model.dropout_rate) if train_dropout else 0.0)
-    return _LbaEncoderFn.apply(meta, x_s, x_v, e_s, e_v, *model._arena.params)
+    # plain Python ints only (no ctypes objects here: this function is traced by Dynamo under torch.compile);
+    # the op validates them against the compiled kernel configuration
+    cfg = [model.in_channels[0], model.in_channels[1], model.edge_dim[0], model.edge_dim[1],
+           model.hidden_channels[0], model.hidden_channels[1], model.edge_hidden_channels[0],
+           model.edge_hidden_channels[1], model.out_channels[0], model.num_ntypes, model.num_etypes,
+           model.num_convs, 1 if model.aggr == "mean" else 0]
+    out, _, _ = torch.ops.caster_gvp.lba_encoder(
+        model._arena.params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, cfg,
+        float(model.dropout_rate) if train_dropout else 0.0, save_state)
+    return out
 
 
+# ===================================================================================== drug encoder
 _GINE_KEYS = ("eps", "w0", "b0", "w1", "b1", "we", "be")     # slab / state_dict order of one GINEConv
 
 
-class _GineEncoderFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, meta, x, eattr, *params):
-        m = meta
-        widths, nl = m["widths"], len(m["widths"]) - 1
-        x, eattr = _f32(x, "x"), _f32(eattr, "eattr")
-        N = int(x.shape[0])
-        ws = [dict(zip(_GINE_KEYS, params[7 * l:7 * l + 7])) for l in range(nl)]
-        hs, masks = [x], []
-        for l in range(nl):
-            mask = None
-            if m["dropout"] > 0 and l < nl - 1:
-                keep = 1.0 - m["dropout"]
-                mask = (torch.rand(N, widths[l + 1], device=x.device) < keep).to(torch.float32).div_(keep)
-            masks.append(mask)
+@torch.library.custom_op("caster_gvp::gine_encoder", mutates_args=(), device_types="cuda")
+def gine_encoder_op(params: List[Tensor], x: Tensor, ntypes: Tensor, eattr: Tensor, etypes: Tensor,
+                    edge_index: Tensor, widths: List[int], num_ntypes: int, num_etypes: int, slope: float,
+                    dropout_p: float, save_state: bool) -> Tuple[Tensor, List[Tensor], List[Tensor]]:
+    """-> (out [N, widths[-1]], hidden [h_1 .. h_{L-1}], masks [m_0 .. m_{L-2}]) -- the lists are empty when
+    save_state is False; a mask is an empty tensor when dropout is off."""
+    nl = len(widths) - 1
+    x, eattr = _f32(x, "x"), _f32(eattr, "eattr")
+    N = int(x.shape[0])
+    csr = ops.csr_for_forward(edge_index, N)
+    ws = [dict(zip(_GINE_KEYS, params[7 * l:7 * l + 7])) for l in range(nl)]
+    hs, masks = [x], []
+    for l in range(nl):
+        mask = None
+        if dropout_p > 0 and l < nl - 1:
+            keep = 1.0 - dropout_p
+            mask = (torch.rand(N, widths[l + 1], device=x.device) < keep).to(torch.float32).div_(keep)
+        masks.append(mask)
+        first = l == 0
+        hs.append(ops.gine_conv_forward(hs[l], ntypes if first else None, num_ntypes if first else 0,
+                                        eattr, etypes, num_etypes, csr, ws[l], widths[l],
+                                        widths[l + 1], widths[l + 1], slope, mask=mask))
+    if not save_state:
+        return hs[-1], [], []
+    return hs[-1], hs[1:-1], [m if m is not None else x.new_empty(0) for m in masks[:-1]]
+
+
+@gine_encoder_op.register_fake
+def _(params, x, ntypes, eattr, etypes, edge_index, widths, num_ntypes, num_etypes, slope, dropout_p, save_state):
+    N, nl = x.shape[0], len(widths) - 1
+    out = x.new_empty((N, widths[-1]), dtype=torch.float32)
+    if not save_state:
+        return out, [], []
+    hidden = [x.new_empty((N, widths[l]), dtype=torch.float32) for l in range(1, nl)]
+    masks = [x.new_empty((N, widths[l + 1]) if dropout_p > 0 else (0,), dtype=torch.float32) for l in range(nl - 1)]
+    return out, hidden, masks
+
+
+@torch.library.custom_op("caster_gvp::gine_encoder_backward", mutates_args=(), device_types="cuda")
+def gine_encoder_backward_op(g_out: Tensor, params: List[Tensor], x: Tensor, ntypes: Tensor, eattr: Tensor,
+                             etypes: Tensor, edge_index: Tensor, hidden: List[Tensor], masks: List[Tensor],
+                             widths: List[int], num_ntypes: int, num_etypes: int, slope: float, need_x: bool,
+                             bwd_workgroups: int) -> Tuple[Tensor, Tensor]:
+    """-> (the gradients of `params`, flattened and concatenated in that order, g_x (empty unless need_x))."""
+    L = _lib.lib()
+    nl = len(widths) - 1
+    x, eattr = _f32(x, "x"), _f32(eattr, "eattr")
+    N, dev = int(x.shape[0]), x.device
+    csr = ops.csr_for_backward(edge_index, N)
+    f32 = dict(dtype=torch.float32, device=dev)
+    nt, et = _i64(ntypes, "ntypes"), _i64(etypes, "etypes")
+    hs = [x] + list(hidden)
+    mk = [masks[l] if l < len(masks) and masks[l].numel() else None for l in range(nl)]
+    ws = [dict(zip(_GINE_KEYS, params[7 * l:7 * l + 7])) for l in range(nl)]
+    g = _f32(g_out, "grad_output")
+    wsp = torch.empty(int(L.cgvp_gine_bwd_workspace_floats()), **f32)
+    layer_floats = [sum(p.numel() for p in params[7 * l:7 * l + 7]) for l in range(nl)]
+    gflat = torch.zeros(sum(layer_floats), **f32)
+    edge_dim = int(eattr.shape[1])
+    with torch.cuda.device(dev):
+        for l in reversed(range(nl)):
             first = l == 0
-            hs.append(ops.gine_conv_forward(hs[l], m["ntypes"] if first else None, m["num_ntypes"] if first else 0,
-                                            eattr, m["etypes"], m["num_etypes"], m["csr"], ws[l], widths[l],
-                                            widths[l + 1], widths[l + 1], m["slope"], mask=mask))
-        ctx.meta, ctx.saved = m, (hs, masks, eattr, ws)
-        return hs[-1]
-
-    @staticmethod
-    def backward(ctx, g):
-        L = _lib.lib()
-        m = ctx.meta
-        hs, masks, eattr, ws = ctx.saved
-        widths, nl = m["widths"], len(m["widths"]) - 1
-        csr = m["csr"]
-        N, dev = int(hs[0].shape[0]), hs[0].device
-        f32 = dict(dtype=torch.float32, device=dev)
-        nt = _i64(m["ntypes"], "ntypes")
-        et = _i64(m["etypes"], "etypes")
-        g = _f32(g, "grad_output")
-        wsp = torch.empty(int(L.cgvp_gine_bwd_workspace_floats()), **f32)
-        grads = [None] * (7 * nl)
-        edge_dim = int(eattr.shape[1])
-        with torch.cuda.device(dev):
-            for l in reversed(range(nl)):
-                first = l == 0
-                cin, cout = widths[l], widths[l + 1]
-                w = {k: _f32(v, k) for k, v in ws[l].items()}
-                sizes = [w[k].numel() for k in _GINE_KEYS]
-                glayer = torch.zeros(sum(sizes), **f32)
-                need_x = (not first) or ctx.needs_input_grad[1]
-                g_x = torch.empty(N, cin - (m["num_ntypes"] if first else 0), **f32) if need_x else None
-                gw = _lib.GineW(**{k: v.data_ptr() for k, v in w.items()})
-                rc = L.cgvp_gine_conv_bwd(_ptr(hs[l]), _ptr(nt if first else None), m["num_ntypes"] if first else 0,
-                                          _ptr(eattr), _ptr(et), m["num_etypes"], edge_dim, _ptr(csr.rowptr),
-                                          _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst), N, csr.num_edges, cin, cout, cout,
-                                          C.byref(gw), float(m["slope"]), _ptr(masks[l]), _ptr(g), _ptr(g_x),
-                                          _ptr(glayer), _ptr(wsp), int(m.get("bwd_workgroups", 0)), _stream())
-                _lib.check(rc, "cgvp_gine_conv_bwd")
-                off = 0
-                for j, k in enumerate(_GINE_KEYS):
-                    grads[7 * l + j] = glayer[off:off + sizes[j]].view(ws[l][k].shape)
-                    off += sizes[j]
-                g = g_x
-        return (None, g if ctx.needs_input_grad[1] else None, None) + tuple(grads)
+            cin, cout = widths[l], widths[l + 1]
+            w = {k: _f32(v, k) for k, v in ws[l].items()}
+            glayer = gflat[sum(layer_floats[:l]):sum(layer_floats[:l + 1])]
+            want_x = (not first) or need_x
+            g_x = torch.empty(N, cin - (num_ntypes if first else 0), **f32) if want_x else None
+            gw = _lib.GineW(**{k: v.data_ptr() for k, v in w.items()})
+            rc = L.cgvp_gine_conv_bwd(_ptr(hs[l]), _ptr(nt if first else None), num_ntypes if first else 0,
+                                      _ptr(eattr), _ptr(et), num_etypes, edge_dim, _ptr(csr.rowptr),
+                                      _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst), N, csr.num_edges, cin, cout, cout,
+                                      C.byref(gw), float(slope), _ptr(mk[l]), _ptr(g), _ptr(g_x),
+                                      _ptr(glayer), _ptr(wsp), int(bwd_workgroups), _stream())
+            _lib.check(rc, "cgvp_gine_conv_bwd")
+            g = g_x
+    return gflat, (g if need_x else torch.empty(0, **f32))
 
 
-def gine_encoder(model, x, ntypes, eattr, etypes, csr, slope, train_dropout, bwd_workgroups=0):
-    """HomoMoleculeGNN_GINE.forward with autograd (and inter-layer dropout when training)."""
+@gine_encoder_backward_op.register_fake
+def _(g_out, params, x, ntypes, eattr, etypes, edge_index, hidden, masks, widths, num_ntypes, num_etypes, slope,
+      need_x, bwd_workgroups):
+    gflat = x.new_empty((sum(p.numel() for p in params),), dtype=torch.float32)
+    return gflat, (x.new_empty(x.shape, dtype=torch.float32) if need_x else x.new_empty((0,), dtype=torch.float32))
+
+
+def _gine_setup(ctx, inputs, output):
+    params, x, ntypes, eattr, etypes, edge_index, widths, num_ntypes, num_etypes, slope, dropout_p, save_state = inputs
+    out, hidden, masks = output
+    if not save_state:
+        raise RuntimeError("caster_gvp::gine_encoder was run with save_state=False; gradients need save_state=True")
+    ctx.meta = (widths, num_ntypes, num_etypes, slope, len(params), len(hidden))
+    ctx.shapes = [tuple(p.shape) for p in params]
+    ctx.save_for_backward(x, ntypes, eattr, etypes, edge_index, *params, *hidden, *masks)
+
+
+def _gine_backward(ctx, g_out, g_hidden, g_masks):
+    widths, num_ntypes, num_etypes, slope, n_params, n_hidden = ctx.meta
+    x, ntypes, eattr, etypes, edge_index, *rest = ctx.saved_tensors
+    params, hidden, masks = rest[:n_params], rest[n_params:n_params + n_hidden], rest[n_params + n_hidden:]
+    need_x = bool(ctx.needs_input_grad[1])
+    gflat, g_x = torch.ops.caster_gvp.gine_encoder_backward(
+        g_out.contiguous(), params, x, ntypes, eattr, etypes, edge_index, hidden, masks, widths, num_ntypes,
+        num_etypes, slope, need_x, GINE_BWD_WORKGROUPS)
+    grads = [g.view(s) for g, s in zip(torch.split(gflat, [_numel(s) for s in ctx.shapes]), ctx.shapes)]
+    return (grads, g_x if need_x else None, None, None, None, None, None, None, None, None, None, None)
+
+
+# Cap on the CUs of the GINE backward (0 = the library default of 16: inside JointGNN it runs beside the
+# protein backward, whose kernels own 240 of the 256 CUs).  A host that trains the drug encoder alone may
+# raise it; it is forwarded as the `max_workgroups` ARGUMENT of cgvp_gine_conv_bwd (the library has no state).
+GINE_BWD_WORKGROUPS = 0
+
+torch.library.register_autograd("caster_gvp::gine_encoder", _gine_backward, setup_context=_gine_setup)
+torch.library.register_autocast("caster_gvp::gine_encoder", "cuda", torch.float32)
+
+
+def gine_encoder(model, x, ntypes, eattr, etypes, edge_index, slope, train_dropout, save_state):
+    """HomoMoleculeGNN_GINE.forward through the custom op (autograd, inter-layer dropout when training)."""
     if eattr.requires_grad:
         raise NotImplementedError("gradients w.r.t. bond features are not produced by the backward kernels")
     params = []
     for conv in model.conv_list:
         kw = conv.kernel_weights()
         params += [kw[k] for k in _GINE_KEYS]
-    meta = dict(widths=model._widths, ntypes=ntypes, etypes=etypes, num_ntypes=model.num_ntypes,
-                num_etypes=model.num_etypes, csr=csr, slope=slope,
-                dropout=float(model.dropout_rate) if train_dropout else 0.0, bwd_workgroups=bwd_workgroups)
-    return _GineEncoderFn.apply(meta, x, eattr, *params)
+    out, _, _ = torch.ops.caster_gvp.gine_encoder(
+        params, x, ntypes, eattr, etypes, edge_index, list(model._widths), model.num_ntypes, model.num_etypes,
+        float(slope), float(model.dropout_rate) if train_dropout else 0.0, save_state)
+    return out

@@ -190,6 +190,26 @@ def cached_csr(edge_index, num_nodes):
     return csr
 
 
+def csr_for_forward(edge_index, num_nodes):
+    """`cached_csr`, plus a forward -> backward hand-off that does not depend on CSR_CACHE_ENABLED: the tables
+    of the latest forward over this tensor object are left on it for the backward of the same step (autograd
+    hands the saved `edge_index` back as the same Python object in eager mode)."""
+    csr = cached_csr(edge_index, num_nodes)
+    try:
+        edge_index._cgvp_csr_step = (edge_index._version, csr)
+    except (AttributeError, RuntimeError):
+        pass
+    return csr
+
+
+def csr_for_backward(edge_index, num_nodes):
+    memo = getattr(edge_index, "_cgvp_csr_step", None)
+    if memo is not None and memo[0] == edge_index._version and memo[1].num_nodes == num_nodes \
+            and memo[1].num_edges == int(edge_index.shape[1]) and memo[1].rowptr.device == edge_index.device:
+        return memo[1]
+    return cached_csr(edge_index, num_nodes)      # e.g. under torch.compile: a different tensor object
+
+
 def prepare_image(params, layout, dims):
     """Fragment image of the arena for the MFMA kernels (one small launch)."""
     L = _lib.lib()

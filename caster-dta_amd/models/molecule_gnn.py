@@ -149,9 +149,6 @@ class HomoMoleculeGNN_GINE(BaseMoleculeGNN):
             GINEConv(MLP([a, b, b]), gin_trainable_eps, edge_w, a, aggr=self.aggr)
             for a, b in zip(widths[:-1], widths[1:])])
         self._widths = widths
-        # cap on the CUs of the GINE backward (0 = the library default of 16, sized to run beside the protein
-        # backward inside JointGNN); a caller training this encoder alone may raise it (<= 256)
-        self.bwd_workgroups = 0
 
     def forward(self, x, edge_index, ntypes, etypes, eattr=None, batch=None):
         slope = activation_slope(self.activation)
@@ -162,18 +159,12 @@ class HomoMoleculeGNN_GINE(BaseMoleculeGNN):
             raise NotImplementedError("nn.Embedding type encoders are not compiled into the fused GINE kernel")
         if eattr is None:
             raise NotImplementedError("the GINE encoder needs edge features (eattr)")
-        csr = ops.cached_csr(edge_index, int(x.shape[0]))
+        if not x.is_cuda:
+            raise RuntimeError(f"x: caster-dta_amd runs on MI355X only (got a {x.device} tensor); there is no CPU path")
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or eattr.requires_grad
                                                   or any(p.requires_grad for p in self.parameters()))
         train_dropout = self.training and self.dropout_rate > 0 and self.num_convs > 1
-        if needs_grad or train_dropout:
-            from gvp_hip import autograd_ops
-            return autograd_ops.gine_encoder(self, x, ntypes, eattr, etypes, csr, slope, train_dropout,
-                                             bwd_workgroups=self.bwd_workgroups)
-        h = x
-        for l, conv in enumerate(self.conv_list):
-            first = l == 0
-            h = ops.gine_conv_forward(h, ntypes if first else None, self.num_ntypes if first else 0, eattr,
-                                      etypes, self.num_etypes, csr, conv.kernel_weights(), self._widths[l],
-                                      self._widths[l + 1], self._widths[l + 1], slope)
-        return h
+        from gvp_hip import autograd_ops
+        # ONE custom op (caster_gvp::gine_encoder) for the whole encoder: one launch per layer (+ the CSR build)
+        return autograd_ops.gine_encoder(self, x, ntypes, eattr, etypes, edge_index, slope, train_dropout,
+                                         save_state=bool(needs_grad or train_dropout))

@@ -140,9 +140,9 @@ class VectorProteinGNN_LBAModel(BaseProteinGNN):
         self.gvp_norm_before_scalar = gvp.LayerNorm(self.hidden_channels)
         self.gvp_to_scalar = gvp.GVP(self.hidden_channels, self.out_channels,
                                      activations=(self.gvp_relu, None), vector_gate=True)
-        self._arena = None
+        named = dict(self.named_parameters())
+        self._arena = ParamArena([named[k] for k in lba_param_keys(self.num_convs)])
         self._hip_cfg = None
-        self._image = None          # (key, fragment image) for the MFMA kernels
 
     # ------------------------------------------------------------------ HIP path
     def _hip_config(self):
@@ -163,13 +163,21 @@ class VectorProteinGNN_LBAModel(BaseProteinGNN):
         return self._hip_cfg
 
     def _arena_buffer(self):
-        if self._arena is None:
-            named = dict(self.named_parameters())
-            self._arena = ParamArena([named[k] for k in lba_param_keys(self.num_convs)])
+        """Re-seat the parameters as views into one flat buffer if something moved them (eager only; the custom
+        op also accepts parameters that are NOT arena views -- it then concatenates them, one extra launch)."""
         dims, layout = self._hip_config()
         if self._arena.total != layout.total:
             raise RuntimeError(f"parameter arena has {self._arena.total} floats, kernels expect {layout.total}")
         return self._arena.buffer()
+
+    def _apply(self, fn, *args, **kwargs):
+        """.to() / .cuda() / .float() re-materialise every parameter: rebuild the arena right away, so that a
+        model handed to torch.compile (which never runs the eager bookkeeping in forward) is already zero-copy."""
+        out = super()._apply(fn, *args, **kwargs)
+        p0 = self._arena.params[0]
+        if p0.is_cuda and p0.dtype == torch.float32:
+            self._arena.rebuild()
+        return out
 
     def forward(self, x, edge_index, ntypes, etypes, eattr=None, batch=None):
         x_s, x_v = x
@@ -178,29 +186,22 @@ class VectorProteinGNN_LBAModel(BaseProteinGNN):
         e_s, e_v = eattr
         if self.aggr not in ("sum", "add", "mean"):
             raise ValueError(f"unsupported aggregation {self.aggr!r}")
-        dims, layout = self._hip_config()
-        params = self._arena_buffer()
-        if params.dtype != torch.float32:
+        if not x_s.is_cuda:
+            raise RuntimeError(f"x: caster-dta_amd runs on MI355X only (got a {x_s.device} tensor); there is no CPU path")
+        p0 = self._arena.params[0]
+        if p0.dtype != torch.float32:
             raise TypeError("the MI355X kernels are fp32; call .float() on the model")
+        if self.out_channels[1] != 0:
+            raise NotImplementedError("the fused head produces scalars only (out_channels = (n, 0))")
+        if not (self._onehot_ntypes and self._onehot_etypes):
+            raise NotImplementedError("ntype_emb_dim / etype_emb_dim (nn.Embedding type encoders) are not "
+                                      "compiled into the fused kernels; use the default one-hot encoding")
+        if not torch.compiler.is_compiling():
+            self._arena_buffer()
         needs_grad = torch.is_grad_enabled() and (
-            params.requires_grad or any(p.requires_grad for p in self._arena.params)
-            or any(t.requires_grad for t in (x_s, x_v, e_s, e_v)))
+            any(p.requires_grad for p in self._arena.params) or any(t.requires_grad for t in (x_s, x_v, e_s, e_v)))
         train_dropout = self.training and self.dropout_rate > 0
-        csr = ops.cached_csr(edge_index, int(x_s.shape[0]))
-        if needs_grad or train_dropout:
-            from gvp_hip import autograd_ops
-            return autograd_ops.lba_encoder(self, params, layout, dims, x_s, x_v, ntypes, e_s, e_v, etypes,
-                                            csr, train_dropout)
-        return ops.lba_encoder_forward(params, layout, dims, self.num_convs, x_s, x_v, ntypes, e_s, e_v,
-                                       etypes, csr, aggr_mean=(self.aggr == "mean"),
-                                       image=self._fragment_image(params, layout, dims))
-
-    def _fragment_image(self, params, layout, dims):
-        """Fragment image of the current weights; rebuilt (one small launch) whenever
-        any parameter was written since the last build."""
-        if ops.VARIANT != "mfma":
-            return None
-        key = (params.data_ptr(), sum(p._version for p in self._arena.params))
-        if self._image is None or self._image[0] != key:
-            self._image = (key, ops.prepare_image(params, layout, dims))
-        return self._image[1]
+        from gvp_hip import autograd_ops
+        # ONE custom op (caster_gvp::lba_encoder) for the whole encoder: 1 + num_convs launches (+ the CSR build)
+        return autograd_ops.lba_encoder(self, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, train_dropout,
+                                        save_state=bool(needs_grad or train_dropout))

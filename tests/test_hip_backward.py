@@ -117,8 +117,7 @@ def test_training_dropout_with_pinned_masks(protein_params, monkeypatch):
     N = gb.num_nodes
     gen = torch.Generator().manual_seed(0)
     pinned = [((torch.rand(N, 20, generator=gen) < 0.8).float() / 0.8) for _ in range(4)]
-    it = iter(pinned)
-    monkeypatch.setattr(autograd_ops, "_dropout_mask", lambda n, p, dev: next(it).to(dev))
+    monkeypatch.setattr(autograd_ops, "_dropout_masks", lambda count, n, p, dev: torch.stack(pinned).to(dev))
     model = _encoder(protein_params).train()
     d = ds.to_torch(gb)
     dd = _to(d)
@@ -133,7 +132,7 @@ def test_training_dropout_with_pinned_masks(protein_params, monkeypatch):
     _check_grads(model, {k: v.grad for k, v in P.items() if v.numel()})
     # and the masks torch draws have the right statistics (per node x channel, scale 1/(1-p))
     monkeypatch.undo()
-    m = autograd_ops._dropout_mask(20000, 0.2, DEV)
+    m = autograd_ops._dropout_masks(1, 20000, 0.2, DEV)[0]
     assert set(np.unique(m.cpu().numpy()).round(4)) == {0.0, 1.25}
     assert abs(float((m == 0).float().mean()) - 0.2) < 0.01
 

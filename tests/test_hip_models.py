@@ -109,14 +109,3 @@ def test_hip_graph_capture_replays(joint):
             assert torch.equal(out, eager)
     finally:
         ops.CSR_CACHE_ENABLED = old
-
-
-def test_training_mode_not_silently_wrong(joint):
-    """Until the backward kernels land, asking for gradients must raise, not fall back."""
-    p = ds.protein_batch(1, 5, length=30)
-    d = _to(ds.to_torch(p))
-    try:
-        from gvp_hip import autograd_ops  # noqa: F401
-    except ImportError:
-        with pytest.raises(ImportError):
-            joint.protein_gnn(**d)
