@@ -1,20 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- graph-pairs/sec of the CASTER-DTA encoder hot path on MI355X.
 
-One "step" = one pass of the hot path over one batch of Davis-shaped synthetic
-pairs resident in HBM: destination-sorted CSR build for both graphs, the protein
-GVP encoder (node embed, 2 x [conv, node update], head) and the drug GINE encoder
-(2 layers).  N>1: one process per GPU (torchrun), each rank runs its own shard of
-pairs -- the encoders have no cross-pair term, so there is no data-path
-collective (weak scaling); timing is barrier + synchronize on both sides, MAX
-over ranks.
+One "step" = one pass of the hot path over one batch of synthetic pairs resident in HBM: destination-sorted CSR
+build for both graphs, the protein GVP encoder (node embed, L x [conv + node update], head) and the drug GINE encoder,
+forward + backward with every weight gradient, in TRAINING mode (dropout p = 0.2 drawn and applied every step, as
+train_model.py:291 trains).  N > 1: one process per GPU (torchrun), each rank runs its own shard of pairs (weak
+scaling) and the step ends with the two collectives data-parallel training of this model needs over RCCL: the
+all-gather of the per-pair embeddings [pairs, 512] fp32 (joint_gnn.py:272) and ONE flat all-reduce of the encoder
+weight gradients.  Timing: barrier + synchronize on both sides, MAX over ranks.
 
-Prints ONE JSON line (see DESIGN.md "Measurement" for the definitions of
-`roofline` and `cpu_baseline`).
+Prints ONE JSON line (DESIGN.md "Measurement" defines `roofline` and `cpu_baseline`).
 """
 import argparse
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -28,9 +29,18 @@ import torch  # noqa: E402
 WORKLOADS = {
     # BASELINE.json configs[1]: Davis, batch 64 pairs, CASTER-DTA(2,2), 300-residue radius graphs (4 A)
     "davis_b64": dict(pairs=64, length=300, thresh=4.0, thresh_type="dist"),
-    # configs[3]: 1000-residue proteins, ~20 edges/residue (kNN 20), replicated to fill the device
+    # configs[2], one rank's share: KIBA, 32 pairs per GPU, protein lengths drawn from the KIBA sequence-length table
+    "kiba_b32": dict(pairs=32, lengths="kiba", thresh=4.0, thresh_type="dist"),
+    # configs[3]: 1000-residue proteins, 20 edges/residue (kNN 20), replicated x64 to fill the device
     "long_graph_x64": dict(pairs=64, length=1000, thresh=20, thresh_type="num"),
 }
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32: 64 FLOP/clk/SIMD = the fp32 vector rate
+# Matrix-core work of the conv kernels per 16-edge tile (MFMA issues of 16x16x4 = 2,048 FLOP
+# each) and the algorithmic MACs per edge behind them (edge embed 1,126 + message 2,543 = 3,669;
+# the backward recomputes the forward and back-propagates data and weights: 3x).
+MFMA_PER_TILE = {"conv_fwd": 103, "conv_bwd": 319}
+MAC_PER_EDGE = {"conv_fwd": 3669, "conv_bwd": 3 * 3669}
 
 
 def parse():
@@ -40,8 +50,13 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="davis_b64", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="fwdbwd", choices=["fwd", "fwdbwd"],
-                    help="fwdbwd (default, BASELINE config 2): forward + backward of both encoders incl. all "
-                         "weight gradients; fwd: inference forward only")
+                    help="fwdbwd (default, BASELINE config 2): training step of both encoders (dropout on, forward + "
+                         "backward incl. all weight gradients); fwd: inference forward only (eval mode)")
+    ap.add_argument("--eval-mode", action="store_true",
+                    help="fwdbwd without dropout (model.eval()): the round-1 measurement, for A/B only")
+    ap.add_argument("--scope", default="encoders", choices=["encoders", "joint"],
+                    help="encoders (default: the metric of BASELINE.json); joint: the whole JointGNN training step "
+                         "(encoders + cross-attention head + MSE loss) with enable_pair_parallel() on N > 1")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--cache-csr", action="store_true", help="reuse the CSR tables across steps")
     ap.add_argument("--collate-csr", action="store_true",
@@ -52,8 +67,35 @@ def parse():
                     help="diagnostic: 'main' runs the drug encoder on the protein stream (no overlap)")
     ap.add_argument("--only", default=None, choices=["protein", "drug"],
                     help="diagnostic: time one encoder alone (the reported metric needs both; never the default)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-runs", type=int, default=20, help="timed CPU-baseline runs per thread count (median)")
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (0 = choose for ~10-30 s)")
     return ap.parse_args()
+
+
+def kernel_source_digest():
+    h = hashlib.sha256()
+    d = os.path.join(REPO, "caster-dta_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(workload, kernel):
+    """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
+    gfx950 correction applied: tools/pmc_summarise.py).  Only reported when the file was measured on the SAME
+    kernel sources and workload; otherwise null (a stale number is worse than none)."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(REPO, "profiles", rnd, f"pmc_traffic_{workload}.json")
+        if not os.path.exists(path) and workload == "davis_b64":
+            path = os.path.join(REPO, "profiles", rnd, "pmc_traffic.json")
+        if not os.path.exists(path):
+            continue
+        doc = json.load(open(path))
+        if doc.get("kernel_source_digest") != kernel_source_digest():
+            continue
+        return doc["kernels"].get(kernel, {}).get("hbm_bytes_per_launch")
+    return None
 
 
 def main():
@@ -64,25 +106,38 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     # Rehearsal on a box with fewer GPUs than ranks (BENCH_REHEARSAL=1): all ranks share cuda:0 and the
-    # timing collective runs over gloo.  The real multi-GPU run is one rank per GPU over RCCL ("nccl").
+    # collectives run over gloo on host copies.  The real multi-GPU run is one rank per GPU over RCCL ("nccl").
     rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    # BENCH_FORCE_COLLECTIVES=1: issue the N > 1 collectives at world size 1 too (exercises the RCCL calls on one GPU)
+    force_coll = os.environ.get("BENCH_FORCE_COLLECTIVES") == "1"
     dev = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    dist = None
+    if world > 1 or force_coll:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    collectives = dist is not None
 
     import davis_synth as ds
     from gvp_hip import ops
     import __graft_entry__ as entry
 
     wl = WORKLOADS[args.workload]
+    train = args.mode == "fwdbwd"
+    dropout_on = train and not args.eval_mode
     model, state = entry._load_model(dev)
-    pb, mb = ds.pair_batch(wl["pairs"], seed=rank, length=wl["length"], thresh=wl["thresh"],
-                           thresh_type=wl["thresh_type"])
+    model.train(dropout_on)
+    lengths = ds.real_lengths(wl["lengths"], wl["pairs"], seed=1000 + rank) if "lengths" in wl else None
+    pb, mb = ds.pair_batch(wl["pairs"], seed=rank, length=wl.get("length", 300), thresh=wl["thresh"],
+                           thresh_type=wl["thresh_type"], lengths=lengths)
     to = lambda d: {k: (tuple(t.to(dev) for t in v) if isinstance(v, tuple) else v.to(dev)) for k, v in d.items()}
     pdata_cpu, mdata_cpu = ds.to_torch(pb), ds.to_torch(mb)
     pdata, mdata = to(pdata_cpu), to(mdata_cpu)
@@ -100,17 +155,25 @@ def main():
             return st, st.plan(range(gb.num_graphs))
         collate = (store_of(pb, pdata), store_of(mb, mdata))
 
-    train = args.mode == "fwdbwd"
     prot_params = [p for p in model.protein_gnn.parameters() if p.numel()]
     drug_params = [p for p in model.molecule_gnn.parameters() if p.numel()]
     enc_params = prot_params + drug_params
+    n_enc = sum(p.numel() for p in enc_params)
     for p in model.parameters():
         p.requires_grad_(train)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     g_res = torch.randn(pb.num_nodes, 64, device=dev, generator=gen)     # upstream gradients of the embeddings
     g_atm = torch.randn(mb.num_nodes, 64, device=dev, generator=gen)
+    target = torch.randn(wl["pairs"] * world, 1, device=dev, generator=gen)
+    # payloads of the N > 1 collectives in --scope encoders: the tensor joint_gnn.py:272 all-gathers (synthetic
+    # values, real shape / dtype) and the flat gradient bucket of both encoders (real gradients)
+    pair_local = torch.randn(wl["pairs"], 512, device=dev, generator=gen)
+    pair_all = torch.empty(wl["pairs"] * world, 512, device=dev)
+    grad_bucket = torch.zeros(n_enc, device=dev)
+    if args.scope == "joint" and collectives and (world > 1 or force_coll):
+        model.enable_pair_parallel()
 
-    def step():
+    def encoders_step():
         main_s = torch.cuda.current_stream()
         if args.only == "protein":                    # diagnostic: one encoder alone
             residues = model.protein_gnn(**pdata)
@@ -132,11 +195,47 @@ def main():
         # backward of both encoders: every weight gradient (22,507 parameters) is produced
         return torch.autograd.grad([residues, atoms], enc_params, [g_res, g_atm])
 
+    def joint_step():
+        if collate:
+            collate[1][0].collate(collate[1][1], attach_to=mdata["edge_index"])
+            collate[0][0].collate(collate[0][1], attach_to=pdata["edge_index"])
+        pred, _ = model(pdata, mdata)
+        if not train:
+            return pred
+        for p in model.parameters():
+            p.grad = None
+        loss = torch.nn.functional.mse_loss(pred, target[:pred.shape[0]])
+        loss.backward()
+        return loss
+
+    step = encoders_step if args.scope == "encoders" else joint_step
+
+    def comm(out):
+        """The per-step collectives of data-parallel training (issued eagerly after the compute of the step)."""
+        if not collectives:
+            return
+        if args.scope == "joint":
+            if train:
+                model.reduce_pair_parallel_grads()
+            return
+        if rehearsal:                                  # gloo on host copies (cuda:0 is shared by all ranks)
+            gathered = [torch.empty(pair_local.shape) for _ in range(world)]
+            dist.all_gather(gathered, pair_local.cpu())
+            if train:
+                flat = torch.cat([g.reshape(-1) for g in out]).cpu()
+                dist.all_reduce(flat)
+            return
+        dist.all_gather_into_tensor(pair_all, pair_local)
+        if train:
+            torch.cat([g.reshape(-1) for g in out], out=grad_bucket)
+            dist.all_reduce(grad_bucket)
+
     with torch.set_grad_enabled(train):
         out = step()
         torch.cuda.synchronize()
         graph = None
-        if not args.no_graph and args.only != "drug" and args.drug_stream == "side":   # drug-only / same-stream diagnostics run eagerly
+        # the joint step is launched eagerly (its dense-padding head has data-dependent shapes: Lmax = int(counts.max()))
+        if not args.no_graph and args.scope == "encoders" and args.only != "drug" and args.drug_stream == "side":
             s = torch.cuda.Stream(device=dev)
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
@@ -146,7 +245,14 @@ def main():
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = step()
-        run = graph.replay if graph is not None else step
+
+        def run():
+            o = out
+            if graph is not None:
+                graph.replay()
+            else:
+                o = step()
+            comm(o)
 
         def barrier():
             if world > 1:
@@ -166,7 +272,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t)
 
-        # ---- roofline leg: per-launch duration of the dominant kernel (conv_fwd), HIP events on its stream
+        # ---- roofline leg: per-launch duration of the dominant conv kernel, HIP events on its launch stream
         roof = None
         if rank == 0:
             ops.KERNEL_EVENTS = []
@@ -181,56 +287,52 @@ def main():
             conv_bytes = 224 * N + 156 * E            # algorithmic bytes of one conv launch
             # dominant kernel = the conv kernel with the largest share of the step (backward when training);
             # backward counted as 2x the forward bytes (fwd + bwd = 3x forward)
-            if not by:                                # --only drug: no conv kernel to report
-                by = {"conv_fwd": [float("nan")]}
-            name = max(by, key=lambda k: sum(by[k]))
-            times = sorted(by[name])
-            nbytes = conv_bytes * (2 if name == "conv_bwd" else 1)
-            avg = sum(times) / len(times)
-            peak = 8000.0
-            kname = {"conv_fwd": "conv_quad_kernel" if ops.VARIANT == "mfma" else "conv_fwd_kernel",
-                     "conv_bwd": "conv_bwd_kernel"}[name]
-            # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-            # separate runs, gfx950 correction applied; profiles/r01/pmc_traffic.json) -- same workload only
-            traffic = None
-            pmc = os.path.join(REPO, "profiles", "r01", "pmc_traffic.json")
-            if args.workload == "davis_b64" and os.path.exists(pmc):
-                k = "conv_bwd_kernel" if name == "conv_bwd" else "conv_quad_kernel"
-                traffic = json.load(open(pmc))["kernels"].get(k, {}).get("hbm_bytes_per_launch")
-            roof = dict(bound="hbm", achieved=round(nbytes / avg / 1e9, 1), peak=peak, unit="GB/s",
-                        frac=round(nbytes / avg / 1e9 / peak, 4), traffic=traffic, kernel=kname,
-                        avg_us=round(avg * 1e6, 2), median_us=round(times[len(times) // 2] * 1e6, 2),
-                        bytes_per_launch=nbytes, launches=len(times),
-                        other={k: round(sum(v) / len(v) * 1e6, 2) for k, v in by.items() if k != name})
+            if by:
+                name = max(by, key=lambda k: sum(by[k]))
+                times = sorted(by[name])
+                nbytes = conv_bytes * (2 if name == "conv_bwd" else 1)
+                avg = sum(times) / len(times)
+                kname = {"conv_fwd": "conv_quad_kernel" if ops.VARIANT == "mfma" else "conv_fwd_kernel",
+                         "conv_bwd": "conv_bwd_kernel"}[name]
+                hbm = dict(achieved=round(nbytes / avg / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                           frac=round(nbytes / avg / 1e9 / PEAK_HBM_GBS, 4), floor_us=round(nbytes / PEAK_HBM_GBS / 1e3, 2))
+                tiles = (E + 15) // 16                # 16 sorted edges per wave tile
+                issued = MFMA_PER_TILE[name] * tiles * 2048.0
+                useful = 2.0 * MAC_PER_EDGE[name] * E
+                mfma = dict(achieved=round(useful / avg / 1e12, 2), issued=round(issued / avg / 1e12, 2),
+                            peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                            frac=round(useful / avg / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                            frac_issued=round(issued / avg / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                            floor_us=round(issued / PEAK_F32_MFMA_TFLOPS / 1e6, 2),
+                            mfma_per_16_edges=MFMA_PER_TILE[name], useful_mac_per_edge=MAC_PER_EDGE[name])
+                # the bound is whichever floor is higher for THIS kernel at THIS size
+                bound = "mfma" if mfma["floor_us"] > hbm["floor_us"] else "hbm"
+                top = mfma if bound == "mfma" else hbm
+                roof = dict(bound=bound, achieved=top["achieved"], peak=top["peak"], unit=top["unit"], frac=top["frac"],
+                            traffic=committed_traffic(args.workload, kname), kernel=kname,
+                            avg_us=round(avg * 1e6, 2), median_us=round(times[len(times) // 2] * 1e6, 2),
+                            bytes_per_launch=nbytes, launches=len(times), hbm=hbm, mfma=mfma,
+                            other={k: round(sum(v) / len(v) * 1e6, 2) for k, v in by.items() if k != name})
 
     pairs_per_step = wl["pairs"] * world
     value = pairs_per_step * args.steps / dt
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
-        from oracle import gvp_oracle as O
-        pp = {k[len("protein_gnn.gnn_model."):]: v for k, v in state.items() if k.startswith("protein_gnn.gnn_model.")}
-        mp = {k[len("molecule_gnn.gnn_model."):]: v for k, v in state.items() if k.startswith("molecule_gnn.gnn_model.")}
-
-        def cpu_step():
-            O.protein_lba_forward(pp, pdata_cpu["x"], pdata_cpu["edge_index"], pdata_cpu["ntypes"],
-                                  pdata_cpu["etypes"], pdata_cpu["eattr"])
-            O.molecule_gine_forward(mp, mdata_cpu["x"], mdata_cpu["edge_index"], mdata_cpu["ntypes"],
-                                    mdata_cpu["etypes"], mdata_cpu["eattr"])
-        with torch.no_grad():
-            cpu_step()
-            n, t0 = 0, time.perf_counter()
-            while n < 3 or time.perf_counter() - t0 < args.cpu_seconds:
-                cpu_step()
-                n += 1
-            cdt = time.perf_counter() - t0
-        cpu = dict(value=round(wl["pairs"] * n / cdt, 1), unit="graph-pairs/sec", cores=torch.get_num_threads(),
-                   kind="port", sample=f"{n} forward passes of the same {wl['pairs']}-pair batch through "
-                   "oracle/gvp_oracle.py (torch CPU eager fp32)")
+        cpu = cpu_baseline(args, wl, state, pb, mb, train)
 
     if rank == 0:
+        what = "encoders" if args.scope == "encoders" else "JointGNN"
+        par = f"pairs sharded x{world}"
+        if collectives and args.scope == "encoders":
+            par += (f"; per step over RCCL: all-gather [{wl['pairs']},512] fp32 pair embeddings (synthetic payload) + "
+                    f"all-reduce of {n_enc} encoder gradients" if not rehearsal else "; gloo rehearsal of the collectives")
+        elif collectives:
+            par += "; enable_pair_parallel(): all-gather of pair embeddings + flat all-reduce of pre-gather gradients"
+        else:
+            par += ", no collective"
         line = {
-            "metric": "graph-pairs/sec (Davis-shaped protein+drug), encoders " + ("fwd+bwd" if train else "forward"),
+            "metric": f"graph-pairs/sec (Davis-shaped protein+drug), {what} " + ("fwd+bwd" if train else "forward"),
             "value": round(value, 1), "unit": "graph-pairs/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -238,14 +340,92 @@ def main():
             "config": {"workload": args.workload, "pairs_per_gpu": wl["pairs"], "residues_per_gpu": pb.num_nodes,
                        "protein_edges_per_gpu": pb.num_edges, "atoms_per_gpu": mb.num_nodes,
                        "drug_edges_per_gpu": mb.num_edges, "encoder": "CASTER-DTA(2,2)", "pass": args.mode,
-                       "csr_build_in_step": ("collate" if args.collate_csr else not args.cache_csr), "hip_graph": graph is not None,
-                       "kernels": ops.VARIANT,
-                       "parallelism": f"pairs sharded x{world}, no collective"},
+                       "scope": args.scope, "train_mode": bool(dropout_on), "dropout_p": 0.2 if dropout_on else 0.0,
+                       "csr_build_in_step": ("collate" if args.collate_csr else not args.cache_csr),
+                       "hip_graph": graph is not None, "kernels": ops.VARIANT, "parallelism": par},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
+
+
+def _cgroup_cpus():
+    """CPU share of this process's cgroup (the GPU box hands a 1-GPU job a slice of the host's cores)."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            return max(1, int(int(quota) / int(period)))
+    except Exception:
+        pass
+    return 1 << 20
+
+
+def cpu_baseline(args, wl, state, pb, mb, train):
+    """oracle/gvp_oracle.py (kind "port": torch CPU eager fp32, the reference's op order) on the host cores of the GPU
+    box, running the SAME pass as the headline (forward + backward through oracle autograd when training) on a
+    bounded sample of the same batch; thread counts {1, physical cores}; median of >= 20 runs after 3 warm-ups."""
+    import davis_synth as ds
+    from oracle import gvp_oracle as O
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        phys = os.cpu_count()
+    phys = max(1, min(phys, len(os.sched_getaffinity(0)), _cgroup_cpus()))
+    # bounded sample: whole graphs from the front of the batch, sized so 2 x (3 + runs) passes stay within ~30 s
+    budget_edges = 60000 if train else 180000
+    n = args.cpu_pairs or wl["pairs"]
+    if not args.cpu_pairs:
+        while n > 1 and int(pb.eptr[n]) > budget_edges:
+            n //= 2
+
+    def cut(gb):
+        ids = range(n)
+        return ds.collate([dict(x_s=gb.x_s[gb.ptr[i]:gb.ptr[i + 1]], x_v=None if gb.x_v is None else gb.x_v[gb.ptr[i]:gb.ptr[i + 1]],
+                                edge_index=gb.edge_index[:, gb.eptr[i]:gb.eptr[i + 1]] - gb.ptr[i],
+                                e_s=gb.e_s[gb.eptr[i]:gb.eptr[i + 1]],
+                                e_v=None if gb.e_v is None else gb.e_v[gb.eptr[i]:gb.eptr[i + 1]],
+                                ntypes=gb.ntypes[gb.ptr[i]:gb.ptr[i + 1]], etypes=gb.etypes[gb.eptr[i]:gb.eptr[i + 1]])
+                           for i in ids])
+    sp, sm = (pb, mb) if n == wl["pairs"] else (cut(pb), cut(mb))
+    pd, md = ds.to_torch(sp), ds.to_torch(sm)
+    pp = {k[len("protein_gnn.gnn_model."):]: v.clone().requires_grad_(train and v.numel() > 0)
+          for k, v in state.items() if k.startswith("protein_gnn.gnn_model.")}
+    mp = {k[len("molecule_gnn.gnn_model."):]: v.clone().requires_grad_(train)
+          for k, v in state.items() if k.startswith("molecule_gnn.gnn_model.")}
+    gr = torch.randn(sp.num_nodes, 64)
+    ga = torch.randn(sm.num_nodes, 64)
+    leaves = [v for v in list(pp.values()) + list(mp.values()) if v.requires_grad]
+
+    def cpu_step():
+        res = O.protein_lba_forward(pp, pd["x"], pd["edge_index"], pd["ntypes"], pd["etypes"], pd["eattr"])
+        atm = O.molecule_gine_forward(mp, md["x"], md["edge_index"], md["ntypes"], md["etypes"], md["eattr"])
+        if train:
+            torch.autograd.grad([res, atm], leaves, [gr, ga])
+
+    results = {}
+    old = torch.get_num_threads()
+    with torch.set_grad_enabled(train):
+        for threads in sorted({1, phys}, reverse=True):
+            torch.set_num_threads(threads)
+            for _ in range(3):
+                cpu_step()
+            ts = []
+            for _ in range(max(args.cpu_runs, 3)):
+                t0 = time.perf_counter()
+                cpu_step()
+                ts.append(time.perf_counter() - t0)
+            results[threads] = statistics.median(ts)
+    torch.set_num_threads(old)
+    best = min(results, key=results.get)         # `value` is the faster of the two settings, `cores` its thread count
+    return dict(value=round(n / results[best], 1), unit="graph-pairs/sec", cores=best, kind="port",
+                by_threads={str(k): round(n / v, 1) for k, v in sorted(results.items())},
+                sample=f"median of {max(args.cpu_runs, 3)} runs after 3 warm-ups of the same pass as the headline "
+                       f"({'forward + backward (oracle autograd, all weight gradients)' if train else 'forward'}) over "
+                       f"the first {n} of the {wl['pairs']} pairs of the batch ({sp.num_nodes} residues, {sp.num_edges} "
+                       f"protein edges) through oracle/gvp_oracle.py, torch CPU eager fp32; timed at 1 thread "
+                       f"and at {phys} threads (the physical cores this process may use), `value` = the faster")
 
 
 if __name__ == "__main__":

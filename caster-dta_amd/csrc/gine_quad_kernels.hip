@@ -52,8 +52,20 @@ struct GineQArgs {
   const int32_t* rowptr; const int32_t* eperm; const int32_t* esrc; const int32_t* edst; int64_t N;
   const float* eps; const float* we; const float* be; const float* w0; const float* b0;
   const float* w1; const float* b1; float slope;
-  const float* mask; const float* g_out; float* g_x; float* slab;
+  const float* mask; gvp::RngArgs rng; const float* g_out; float* g_x; float* slab;
 };
+
+// dropout factors of channels 16 mt + 4 g .. + 3 of atom n (given mask row of width COUT, or regenerated)
+template <int COUT>
+__device__ __forceinline__ f4 gine_dropout(const float* mask, const gvp::RngArgs& rng, int64_t n, int mt, int g) {
+  if (mask) return *reinterpret_cast<const f4*>(mask + n * COUT + 16 * mt + 4 * g);
+  if (rng.seed) {
+    float f[4];
+    gvp::dropout4(rng.seed[0], rng.seed[1], rng.stream, n, 4 * mt + g, rng.p, f);
+    return f4{f[0], f[1], f[2], f[3]};
+  }
+  return f4{1.f, 1.f, 1.f, 1.f};
+}
 
 template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
 struct GineQ {
@@ -312,7 +324,7 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
         f4 gy = zero;
         if (valid) {
           gy = *reinterpret_cast<const f4*>(a.g_out + n * COUT + 16 * mt + 4 * g);
-          if (a.mask) gy = gy * *reinterpret_cast<const f4*>(a.mask + n * COUT + 16 * mt + 4 * g);
+          gy = gy * gine_dropout<COUT>(a.mask, a.rng, n, mt, g);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) dy[mt][r] = gy[r] * (acc[0][r] > 0.f ? 1.f : a.slope);
@@ -483,7 +495,7 @@ struct GineFArgs {
   const float* x; const int64_t* ntypes; const float* eattr; const int64_t* etypes;
   const int32_t* rowptr; const int32_t* eperm; const int32_t* esrc; const int32_t* edst; int64_t N;
   const float* eps; const float* we; const float* be; const float* w0; const float* b0;
-  const float* w1; const float* b1; float slope; const float* mask; float* out;
+  const float* w1; const float* b1; float slope; const float* mask; gvp::RngArgs rng; float* out;
 };
 constexpr int GF_WPB = 4, GF_TPB = WAVE * GF_WPB;
 
@@ -626,7 +638,7 @@ __global__ __launch_bounds__(GF_TPB) void gine_quad_fwd_kernel(GineFArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) y[r] = acc[0][r] > 0.f ? acc[0][r] : acc[0][r] * a.slope;
         if (valid) {
-          if (a.mask) y = y * *reinterpret_cast<const f4*>(a.mask + n * COUT + 16 * mt + 4 * g);
+          y = y * gine_dropout<COUT>(a.mask, a.rng, n, mt, g);
           *reinterpret_cast<f4*>(a.out + n * COUT + 16 * mt + 4 * g) = y;
         }
       }
@@ -675,11 +687,11 @@ namespace quad {
 int gine_bwd(int cin, int chid, int cout, int nt, int net, int ed, const float* x, const int64_t* ntypes,
              const float* eattr, const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,
              const int32_t* esrc, const int32_t* edst, int64_t N, const cgvp_gine_w* w, float slope,
-             const float* mask, const float* g_out, float* g_x, float* slab, int max_workgroups, int* rows,
-             int* row_len, hipStream_t st) {
+             const float* mask, gvp::RngArgs rng, const float* g_out, float* g_x, float* slab, int max_workgroups,
+             int* rows, int* row_len, hipStream_t st) {
   const int cap = max_workgroups <= 0 ? kGineBwdDefaultGrid : (max_workgroups > kGineBwdMaxGrid ? kGineBwdMaxGrid : max_workgroups);
   GineQArgs a{x, ntypes, eattr, etypes, rowptr, eperm, esrc, edst, N, w->eps, w->we, w->be, w->w0, w->b0,
-              w->w1, w->b1, slope, mask, g_out, g_x, slab};
+              w->w1, w->b1, slope, mask, rng, g_out, g_x, slab};
   // compiled for the layer shapes of HomoMoleculeGNN_GINE in CASTER-DTA (molecule_gnn.py:240-250)
   if (cin == 52 && chid == 16 && cout == 16 && nt == 11 && net == 5 && ed == 9) return launch<52, 16, 16, 11, 5, 9>(a, cap, rows, row_len, st);
   if (cin == 16 && chid == 64 && cout == 64 && nt == 0 && net == 5 && ed == 9) return launch<16, 64, 64, 0, 5, 9>(a, cap, rows, row_len, st);
@@ -692,9 +704,9 @@ int gine_bwd(int cin, int chid, int cout, int nt, int net, int ed, const float* 
 int gine_fwd(int cin, int chid, int cout, int nt, int net, int ed, const float* x, const int64_t* ntypes,
              const float* eattr, const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,
              const int32_t* esrc, const int32_t* edst, int64_t N, const cgvp_gine_w* w, float slope,
-             const float* mask, float* out, hipStream_t st) {
+             const float* mask, gvp::RngArgs rng, float* out, hipStream_t st) {
   GineFArgs a{x, ntypes, eattr, etypes, rowptr, eperm, esrc, edst, N, w->eps, w->we, w->be, w->w0, w->b0,
-              w->w1, w->b1, slope, mask, out};
+              w->w1, w->b1, slope, mask, rng, out};
   if (cin == 52 && chid == 16 && cout == 16 && nt == 11 && net == 5 && ed == 9) return launch_fwd<52, 16, 16, 11, 5, 9>(a, st);
   if (cin == 16 && chid == 64 && cout == 64 && nt == 0 && net == 5 && ed == 9) return launch_fwd<16, 64, 64, 0, 5, 9>(a, st);
   if (cin == 16 && chid == 16 && cout == 16 && nt == 0 && net == 5 && ed == 9) return launch_fwd<16, 16, 16, 0, 5, 9>(a, st);

@@ -5,6 +5,7 @@
 
 #include "../../include/caster_gvp.h"
 #include "gvp_math.h"
+#include "gvp_rng.h"
 
 // Float offsets of the per-kernel slices inside the fragment image.
 struct QuadOffsets {
@@ -25,15 +26,17 @@ int node_embed(int nt_node, const float* img, const float* x_s, const float* x_v
 int conv(int nt_edge, const float* img, const float* h, const float* e_s, const float* e_v,
          const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
          const int32_t* edst, int64_t N, int64_t E, int mean, float* dh, int fuse, const float* img_node,
-         const float* img_head, float* h_out, float* out, const float* mask0, const float* mask1, hipStream_t st);
+         const float* img_head, float* h_out, float* out, const float* mask0, const float* mask1, gvp::RngArgs rng,
+         hipStream_t st);
 int node_update(const float* img_node, const float* img_head, const float* h, const float* dh, int64_t N,
-                int with_head, float* h_out, float* out, const float* mask0, const float* mask1, hipStream_t st);
+                int with_head, float* h_out, float* out, const float* mask0, const float* mask1, gvp::RngArgs rng,
+                hipStream_t st);
 
 // ---- backward (gvp_quad_bwd_kernels.hip).  Weight gradients are written as one
 // partial block per workgroup into `slab` ([grid][block floats]); `grid` returns
 // the number of rows to reduce.
 int node_update_bwd(const float* img_node, const float* imgT_node, const float* h, const float* dh,
-                    const float* mask0, const float* mask1, const float* g_up0, const float* g_up1,
+                    const float* mask0, const float* mask1, gvp::RngArgs rng, const float* g_up0, const float* g_up1,
                     const float* g_up2, int64_t N, float* g_dh, float* g_h, float* zero_rows, float* slab, int* grid,
                     hipStream_t st);
 int head_bwd(const float* img_head, const float* imgT_head, const float* h_out, const float* g_out, int64_t N,
@@ -52,12 +55,12 @@ constexpr int kGineBwdDefaultGrid = 16;   // the CUs the protein backward (kBwdM
 int gine_bwd(int cin, int chid, int cout, int nt, int net, int ed, const float* x, const int64_t* ntypes,
              const float* eattr, const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,
              const int32_t* esrc, const int32_t* edst, int64_t N, const cgvp_gine_w* w, float slope,
-             const float* mask, const float* g_out, float* g_x, float* slab, int max_workgroups, int* rows,
+             const float* mask, gvp::RngArgs rng, const float* g_out, float* g_x, float* slab, int max_workgroups, int* rows,
              int* row_len, hipStream_t st);
 int gine_fwd(int cin, int chid, int cout, int nt, int net, int ed, const float* x, const int64_t* ntypes,
              const float* eattr, const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,
              const int32_t* esrc, const int32_t* edst, int64_t N, const cgvp_gine_w* w, float slope,
-             const float* mask, float* out, hipStream_t st);
+             const float* mask, gvp::RngArgs rng, float* out, hipStream_t st);
 int reduce_slab(const float* slab, int rows, int stride, int col0, int len, float* dst, hipStream_t st);
 int reduce_segments(const cgvp_segment* segs, int nsegs, float* grad_params, hipStream_t st);
 int bwd_block_sizes(int nt_node, int nt_edge, int* emb, int* conv_edge, int* conv_total, int* node, int* head);

@@ -400,6 +400,7 @@ struct GineArgs {
   const float* eps; const float* we; const float* be; const float* w0; const float* b0;
   const float* w1; const float* b1; float slope; float* out;
   const float* mask;     // optional [N][cout] dropout factors applied after the activation
+  gvp::RngArgs rng;      // ... or generated in the kernel (mask == NULL, rng.seed != NULL)
 };
 
 constexpr int GINE_APB = 4;   // atoms (waves) per block
@@ -490,6 +491,11 @@ __global__ __launch_bounds__(WAVE * GINE_APB) void gine_conv_kernel(GineArgs a) 
     for (int k = 0; k < a.chid; ++k) y = fmaf(wr[k], tbuf[w][k], y);
     y = y > 0.f ? y : y * a.slope;
     if (a.mask) y *= a.mask[i * a.cout + lane];
+    else if (a.rng.seed) {
+      float f[4];
+      gvp::dropout4(a.rng.seed[0], a.rng.seed[1], a.rng.stream, i, lane >> 2, a.rng.p, f);
+      y *= f[lane & 3];
+    }
     a.out[i * a.cout + lane] = y;
   }
 }
@@ -502,6 +508,33 @@ constexpr int gine_layer_floats(int cin, int chid, int cout, int ke) {
 }
 
 }  // namespace
+
+// ------------------------------------------------------------- dropout plumbing
+static int check_rng(const cgvp_rng* rng) {
+  if (!rng || !rng->seed) return 0;
+  if (!(rng->p >= 0.f && rng->p < 1.f) || rng->stream < 0 || ((uintptr_t)rng->seed & 7)) return CGVP_ERR_BAD_ARG;
+  return 0;
+}
+// kernel-argument form; `base` = the stream the entry point's convention assigns when the caller leaves it 0
+static gvp::RngArgs rng_args(const cgvp_rng* rng, int base) {
+  if (!rng || !rng->seed) return gvp::RngArgs{nullptr, 0.f, 0};
+  (void)base;
+  return gvp::RngArgs{reinterpret_cast<const unsigned long long*>(rng->seed), rng->p, rng->stream};
+}
+
+struct MaskArgs { gvp::RngArgs rng; int num_masks; int64_t N; int width; float* out; };
+__global__ __launch_bounds__(256) void dropout_masks_kernel(MaskArgs a) {
+  const int64_t per = a.N * (a.width / 4), total = per * a.num_masks;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(t / per);
+    const int64_t r = t - (int64_t)m * per, n = r / (a.width / 4);
+    const int blk = (int)(r - n * (a.width / 4));
+    float f[4];
+    gvp::dropout4(a.rng.seed[0], a.rng.seed[1], a.rng.stream + m, n, blk, a.rng.p, f);
+    float* o = a.out + ((int64_t)m * a.N + n) * a.width + 4 * blk;
+    o[0] = f[0]; o[1] = f[1]; o[2] = f[2]; o[3] = f[3];
+  }
+}
 
 // ===================================================================== C ABI
 extern "C" {
@@ -610,7 +643,7 @@ int cgvp_conv_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float*
     if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
     if (int rc = quad::conv(layout->nt_edge, image + o.conv0 + layer * o.layer_stride, h, e_s, e_v, etypes, rowptr,
                             eperm, esrc, edst, N, E, aggr_mean ? 1 : 0, dh, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
-                            nullptr, (hipStream_t)stream)) return rc;
+                            nullptr, gvp::RngArgs{nullptr, 0.f, 0}, (hipStream_t)stream)) return rc;
     return launch_status();
   }
   // target nodes per workgroup: aim at ~48 of the 64 edge lanes per chunk
@@ -634,8 +667,9 @@ int cgvp_conv_layer_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
                         const float* h, const float* e_s, const float* e_v, const int64_t* etypes,
                         const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc, const int32_t* edst,
                         int64_t N, int64_t E, int32_t aggr_mean, const float* mask0, const float* mask1,
-                        int32_t with_head, float* dh, float* h_out, float* out, void* stream) {
+                        const cgvp_rng* rng, int32_t with_head, float* dh, float* h_out, float* out, void* stream) {
   if (int rc = check_dims(dims)) return rc;
+  if (int rc = check_rng(rng)) return rc;
   if (N < 0 || E < 0 || !layout || !image) return CGVP_ERR_BAD_ARG;
   if (layer < 0 || layer >= num_convs_of(*layout)) return CGVP_ERR_BAD_ARG;
   if (N == 0) return 0;
@@ -648,7 +682,7 @@ int cgvp_conv_layer_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
   if (int rc = quad::conv(layout->nt_edge, image + o.conv0 + layer * o.layer_stride, h, e_s, e_v, etypes, rowptr, eperm,
                           esrc, edst, N, E, aggr_mean ? 1 : 0, dh, with_head ? 2 : 1,
                           image + o.node0 + layer * o.layer_stride, image + o.head, h_out, out, mask0, mask1,
-                          (hipStream_t)stream)) return rc;
+                          rng_args(rng, 2 * layer), (hipStream_t)stream)) return rc;
   return launch_status();
 }
 
@@ -666,7 +700,8 @@ int cgvp_node_update_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const
     QuadOffsets o;
     if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
     if (int rc = quad::node_update(image + o.node0 + layer * o.layer_stride, image + o.head, h, dh, N,
-                                   with_head ? 1 : 0, h_out, out, nullptr, nullptr, (hipStream_t)stream)) return rc;
+                                   with_head ? 1 : 0, h_out, out, nullptr, nullptr, gvp::RngArgs{nullptr, 0.f, 0},
+                                   (hipStream_t)stream)) return rc;
     return launch_status();
   }
   NodeUpdateArgs a{params, cvt(*layout), layer, h, dh, N, h_out, out};
@@ -678,9 +713,10 @@ int cgvp_node_update_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const
 
 int cgvp_node_update_fwd_train(const cgvp_dims* dims, const cgvp_layout* layout, const float* image,
                                int32_t layer, const float* h, const float* dh, const float* mask0,
-                               const float* mask1, int64_t N, int32_t with_head, float* h_out, float* out,
-                               void* stream) {
+                               const float* mask1, const cgvp_rng* rng, int64_t N, int32_t with_head, float* h_out,
+                               float* out, void* stream) {
   if (int rc = check_dims(dims)) return rc;
+  if (int rc = check_rng(rng)) return rc;
   if (N < 0 || !layout || !image) return CGVP_ERR_BAD_ARG;
   if (layer < 0 || layer >= num_convs_of(*layout)) return CGVP_ERR_BAD_ARG;
   if (N == 0) return 0;
@@ -690,7 +726,8 @@ int cgvp_node_update_fwd_train(const cgvp_dims* dims, const cgvp_layout* layout,
   QuadOffsets o;
   if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
   if (int rc = quad::node_update(image + o.node0 + layer * o.layer_stride, image + o.head, h, dh, N,
-                                 with_head ? 1 : 0, h_out, out, mask0, mask1, (hipStream_t)stream)) return rc;
+                                 with_head ? 1 : 0, h_out, out, mask0, mask1, rng_args(rng, 2 * layer),
+                                 (hipStream_t)stream)) return rc;
   return launch_status();
 }
 
@@ -706,11 +743,12 @@ int64_t cgvp_bwd_workspace_floats(const cgvp_dims* dims, const cgvp_layout* layo
 
 int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image, int32_t layer,
                          const float* h, const float* dh, const float* mask0, const float* mask1,
-                         const float* h_out, const float* g_out, const float* g_up0, const float* g_up1,
+                         const cgvp_rng* rng, const float* h_out, const float* g_out, const float* g_up0, const float* g_up1,
                          const float* g_up2, int64_t N, int32_t with_head, float* g_dh, float* g_h,
                          float* zero_out, float* grad_params, float* workspace, cgvp_segment* segs, int32_t* nsegs,
                          void* stream) {
   if (int rc = check_dims(dims)) return rc;
+  if (int rc = check_rng(rng)) return rc;
   if (N < 0 || !layout || !image || !grad_params || !workspace) return CGVP_ERR_BAD_ARG;
   const int nc = num_convs_of(*layout);
   if (layer < 0 || layer >= nc) return CGVP_ERR_BAD_ARG;
@@ -730,7 +768,8 @@ int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const
     g_up0 = g_dh; g_up1 = nullptr; g_up2 = nullptr;
   }
   if (int rc = quad::node_update_bwd(image + o.node0 + layer * o.layer_stride, image + o.nodeT0 + layer * o.layerT_stride,
-                                     h, dh, mask0, mask1, g_up0, g_up1, g_up2, N, g_dh, g_h, zero_out, workspace, &grid, st)) return rc;
+                                     h, dh, mask0, mask1, rng_args(rng, 2 * layer), g_up0, g_up1, g_up2, N, g_dh, g_h, zero_out,
+                                     workspace, &grid, st)) return rc;
   const int node_len = conv_ff1() + LFf1::size(0) - conv_ln0();          // norm.0 .. end of ff_func.1
   cgvp_segment sg[2] = {{workspace, grid, nd, 0, node_len, layout->conv0 + layer * layout->conv_stride + conv_ln0()},
                         {head_slab, hgrid, hd, 0, layout->total - layout->ln_out, layout->ln_out}};
@@ -801,8 +840,11 @@ int cgvp_gine_conv_fwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
                        const int64_t* etypes, int32_t num_etypes, int32_t edge_dim,
                        const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc, const int32_t* edst,
                        int64_t N, int64_t E, int32_t cin, int32_t chid, int32_t cout, const cgvp_gine_w* w,
-                       float act_slope, const float* mask, int32_t variant, float* out, void* stream) {
+                       float act_slope, const float* mask, const cgvp_rng* rng, int32_t variant, float* out,
+                       void* stream) {
   if (N < 0 || E < 0 || !w) return CGVP_ERR_BAD_ARG;
+  if (int rc = check_rng(rng)) return rc;
+  const gvp::RngArgs ra = rng_args(rng, 0);
   if (num_ntypes < 0 || num_etypes < 0 || edge_dim < 0 || cin <= num_ntypes) return CGVP_ERR_BAD_ARG;
   if (cin > WAVE || chid > WAVE || cout > WAVE || chid < 1 || cout < 1 || num_etypes + edge_dim > GINE_MAXKE)
     return CGVP_ERR_UNSUPPORTED_DIMS;
@@ -813,14 +855,25 @@ int cgvp_gine_conv_fwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
   // out / mask); variant 1 or any other shape: generic one-wave-per-atom kernel
   if (variant == 0 && edst && !((uintptr_t)out & 15) && !((uintptr_t)mask & 15)) {
     const int rc = quad::gine_fwd(cin, chid, cout, num_ntypes, num_etypes, edge_dim, x, ntypes, eattr, etypes, rowptr,
-                                  eperm, esrc, edst, N, w, act_slope, mask, out, (hipStream_t)stream);
+                                  eperm, esrc, edst, N, w, act_slope, mask, ra, out, (hipStream_t)stream);
     if (rc <= 0) return rc < 0 ? rc : launch_status();
   }
   GineArgs a{x, ntypes, num_ntypes, eattr, etypes, num_etypes, edge_dim, rowptr, eperm, esrc, N, cin,
-             chid, cout, w->eps, w->we, w->be, w->w0, w->b0, w->w1, w->b1, act_slope, out, mask};
+             chid, cout, w->eps, w->we, w->be, w->w0, w->b0, w->w1, w->b1, act_slope, out, mask, ra};
   const size_t lds = (size_t)(chid * (cin + 1) + cout * (chid + 1) + 2 * GINE_APB * WAVE) * sizeof(float);
   hipLaunchKernelGGL(gine_conv_kernel, dim3((unsigned)((N + GINE_APB - 1) / GINE_APB)),
                      dim3(WAVE * GINE_APB), lds, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+int cgvp_dropout_masks(const cgvp_rng* rng, int32_t num_masks, int64_t N, int32_t width, float* out, void* stream) {
+  if (!rng || !rng->seed || !out || num_masks < 1 || N < 0 || width < 4 || (width & 3)) return CGVP_ERR_BAD_ARG;
+  if (int rc = check_rng(rng)) return rc;
+  if (N == 0) return 0;
+  MaskArgs a{rng_args(rng, 0), num_masks, N, width, out};
+  const int64_t total = (int64_t)num_masks * N * (width / 4);
+  hipLaunchKernelGGL(dropout_masks_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, a);
   return launch_status();
 }
 
@@ -836,9 +889,10 @@ int cgvp_gine_conv_bwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
                        const int64_t* etypes, int32_t num_etypes, int32_t edge_dim, const int32_t* rowptr,
                        const int32_t* eperm, const int32_t* esrc, const int32_t* edst, int64_t N, int64_t E,
                        int32_t cin, int32_t chid, int32_t cout, const cgvp_gine_w* w, float act_slope,
-                       const float* mask, const float* g_out, float* g_x, float* grad_layer, float* workspace,
-                       int32_t max_workgroups, void* stream) {
+                       const float* mask, const cgvp_rng* rng, const float* g_out, float* g_x, float* grad_layer,
+                       float* workspace, int32_t max_workgroups, void* stream) {
   if (N < 0 || E < 0 || !w || !grad_layer || !workspace) return CGVP_ERR_BAD_ARG;
+  if (int rc = check_rng(rng)) return rc;
   if (N == 0) return 0;
   if (!x || !g_out || !rowptr || (num_ntypes > 0 && !ntypes)) return CGVP_ERR_BAD_ARG;
   if (E > 0 && (!eperm || !esrc || !edst || (edge_dim > 0 && !eattr) || (num_etypes > 0 && !etypes))) return CGVP_ERR_BAD_ARG;
@@ -850,7 +904,7 @@ int cgvp_gine_conv_bwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
   }
   int rows = 0, row_len = 0;
   if (int rc = quad::gine_bwd(cin, chid, cout, num_ntypes, num_etypes, edge_dim, x, ntypes, eattr, etypes, rowptr, eperm,
-                              esrc, edst, N, w, act_slope, mask, g_out, g_x, workspace, max_workgroups, &rows, &row_len, st)) return rc;
+                              esrc, edst, N, w, act_slope, mask, rng_args(rng, 0), g_out, g_x, workspace, max_workgroups, &rows, &row_len, st)) return rc;
   quad::reduce_slab(workspace, rows, row_len, 0, row_len, grad_layer, st);
   return launch_status();
 }

@@ -127,9 +127,24 @@ constexpr int HB_LN = 0, HB_GVP = 2 * NS, HEAD_BLK = HB_GVP + LHead::size(0);
 constexpr int NODE_GB = pad4(NODE_BLK), HEAD_GB = pad4(HEAD_BLK);
 
 constexpr int MROW = NS + NV;          // dropout mask row: 16 scalar + 4 vector-channel factors
+// factors of node n for lane (i, g): given mask row or regenerated (same function as the forward, gvp_quad_kernels.hip)
+__device__ __forceinline__ void node_dropout(const float* mask, const gvp::RngArgs& rng, int which, int64_t n, int g,
+                                             f4& ms, float& mv) {
+  if (mask) {
+    ms = *reinterpret_cast<const f4*>(mask + n * MROW + 4 * g);
+    mv = mask[n * MROW + NS + g];
+  } else if (rng.seed) {
+    const unsigned long long seed = rng.seed[0], off = rng.seed[1];
+    float fs[4], fv[4];
+    gvp::dropout4(seed, off, rng.stream + which, n, g, rng.p, fs);
+    gvp::dropout4(seed, off, rng.stream + which, n, NS / 4, rng.p, fv);
+    ms = f4{fs[0], fs[1], fs[2], fs[3]};
+    mv = g == 0 ? fv[0] : g == 1 ? fv[1] : g == 2 ? fv[2] : fv[3];
+  }
+}
 struct NodeBArgs {
   const float* img_node; const float* imgT_node;
-  const float* h; const float* dh; const float* mask0; const float* mask1;
+  const float* h; const float* dh; const float* mask0; const float* mask1; gvp::RngArgs rng;
   const float* g_up0; const float* g_up1; const float* g_up2;
   int64_t N; float* g_dh; float* g_h; float* zero_rows; float* slab;
 };
@@ -172,8 +187,8 @@ __global__ __launch_bounds__(BW_TPB, 2) void node_bwd_kernel(NodeBArgs a) {
     if (active) {
       const float* hr = a.h + n * ROW;
       const float* dr = a.dh + n * ROW;
-      if (a.mask0) { m0s = *reinterpret_cast<const f4*>(a.mask0 + n * MROW + 4 * g); m0v = a.mask0[n * MROW + NS + g]; }
-      if (a.mask1) { m1s = *reinterpret_cast<const f4*>(a.mask1 + n * MROW + 4 * g); m1v = a.mask1[n * MROW + NS + g]; }
+      node_dropout(a.mask0, a.rng, 0, n, g, m0s, m0v);      // the factors the forward applied (given, or regenerated)
+      node_dropout(a.mask1, a.rng, 1, n, g, m1s, m1v);
       x0[0] = *reinterpret_cast<const f4*>(hr + 4 * g) + *reinterpret_cast<const f4*>(dr + 4 * g) * m0s;
 #pragma unroll
       for (int p = 0; p < 3; ++p) xv0[p][0] = hr[NS + 3 * g + p] + dr[NS + 3 * g + p] * m0v;
@@ -776,10 +791,10 @@ int reduce_slab(const float* slab, int rows, int stride, int col0, int len, floa
 }
 
 int node_update_bwd(const float* img_node, const float* imgT_node, const float* h, const float* dh,
-                    const float* mask0, const float* mask1, const float* g_up0, const float* g_up1,
+                    const float* mask0, const float* mask1, gvp::RngArgs rng, const float* g_up0, const float* g_up1,
                     const float* g_up2, int64_t N, float* g_dh, float* g_h, float* zero_rows, float* slab, int* grid,
                     hipStream_t st) {
-  NodeBArgs a{img_node, imgT_node, h, dh, mask0, mask1, g_up0, g_up1, g_up2, N, g_dh, g_h, zero_rows, slab};
+  NodeBArgs a{img_node, imgT_node, h, dh, mask0, mask1, rng, g_up0, g_up1, g_up2, N, g_dh, g_h, zero_rows, slab};
   const int G = grid_for((N + TILE - 1) / TILE);
   *grid = G;
   const size_t lds = (size_t)node_bwd_lds_floats() * sizeof(float);

@@ -162,8 +162,26 @@ struct NodeQArgs {
   const float* img_node; const float* img_head;
   const float* h; const float* dh; int64_t N; float* h_out; float* out;
   const float* mask0; const float* mask1;
+  gvp::RngArgs rng;            // in-kernel dropout (used where the mask pointers are NULL); stream = 2 * layer
 };
 constexpr int MROW = NS + NV;
+
+// Dropout factors of node n for lane (i, g): scalar channels 4g..4g+3 and vector channel g of mask `which`
+// (0 = dropout[0] on dh, 1 = dropout[1] on the feed-forward output): read from the given mask, or generated.
+__device__ __forceinline__ void node_dropout(const float* mask, const gvp::RngArgs& rng, int which, int64_t n, int g,
+                                             f4& ms, float& mv) {
+  if (mask) {
+    ms = *reinterpret_cast<const f4*>(mask + n * MROW + 4 * g);
+    mv = mask[n * MROW + NS + g];
+  } else if (rng.seed) {
+    const unsigned long long seed = rng.seed[0], off = rng.seed[1];
+    float fs[4], fv[4];
+    gvp::dropout4(seed, off, rng.stream + which, n, g, rng.p, fs);
+    gvp::dropout4(seed, off, rng.stream + which, n, NS / 4, rng.p, fv);
+    ms = f4{fs[0], fs[1], fs[2], fs[3]};
+    mv = g == 0 ? fv[0] : g == 1 ? fv[1] : g == 2 ? fv[2] : fv[3];
+  }
+}
 
 // Rest of GVPConvLayer.forward for one tile of 16 residues, from s/v = h + mask0 * dh (lane (i, g)
 // holds scalars 4g..4g+3 and vector channel g): LN0, feed-forward GVPs, residual, LN1 -> h_out
@@ -239,13 +257,15 @@ __device__ __forceinline__ void node_inputs(const NodeQArgs& a, int lane, bool a
   const float* hr = a.h + n * ROW;
   f4 ds = *reinterpret_cast<const f4*>(dr + 4 * g);
   float dv[3] = {dr[NS + 3 * g], dr[NS + 3 * g + 1], dr[NS + 3 * g + 2]};
-  if (a.mask0) {
-    ds *= *reinterpret_cast<const f4*>(a.mask0 + n * MROW + 4 * g);
-    const float mv = a.mask0[n * MROW + NS + g];
+  {
+    f4 m0s = {1.f, 1.f, 1.f, 1.f};
+    float m0v = 1.f;
+    node_dropout(a.mask0, a.rng, 0, n, g, m0s, m0v);
+    node_dropout(a.mask1, a.rng, 1, n, g, m1s, m1v);
+    ds *= m0s;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) dv[p] *= mv;
+    for (int p = 0; p < 3; ++p) dv[p] *= m0v;
   }
-  if (a.mask1) { m1s = *reinterpret_cast<const f4*>(a.mask1 + n * MROW + 4 * g); m1v = a.mask1[n * MROW + NS + g]; }
   s[0] = *reinterpret_cast<const f4*>(hr + 4 * g) + ds;
 #pragma unroll
   for (int p = 0; p < 3; ++p) v[p][0] = hr[NS + 3 * g + p] + dv[p];
@@ -583,14 +603,15 @@ void conv_launch(const ConvQArgs& a, dim3 grid, hipStream_t st) {
 int conv(int nt_edge, const float* img, const float* h, const float* e_s, const float* e_v,
          const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
          const int32_t* edst, int64_t N, int64_t E, int mean, float* dh, int fuse, const float* img_node,
-         const float* img_head, float* h_out, float* out, const float* mask0, const float* mask1, hipStream_t st) {
+         const float* img_head, float* h_out, float* out, const float* mask0, const float* mask1, gvp::RngArgs rng,
+         hipStream_t st) {
   // target nodes per wave: one pass of CTN lockstep 16-edge tiles (~30 edges) per wave
   int64_t deg = N > 0 ? (E + N - 1) / N : 1;
   if (deg < 1) deg = 1;
   int npw = (int)((CTN * TILE - 2) / deg);
   npw = npw < 1 ? 1 : (npw > WAVE ? WAVE : npw);
   ConvQArgs a{img, h, e_s, e_v, etypes, rowptr, eperm, esrc, edst, N, npw, mean, dh,
-              NodeQArgs{img_node, img_head, h, nullptr, N, h_out, out, mask0, mask1}};
+              NodeQArgs{img_node, img_head, h, nullptr, N, h_out, out, mask0, mask1, rng}};
   const int64_t groups = (N + npw - 1) / npw;
   const dim3 grid((unsigned)((groups + WPB - 1) / WPB));
   if (nt_edge != 0 && nt_edge != 1) return CGVP_ERR_UNSUPPORTED_DIMS;
@@ -604,8 +625,9 @@ int conv(int nt_edge, const float* img, const float* h, const float* e_s, const 
 }
 
 int node_update(const float* img_node, const float* img_head, const float* h, const float* dh, int64_t N,
-                int with_head, float* h_out, float* out, const float* mask0, const float* mask1, hipStream_t st) {
-  NodeQArgs a{img_node, img_head, h, dh, N, h_out, out, mask0, mask1};
+                int with_head, float* h_out, float* out, const float* mask0, const float* mask1, gvp::RngArgs rng,
+                hipStream_t st) {
+  NodeQArgs a{img_node, img_head, h, dh, N, h_out, out, mask0, mask1, rng};
   const dim3 grid((unsigned)((N + WPB * TILE - 1) / (WPB * TILE)));
   if (with_head) hipLaunchKernelGGL(node_quad_kernel<true>, grid, dim3(TPB), 0, st, a);
   else hipLaunchKernelGGL(node_quad_kernel<false>, grid, dim3(TPB), 0, st, a);

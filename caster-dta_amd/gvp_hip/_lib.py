@@ -15,11 +15,11 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CGVP_LIB_PATH: A/B builds of the same ABI (diagnostics); the default is the in-tree library
 LIB_PATH = os.environ.get("CGVP_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libcaster_gvp.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 # sha256 of include/caster_gvp.h with comments, blank space and the CGVP_ABI_VERSION line removed, as
 # `abi_header_digest()` computes it.  tests/test_abi.py fails when the header's declarations change
 # without CGVP_ABI_VERSION, ABI_VERSION and this digest being updated together.
-ABI_HEADER_SHA256 = "d3742d08cd34b44890e21bb3102362066447fc91a4dc006ac27ca31039704869"
+ABI_HEADER_SHA256 = "e1789dac7b210feef98a4df8e688c40783734cc3ce117ceee12e2d8e70d93b2a"
 
 
 class HipLibraryError(RuntimeError):
@@ -43,6 +43,11 @@ class Segment(C.Structure):
                 ("len", C.c_int32), ("dst", C.c_int32)]
 
 
+class Rng(C.Structure):
+    """cgvp_rng: in-kernel dropout -- device pointer to {seed, offset} (2 x uint64), drop probability, first stream id."""
+    _fields_ = [("seed", C.c_void_p), ("p", C.c_float), ("stream", C.c_int32)]
+
+
 class GineW(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("eps", "we", "be", "w0", "b0", "w1", "b1")]
 
@@ -64,23 +69,24 @@ _SIGNATURES = {
                                 _P, _I64, _I64, _I32, _P, _P]),
     "cgvp_node_update_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _I32, _P, _P, _I64, _I32,
                                        _P, _P, _P]),
+    "cgvp_dropout_masks": (C.c_int, [C.POINTER(Rng), _I32, _I64, _I32, _P, _P]),
     "cgvp_conv_layer_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64,
-                                      _I64, _I32, _P, _P, _I32, _P, _P, _P, _P]),
-    "cgvp_node_update_fwd_train": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _P, _P, _I64,
-                                             _I32, _P, _P, _P]),
+                                      _I64, _I32, _P, _P, C.POINTER(Rng), _I32, _P, _P, _P, _P]),
+    "cgvp_node_update_fwd_train": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _P, _P,
+                                             C.POINTER(Rng), _I64, _I32, _P, _P, _P]),
     "cgvp_bwd_workspace_floats": (C.c_int64, [C.POINTER(Dims), C.POINTER(Layout)]),
-    "cgvp_node_update_bwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                       _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "cgvp_node_update_bwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _P, _P, C.POINTER(Rng), _P, _P,
+                                       _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cgvp_conv_bwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I64,
                                 _I64, _I32, _P, _P, _I32, _P, _P, _P, _P, _P, _P]),
     "cgvp_node_embed_bwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P,
                                       _P, _P, _P, _P, _P]),
     "cgvp_bwd_reduce": (C.c_int, [_P, _I32, _P, _P]),
     "cgvp_gine_conv_fwd": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32,
-                                     _I32, C.POINTER(GineW), C.c_float, _P, _I32, _P, _P]),
+                                     _I32, C.POINTER(GineW), C.c_float, _P, C.POINTER(Rng), _I32, _P, _P]),
     "cgvp_gine_bwd_workspace_floats": (C.c_int64, []),
     "cgvp_gine_conv_bwd": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32,
-                                     C.POINTER(GineW), C.c_float, _P, _P, _P, _P, _P, _I32, _P]),
+                                     C.POINTER(GineW), C.c_float, _P, C.POINTER(Rng), _P, _P, _P, _P, _I32, _P]),
 }
 
 _lib = None

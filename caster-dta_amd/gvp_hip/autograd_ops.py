@@ -16,9 +16,12 @@ Ops
   caster_gvp::gine_encoder           HomoMoleculeGNN_GINE.forward (molecule_gnn.py:254-268)
   caster_gvp::gine_encoder_backward
 
-The forward ops save each stage's INPUTS (node rows h_l, aggregated messages dh_l, dropout masks) as extra outputs;
-the backward ops launch the hand-written backward kernels, which recompute their stage and emit data gradients plus
-an arena of weight gradients.  No PyTorch arithmetic is involved besides drawing dropout masks.
+The forward ops save each stage's INPUTS (node rows h_l, aggregated messages dh_l) and the dropout SEED as extra
+outputs; the backward ops launch the hand-written backward kernels, which recompute their stage (regenerating the
+same dropout factors from the seed) and emit data gradients plus an arena of weight gradients.  Dropout factors are
+generated inside the kernels (Philox keyed by (seed, offset, mask id, node, channel), csrc/gvp_rng.h): the only
+PyTorch launch of an encoder pass is the one `randint` that draws {seed, offset} from torch's CUDA generator
+(so `torch.manual_seed` governs it and HIP-graph replays advance it).
 """
 from __future__ import annotations
 
@@ -38,11 +41,15 @@ _CFG_FIELDS = ("node_in_s", "node_in_v", "edge_in_s", "edge_in_v", "hidden_s", "
 CFG_NTN, CFG_NTE, CFG_NC, CFG_MEAN, CFG_LEN = 9, 10, 11, 12, 13
 
 
-def _dropout_masks(count, n, p, device):
-    """`count` masks of gvp_layers.Dropout (gvp_layers.py:187-219) in one draw: [count, n, 16 scalar-channel +
-    4 vector-channel factors], each 0 or 1/(1-p) (a vector channel's factor is shared by its xyz components)."""
-    keep = 1.0 - p
-    return (torch.rand(count, n, MROW, device=device) < keep).to(torch.float32).div_(keep)
+# Test hook: a callable (count, n, width, p, device) -> [count, n, width] fp32 tensor of EXPLICIT dropout factors
+# (0 or 1/(1-p)).  When set, the ops pass these masks to the kernels instead of a seed (the kernels' mask pointers
+# take precedence over in-kernel generation); production leaves it None.
+PINNED_MASKS = None
+
+
+def draw_seed(device):
+    """{seed, offset} for the in-kernel generator: int64[2] on the device, from torch's CUDA generator."""
+    return torch.randint(0, 1 << 62, (2,), dtype=torch.int64, device=device)
 
 
 def make_cfg(dims, num_ntypes, num_etypes, num_convs, aggr_mean):
@@ -88,9 +95,10 @@ def fragment_image(params, flat, layout, dims):
 @torch.library.custom_op("caster_gvp::lba_encoder", mutates_args=(), device_types="cuda")
 def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tensor, e_s: Tensor, e_v: Tensor,
                    etypes: Tensor, edge_index: Tensor, cfg: List[int], dropout_p: float,
-                   save_state: bool) -> Tuple[Tensor, Tensor, Tensor]:
-    """-> (out [N, out_s], state [2 L + 1, N, 28] = h_0..h_{L-1}, dh_0..dh_{L-1}, head input, masks [2 L, N, 20]).
-    save_state=False is the inference launch sequence (state / masks come back empty)."""
+                   save_state: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """-> (out [N, out_s], state [2 L + 1, N, 28] = h_0..h_{L-1}, dh_0..dh_{L-1}, head input,
+           masks (empty unless the PINNED_MASKS test hook is set: [2 L, N, 20]), seed int64[2] (empty without dropout)).
+    save_state=False is the inference launch sequence (state / masks / seed come back empty)."""
     if ops.VARIANT != "mfma" and save_state:
         raise NotImplementedError("training / gradients need the MFMA kernels (CGVP_VARIANT=mfma)")
     L = _lib.lib()
@@ -108,7 +116,7 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
     if not save_state:
         out = ops.lba_encoder_forward(flat, layout, dims, nc, x_s, x_v, ntypes, e_s, e_v, etypes, csr,
                                       aggr_mean=mean, image=image)
-        return out, torch.empty(0, **f32), torch.empty(0, **f32)
+        return out, torch.empty(0, **f32), torch.empty(0, **f32), torch.empty(0, dtype=torch.int64, device=dev)
     if tuple(x_s.shape) != (N, dims.node_in_s) or tuple(x_v.shape) != (N, dims.node_in_v, 3) or \
             tuple(e_s.shape) != (E, dims.edge_in_s) or tuple(e_v.shape) != (E, dims.edge_in_v, 3):
         raise NotImplementedError("feature shapes do not match the compiled CASTER-DTA configuration")
@@ -116,11 +124,12 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
     et = _i64(etypes, "etypes") if layout.nt_edge > 0 else None
     state = torch.empty(2 * nc + 1, N, ROW, **f32)
     hs, dhs, h_last = [state[l] for l in range(nc)], [state[nc + l] for l in range(nc)], state[2 * nc]
-    if dropout_p > 0:
-        masks = _dropout_masks(2 * nc, N, dropout_p, dev)
+    masks, mk, seed = torch.empty(0, **f32), [(None, None)] * nc, torch.empty(0, dtype=torch.int64, device=dev)
+    if dropout_p > 0 and PINNED_MASKS is not None:
+        masks = PINNED_MASKS(2 * nc, N, MROW, dropout_p, dev)
         mk = [(masks[2 * l], masks[2 * l + 1]) for l in range(nc)]
-    else:
-        masks, mk = torch.empty(0, **f32), [(None, None)] * nc
+    elif dropout_p > 0:
+        seed = draw_seed(dev)
     out = torch.empty(N, dims.out_s, **f32)
     with torch.cuda.device(dev):
         st = _stream()
@@ -129,13 +138,14 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
                    "cgvp_node_embed_fwd")
         for l in range(nc):
             last = l == nc - 1
+            rng = ops.make_rng(seed, dropout_p, 2 * l)
             if ops.fuse_layer(N, E):
                 with ops._timed("conv_fwd"):
                     _lib.check(L.cgvp_conv_layer_fwd(d, lay, I, l, _ptr(hs[l]), _ptr(e_s), _ptr(e_v), _ptr(et),
                                                      _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc),
                                                      _ptr(csr.edst), N, E, 1 if mean else 0,
-                                                     _ptr(mk[l][0]), _ptr(mk[l][1]), 1 if last else 0,
-                                                     _ptr(dhs[l]), _ptr(h_last if last else hs[l + 1]), _ptr(out),
+                                                     _ptr(mk[l][0]), _ptr(mk[l][1]), ops._rng_ref(rng),
+                                                     1 if last else 0, _ptr(dhs[l]), _ptr(h_last if last else hs[l + 1]), _ptr(out),
                                                      st), "cgvp_conv_layer_fwd")
                 continue
             with ops._timed("conv_fwd"):
@@ -143,27 +153,30 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
                                            _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst),
                                            N, E, 1 if mean else 0, _ptr(dhs[l]), st), "cgvp_conv_fwd")
             _lib.check(L.cgvp_node_update_fwd_train(d, lay, I, l, _ptr(hs[l]), _ptr(dhs[l]), _ptr(mk[l][0]),
-                                                    _ptr(mk[l][1]), N, 1 if last else 0,
+                                                    _ptr(mk[l][1]), ops._rng_ref(rng), N, 1 if last else 0,
                                                     _ptr(h_last if last else hs[l + 1]), _ptr(out), st),
                        "cgvp_node_update_fwd_train")
-    return out, state, masks
+    return out, state, masks, seed
 
 
 @lba_encoder_op.register_fake
 def _(params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, cfg, dropout_p, save_state):
     N, nc = x_s.shape[0], cfg[CFG_NC]
     out = x_s.new_empty((N, cfg[8]), dtype=torch.float32)
+    e32, e64 = x_s.new_empty((0,), dtype=torch.float32), x_s.new_empty((0,), dtype=torch.int64)
     if not save_state:
-        return out, x_s.new_empty((0,), dtype=torch.float32), x_s.new_empty((0,), dtype=torch.float32)
-    masks = x_s.new_empty((2 * nc, N, MROW), dtype=torch.float32) if dropout_p > 0 else \
-        x_s.new_empty((0,), dtype=torch.float32)
-    return out, x_s.new_empty((2 * nc + 1, N, ROW), dtype=torch.float32), masks
+        return out, e32, e32, e64
+    pinned = dropout_p > 0 and PINNED_MASKS is not None
+    masks = x_s.new_empty((2 * nc, N, MROW), dtype=torch.float32) if pinned else e32
+    seed = x_s.new_empty((2,), dtype=torch.int64) if dropout_p > 0 and not pinned else e64
+    return out, x_s.new_empty((2 * nc + 1, N, ROW), dtype=torch.float32), masks, seed
 
 
 @torch.library.custom_op("caster_gvp::lba_encoder_backward", mutates_args=(), device_types="cuda")
 def lba_encoder_backward_op(g_out: Tensor, params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tensor,
                             e_s: Tensor, e_v: Tensor, etypes: Tensor, edge_index: Tensor, state: Tensor,
-                            masks: Tensor, cfg: List[int], need_x: bool) -> Tuple[Tensor, Tensor, Tensor]:
+                            masks: Tensor, seed: Tensor, cfg: List[int], dropout_p: float,
+                            need_x: bool) -> Tuple[Tensor, Tensor, Tensor]:
     """-> (grad arena [layout.total], g_x_s [N, 17], g_x_v [N, 3, 3]) (the latter two empty unless need_x)."""
     L = _lib.lib()
     dims, layout = _dims_layout(cfg)
@@ -208,10 +221,11 @@ def lba_encoder_backward_op(g_out: Tensor, params: List[Tensor], x_s: Tensor, x_
         for l in reversed(range(nc)):
             last = l == nc - 1
             g_dh = torch.empty(N, ROW, **f32)
-            g_h = torch.empty(N, ROW, **f32) if mk[l][0] is not None else None
+            g_h = torch.empty(N, ROW, **f32) if (mk[l][0] is not None or seed.numel()) else None
             g_src = torch.empty(N, ROW, **f32)       # zeroed by the node stage, filled by the conv stage's atomics
+            rng = ops.make_rng(seed, dropout_p, 2 * l)
             _lib.check(L.cgvp_node_update_bwd(d, lay, I, l, _ptr(hs[l]), _ptr(dhs[l]), _ptr(mk[l][0]),
-                                              _ptr(mk[l][1]), _ptr(h_last if last else None),
+                                              _ptr(mk[l][1]), ops._rng_ref(rng), _ptr(h_last if last else None),
                                               _ptr(g_out if last else None), _ptr(ups[0]),
                                               _ptr(ups[1]), _ptr(ups[2]), N, 1 if last else 0, _ptr(g_dh),
                                               _ptr(g_h), _ptr(g_src), _ptr(gparams), _ptr(region()),
@@ -238,7 +252,7 @@ def lba_encoder_backward_op(g_out: Tensor, params: List[Tensor], x_s: Tensor, x_
 
 
 @lba_encoder_backward_op.register_fake
-def _(g_out, params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, cfg, need_x):
+def _(g_out, params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, seed, cfg, dropout_p, need_x):
     total = sum(p.numel() for p in params)
     gp = x_s.new_empty((total,), dtype=torch.float32)
     if need_x:
@@ -248,12 +262,12 @@ def _(g_out, params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, mask
 
 def _lba_setup(ctx, inputs, output):
     params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, cfg, dropout_p, save_state = inputs
-    out, state, masks = output
+    out, state, masks, seed = output
     if not save_state:
         raise RuntimeError("caster_gvp::lba_encoder was run with save_state=False; gradients need save_state=True")
-    ctx.cfg = cfg
+    ctx.cfg, ctx.dropout_p = cfg, dropout_p
     ctx.shapes = [tuple(p.shape) for p in params]
-    ctx.save_for_backward(x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, *params)
+    ctx.save_for_backward(x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, seed, *params)
 
 
 def _numel(shape):
@@ -263,11 +277,12 @@ def _numel(shape):
     return n
 
 
-def _lba_backward(ctx, g_out, g_state, g_masks):
-    x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, *params = ctx.saved_tensors
+def _lba_backward(ctx, g_out, g_state, g_masks, g_seed):
+    x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, seed, *params = ctx.saved_tensors
     need_x = bool(ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
     gflat, g_x_s, g_x_v = torch.ops.caster_gvp.lba_encoder_backward(
-        g_out.contiguous(), params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, ctx.cfg, need_x)
+        g_out.contiguous(), params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, seed, ctx.cfg,
+        ctx.dropout_p, need_x)
     grads = [g.view(s) for g, s in zip(torch.split(gflat, [_numel(s) for s in ctx.shapes]), ctx.shapes)]
     return (grads, g_x_s if need_x else None, g_x_v if need_x else None, None, None, None, None, None, None, None,
             None)
@@ -287,7 +302,7 @@ def lba_encoder(model, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, train_dro
            model.hidden_channels[0], model.hidden_channels[1], model.edge_hidden_channels[0],
            model.edge_hidden_channels[1], model.out_channels[0], model.num_ntypes, model.num_etypes,
            model.num_convs, 1 if model.aggr == "mean" else 0]
-    out, _, _ = torch.ops.caster_gvp.lba_encoder(
+    out, _, _, _ = torch.ops.caster_gvp.lba_encoder(
         model._arena.params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, cfg,
         float(model.dropout_rate) if train_dropout else 0.0, save_state)
     return out
@@ -300,46 +315,54 @@ _GINE_KEYS = ("eps", "w0", "b0", "w1", "b1", "we", "be")     # slab / state_dict
 @torch.library.custom_op("caster_gvp::gine_encoder", mutates_args=(), device_types="cuda")
 def gine_encoder_op(params: List[Tensor], x: Tensor, ntypes: Tensor, eattr: Tensor, etypes: Tensor,
                     edge_index: Tensor, widths: List[int], num_ntypes: int, num_etypes: int, slope: float,
-                    dropout_p: float, save_state: bool) -> Tuple[Tensor, List[Tensor], List[Tensor]]:
-    """-> (out [N, widths[-1]], hidden [h_1 .. h_{L-1}], masks [m_0 .. m_{L-2}]) -- the lists are empty when
-    save_state is False; a mask is an empty tensor when dropout is off."""
+                    dropout_p: float, save_state: bool) -> Tuple[Tensor, List[Tensor], List[Tensor], Tensor]:
+    """-> (out [N, widths[-1]], hidden [h_1 .. h_{L-1}], masks [m_0 .. m_{L-2}] (PINNED_MASKS test hook only; empty
+    tensors otherwise), seed int64[2] (empty without dropout)) -- the lists are empty when save_state is False."""
     nl = len(widths) - 1
     x, eattr = _f32(x, "x"), _f32(eattr, "eattr")
     N = int(x.shape[0])
     csr = ops.csr_for_forward(edge_index, N)
     ws = [dict(zip(_GINE_KEYS, params[7 * l:7 * l + 7])) for l in range(nl)]
     hs, masks = [x], []
+    seed = x.new_empty(0, dtype=torch.int64)
+    if dropout_p > 0 and nl > 1 and PINNED_MASKS is None:
+        seed = draw_seed(x.device)
     for l in range(nl):
-        mask = None
+        mask, rng = None, None
         if dropout_p > 0 and l < nl - 1:
-            keep = 1.0 - dropout_p
-            mask = (torch.rand(N, widths[l + 1], device=x.device) < keep).to(torch.float32).div_(keep)
+            if PINNED_MASKS is not None:
+                mask = PINNED_MASKS(1, N, widths[l + 1], dropout_p, x.device)[0]
+            else:
+                rng = ops.make_rng(seed, dropout_p, l)
         masks.append(mask)
         first = l == 0
         hs.append(ops.gine_conv_forward(hs[l], ntypes if first else None, num_ntypes if first else 0,
                                         eattr, etypes, num_etypes, csr, ws[l], widths[l],
-                                        widths[l + 1], widths[l + 1], slope, mask=mask))
+                                        widths[l + 1], widths[l + 1], slope, mask=mask, rng=rng))
     if not save_state:
-        return hs[-1], [], []
-    return hs[-1], hs[1:-1], [m if m is not None else x.new_empty(0) for m in masks[:-1]]
+        return hs[-1], [], [], x.new_empty(0, dtype=torch.int64)
+    return hs[-1], hs[1:-1], [m if m is not None else x.new_empty(0) for m in masks[:-1]], seed
 
 
 @gine_encoder_op.register_fake
 def _(params, x, ntypes, eattr, etypes, edge_index, widths, num_ntypes, num_etypes, slope, dropout_p, save_state):
     N, nl = x.shape[0], len(widths) - 1
     out = x.new_empty((N, widths[-1]), dtype=torch.float32)
+    e64 = x.new_empty((0,), dtype=torch.int64)
     if not save_state:
-        return out, [], []
+        return out, [], [], e64
     hidden = [x.new_empty((N, widths[l]), dtype=torch.float32) for l in range(1, nl)]
-    masks = [x.new_empty((N, widths[l + 1]) if dropout_p > 0 else (0,), dtype=torch.float32) for l in range(nl - 1)]
-    return out, hidden, masks
+    pinned = dropout_p > 0 and PINNED_MASKS is not None
+    masks = [x.new_empty((N, widths[l + 1]) if pinned else (0,), dtype=torch.float32) for l in range(nl - 1)]
+    seed = x.new_empty((2,), dtype=torch.int64) if dropout_p > 0 and nl > 1 and not pinned else e64
+    return out, hidden, masks, seed
 
 
 @torch.library.custom_op("caster_gvp::gine_encoder_backward", mutates_args=(), device_types="cuda")
 def gine_encoder_backward_op(g_out: Tensor, params: List[Tensor], x: Tensor, ntypes: Tensor, eattr: Tensor,
                              etypes: Tensor, edge_index: Tensor, hidden: List[Tensor], masks: List[Tensor],
-                             widths: List[int], num_ntypes: int, num_etypes: int, slope: float, need_x: bool,
-                             bwd_workgroups: int) -> Tuple[Tensor, Tensor]:
+                             seed: Tensor, widths: List[int], num_ntypes: int, num_etypes: int, slope: float,
+                             dropout_p: float, need_x: bool, bwd_workgroups: int) -> Tuple[Tensor, Tensor]:
     """-> (the gradients of `params`, flattened and concatenated in that order, g_x (empty unless need_x))."""
     L = _lib.lib()
     nl = len(widths) - 1
@@ -365,10 +388,11 @@ def gine_encoder_backward_op(g_out: Tensor, params: List[Tensor], x: Tensor, nty
             want_x = (not first) or need_x
             g_x = torch.empty(N, cin - (num_ntypes if first else 0), **f32) if want_x else None
             gw = _lib.GineW(**{k: v.data_ptr() for k, v in w.items()})
+            rng = ops.make_rng(seed, dropout_p, l) if l < nl - 1 else None
             rc = L.cgvp_gine_conv_bwd(_ptr(hs[l]), _ptr(nt if first else None), num_ntypes if first else 0,
                                       _ptr(eattr), _ptr(et), num_etypes, edge_dim, _ptr(csr.rowptr),
                                       _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst), N, csr.num_edges, cin, cout, cout,
-                                      C.byref(gw), float(slope), _ptr(mk[l]), _ptr(g), _ptr(g_x),
+                                      C.byref(gw), float(slope), _ptr(mk[l]), ops._rng_ref(rng), _ptr(g), _ptr(g_x),
                                       _ptr(glayer), _ptr(wsp), int(bwd_workgroups), _stream())
             _lib.check(rc, "cgvp_gine_conv_bwd")
             g = g_x
@@ -376,30 +400,30 @@ def gine_encoder_backward_op(g_out: Tensor, params: List[Tensor], x: Tensor, nty
 
 
 @gine_encoder_backward_op.register_fake
-def _(g_out, params, x, ntypes, eattr, etypes, edge_index, hidden, masks, widths, num_ntypes, num_etypes, slope,
-      need_x, bwd_workgroups):
+def _(g_out, params, x, ntypes, eattr, etypes, edge_index, hidden, masks, seed, widths, num_ntypes, num_etypes, slope,
+      dropout_p, need_x, bwd_workgroups):
     gflat = x.new_empty((sum(p.numel() for p in params),), dtype=torch.float32)
     return gflat, (x.new_empty(x.shape, dtype=torch.float32) if need_x else x.new_empty((0,), dtype=torch.float32))
 
 
 def _gine_setup(ctx, inputs, output):
     params, x, ntypes, eattr, etypes, edge_index, widths, num_ntypes, num_etypes, slope, dropout_p, save_state = inputs
-    out, hidden, masks = output
+    out, hidden, masks, seed = output
     if not save_state:
         raise RuntimeError("caster_gvp::gine_encoder was run with save_state=False; gradients need save_state=True")
-    ctx.meta = (widths, num_ntypes, num_etypes, slope, len(params), len(hidden))
+    ctx.meta = (widths, num_ntypes, num_etypes, slope, dropout_p, len(params), len(hidden))
     ctx.shapes = [tuple(p.shape) for p in params]
-    ctx.save_for_backward(x, ntypes, eattr, etypes, edge_index, *params, *hidden, *masks)
+    ctx.save_for_backward(x, ntypes, eattr, etypes, edge_index, seed, *params, *hidden, *masks)
 
 
-def _gine_backward(ctx, g_out, g_hidden, g_masks):
-    widths, num_ntypes, num_etypes, slope, n_params, n_hidden = ctx.meta
-    x, ntypes, eattr, etypes, edge_index, *rest = ctx.saved_tensors
+def _gine_backward(ctx, g_out, g_hidden, g_masks, g_seed):
+    widths, num_ntypes, num_etypes, slope, dropout_p, n_params, n_hidden = ctx.meta
+    x, ntypes, eattr, etypes, edge_index, seed, *rest = ctx.saved_tensors
     params, hidden, masks = rest[:n_params], rest[n_params:n_params + n_hidden], rest[n_params + n_hidden:]
     need_x = bool(ctx.needs_input_grad[1])
     gflat, g_x = torch.ops.caster_gvp.gine_encoder_backward(
-        g_out.contiguous(), params, x, ntypes, eattr, etypes, edge_index, hidden, masks, widths, num_ntypes,
-        num_etypes, slope, need_x, GINE_BWD_WORKGROUPS)
+        g_out.contiguous(), params, x, ntypes, eattr, etypes, edge_index, hidden, masks, seed, widths, num_ntypes,
+        num_etypes, slope, dropout_p, need_x, GINE_BWD_WORKGROUPS)
     grads = [g.view(s) for g, s in zip(torch.split(gflat, [_numel(s) for s in ctx.shapes]), ctx.shapes)]
     return (grads, g_x if need_x else None, None, None, None, None, None, None, None, None, None, None)
 
@@ -421,7 +445,7 @@ def gine_encoder(model, x, ntypes, eattr, etypes, edge_index, slope, train_dropo
     for conv in model.conv_list:
         kw = conv.kernel_weights()
         params += [kw[k] for k in _GINE_KEYS]
-    out, _, _ = torch.ops.caster_gvp.gine_encoder(
+    out, _, _, _ = torch.ops.caster_gvp.gine_encoder(
         params, x, ntypes, eattr, etypes, edge_index, list(model._widths), model.num_ntypes, model.num_etypes,
         float(slope), float(model.dropout_rate) if train_dropout else 0.0, save_state)
     return out

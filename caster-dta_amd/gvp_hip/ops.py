@@ -11,7 +11,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import Dims, GineW, Layout
+from ._lib import Dims, GineW, Layout, Rng
 
 CASTER_DIMS = dict(node_in_s=17, node_in_v=3, edge_in_s=32, edge_in_v=1, hidden_s=16, hidden_v=4,
                    edge_hidden_s=32, edge_hidden_v=1, out_s=64)
@@ -44,6 +44,28 @@ def _i64(t, name):
     if t.dtype != torch.int64:
         t = t.long()
     return t.contiguous()
+
+
+def make_rng(seed, p, stream):
+    """cgvp_rng for in-kernel dropout: `seed` = int64[2] CUDA tensor {seed, offset}; None -> NULL (no dropout)."""
+    if seed is None or seed.numel() == 0 or p <= 0:
+        return None
+    return Rng(seed.data_ptr(), float(p), int(stream))
+
+
+def _rng_ref(rng):
+    return C.byref(rng) if rng is not None else None
+
+
+def dropout_masks(seed, p, stream, num_masks, num_nodes, width):
+    """The factors the kernels apply for (seed, p, stream .. stream + num_masks - 1): [num_masks, N, width]
+    (width 20 = protein row [16 scalar | 4 vector-channel]; otherwise the GINE row)."""
+    out = torch.empty(num_masks, num_nodes, width, dtype=torch.float32, device=seed.device)
+    rng = make_rng(seed, p, stream)
+    with torch.cuda.device(seed.device):
+        _lib.check(_lib.lib().cgvp_dropout_masks(C.byref(rng), num_masks, num_nodes, width, _ptr(out), _stream()),
+                   "cgvp_dropout_masks")
+    return out
 
 
 def make_dims(**kw):
@@ -269,7 +291,7 @@ def lba_encoder_forward(params, layout, dims, num_convs, x_s, x_v, ntypes, e_s, 
                     _lib.check(L.cgvp_conv_layer_fwd(d, lay, I, layer, _ptr(h), _ptr(e_s), _ptr(e_v), _ptr(et),
                                                      _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc),
                                                      _ptr(csr.edst), N, E, 1 if aggr_mean else 0, C.c_void_p(0),
-                                                     C.c_void_p(0), 1 if last else 0, C.c_void_p(0),
+                                                     C.c_void_p(0), None, 1 if last else 0, C.c_void_p(0),
                                                      _ptr(None if last else h2), _ptr(out), st),
                                "cgvp_conv_layer_fwd")
                 if not last:
@@ -295,7 +317,8 @@ def lba_encoder_forward(params, layout, dims, num_convs, x_s, x_v, ntypes, e_s, 
     return (out, stages) if return_stages else out
 
 
-def gine_conv_forward(x, ntypes, num_ntypes, eattr, etypes, num_etypes, csr, w, cin, chid, cout, slope, mask=None):
+def gine_conv_forward(x, ntypes, num_ntypes, eattr, etypes, num_etypes, csr, w, cin, chid, cout, slope, mask=None,
+                      rng=None):
     """One GINEConv + activation (molecule_gnn.py:260-266).  `w` maps the
     cgvp_gine_w field names to contiguous fp32 CUDA tensors."""
     L = _lib.lib()
@@ -313,7 +336,7 @@ def gine_conv_forward(x, ntypes, num_ntypes, eattr, etypes, num_etypes, csr, w, 
     with torch.cuda.device(x.device):
         rc = L.cgvp_gine_conv_fwd(_ptr(x), _ptr(nt), num_ntypes, _ptr(eattr), _ptr(et), num_etypes, edge_dim,
                                   _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst), N, csr.num_edges,
-                                  cin, chid, cout, C.byref(gw), float(slope), _ptr(mask),
+                                  cin, chid, cout, C.byref(gw), float(slope), _ptr(mask), _rng_ref(rng),
                                   0 if VARIANT == "mfma" else 1, _ptr(out), _stream())
     _lib.check(rc, "cgvp_gine_conv_fwd")
     return out

@@ -11,7 +11,8 @@ Multi-GPU: independent protein/drug pairs shard across ranks (one process per
 GPU).  `enable_pair_parallel()` inserts ONE all-gather of the per-pair embedding
 `cat[protein_embed, molecule_embed]` ([B_local, 512] fp32 -> [B, 512], RCCL over
 xGMI) right before `pm_embed_lin` (joint_gnn.py:272-273); the affinity head then
-runs replicated and every rank returns all B predictions.
+runs replicated and every rank returns all B predictions.  Training adds ONE flat
+all-reduce of the pre-gather parameter gradients (`reduce_pair_parallel_grads`).
 """
 from functools import partial
 
@@ -105,35 +106,70 @@ class JointGNN(nn.Module):
         self.output_layer = nn.Linear(head_dim, 1)
         self._pair_group = None
         self._pair_parallel = False
+        self._pair_counts = None
 
     # ------------------------------------------------------------ multi-GPU
-    def enable_pair_parallel(self, group=None):
-        """Shard pairs over the ranks of `group`: all-gather pair embeddings before the head."""
+    def enable_pair_parallel(self, group=None, pair_counts=None):
+        """Shard pairs over the ranks of `group`: ONE all-gather of the per-pair embeddings before the head.
+
+        `pair_counts`: pairs held by every rank, as the sampler knows them (list of world_size ints).  None =
+        every rank holds the same number of pairs (what a sharded sampler with drop_last / padding delivers);
+        no count exchange and no host synchronisation happen inside the step either way.  Change it per step
+        with `set_pair_counts` (e.g. a ragged last batch).
+
+        Gradients: every rank evaluates the SAME full-batch loss on the gathered embeddings, so
+          * parameters after the gather (pm_embed_lin, out_fc_layers, output_layer) get the complete gradient on
+            every rank -- nothing to reduce;
+          * parameters before it (both encoders, residue / atom lins, cross attention, protein / molecule lins)
+            get the contribution of the LOCAL pairs only.  Call `reduce_pair_parallel_grads()` after
+            `loss.backward()` and before `optimizer.step()`: one flat all-reduce(SUM) over RCCL.
+        Do not wrap the model in DistributedDataParallel as well (it would average what must be summed)."""
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self._pair_group, self._pair_parallel = group, True
+        self.set_pair_counts(pair_counts)
         return self
+
+    def set_pair_counts(self, pair_counts):
+        import torch.distributed as dist
+        if pair_counts is not None:
+            pair_counts = [int(c) for c in pair_counts]
+            if len(pair_counts) != dist.get_world_size(self._pair_group):
+                raise ValueError("pair_counts needs one entry per rank")
+        self._pair_counts = pair_counts
 
     def _gather_pairs(self, pair):
         import torch.distributed as dist
         world = dist.get_world_size(self._pair_group)
         if world == 1:
             return pair
-        counts = [torch.zeros(1, dtype=torch.long, device=pair.device) for _ in range(world)]
-        dist.all_gather(counts, torch.tensor([pair.shape[0]], dtype=torch.long, device=pair.device),
-                        group=self._pair_group)
-        counts = [int(c) for c in counts]
-        width = max(counts)
-        padded = pair if pair.shape[0] == width else torch.cat(
-            [pair, pair.new_zeros(width - pair.shape[0], pair.shape[1])])
-        if pair.requires_grad and torch.is_grad_enabled():
-            from torch.distributed.nn.functional import all_gather as ag
-            parts = ag(padded.contiguous(), group=self._pair_group)
-        else:
-            parts = [torch.empty_like(padded) for _ in range(world)]
-            dist.all_gather(parts, padded.contiguous(), group=self._pair_group)
-        return torch.cat([p[:c] for p, c in zip(parts, counts)])
+        rank = dist.get_rank(self._pair_group)
+        counts = self._pair_counts or [int(pair.shape[0])] * world
+        if counts[rank] != pair.shape[0]:
+            raise ValueError(f"rank {rank} holds {pair.shape[0]} pairs, pair_counts says {counts[rank]}")
+        return _GatherPairs.apply(pair, counts, rank, self._pair_group)
+
+    def pre_gather_parameters(self):
+        """Parameters whose gradient is rank-local under pair parallelism (everything up to the gather)."""
+        post = {id(p) for m in (self.pm_embed_lin, self.out_fc_layers, self.out_fc_norms, self.output_layer)
+                for p in m.parameters()}
+        return [p for p in self.parameters() if p.numel() and id(p) not in post]
+
+    @torch.no_grad()
+    def reduce_pair_parallel_grads(self):
+        """All-reduce(SUM) of the pre-gather parameter gradients as ONE flat bucket (a few hundred KB: latency
+        bound; one collective instead of ~90)."""
+        import torch.distributed as dist
+        if not self._pair_parallel or dist.get_world_size(self._pair_group) == 1:
+            return
+        ps = [p for p in self.pre_gather_parameters() if p.requires_grad]
+        for p in ps:
+            if p.grad is None:                    # e.g. a rank without pairs: contributes zeros
+                p.grad = torch.zeros_like(p)
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self._pair_group)
+        torch._foreach_copy_([p.grad for p in ps], [c.view_as(p) for c, p in zip(flat.split([p.numel() for p in ps]), ps)])
 
     # ------------------------------------------------------------ forward
     def forward_with_graphs(self, protein_graph, molecule_graph):
@@ -199,6 +235,30 @@ class JointGNN(nn.Module):
             norms.append(norm(nxt))
             width = nxt
         return nn.ModuleList(lins), nn.ModuleList(norms), width
+
+
+class _GatherPairs(torch.autograd.Function):
+    """All-gather of the per-pair embeddings ([B_r, D] per rank -> [B, D] on every rank, rank order) as ONE
+    collective (`all_gather_into_tensor`, shards padded to the largest rank).  Backward: the head and its loss
+    are replicated, so the gradient of the gathered tensor is already complete on every rank and the local
+    gradient is its own slice -- no collective in the backward."""
+
+    @staticmethod
+    def forward(ctx, pair, counts, rank, group):
+        import torch.distributed as dist
+        world, width = len(counts), max(counts)
+        padded = pair if pair.shape[0] == width else torch.cat(
+            [pair, pair.new_zeros(width - pair.shape[0], pair.shape[1])])
+        out = pair.new_empty(world * width, pair.shape[1])
+        dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+        ctx.lo, ctx.n = sum(counts[:rank]), counts[rank]
+        if all(c == width for c in counts):
+            return out
+        return torch.cat([out[r * width:r * width + c] for r, c in enumerate(counts)])
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[ctx.lo:ctx.lo + ctx.n], None, None, None
 
 
 def _tupled(kwargs):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 14
+#define CGVP_ABI_VERSION 15
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
@@ -150,6 +150,28 @@ int cgvp_node_update_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const
                          int64_t num_nodes, int32_t with_head, float* h_out, float* out,
                          void* stream);
 
+/* IN-KERNEL DROPOUT (training).  gvp_layers.Dropout (gvp_layers.py:187-219) multiplies by Bernoulli(1-p)/(1-p)
+ * factors, one per (node, scalar channel) and one per (node, vector channel) shared by its xyz.  The kernels
+ * generate them with a counter-based generator (Philox4x32-10, csrc/gvp_rng.h) keyed by
+ * (seed, offset, stream, node, channel), so the backward pass regenerates exactly the factors of the forward
+ * pass and no mask ever exists in HBM.  `seed` points at TWO uint64 on the device {seed, offset} (so a
+ * HIP-graph replay sees fresh values when the host refreshes them on the stream); `stream` is the id of the
+ * first mask of the call: conv layer l passes 2*l (its dropout[0] uses stream, dropout[1] stream + 1), GINE
+ * layer l passes l.  rng == NULL or rng->seed == NULL: no dropout.  Explicit mask pointers, where an entry
+ * point has them, take precedence (tests pin masks that way). */
+typedef struct {
+  const uint64_t* seed;   /* device pointer to {seed, offset}            */
+  float p;                /* drop probability, 0 <= p < 1                */
+  int32_t stream;         /* id of the first mask this call draws        */
+} cgvp_rng;
+
+/* The factors the kernels would apply, written out for inspection (statistics tests; checking a training
+ * step against the CPU oracle run with the same masks): out [num_masks][N][width], mask m of the call =
+ * stream rng->stream + m.  width 20 = the protein row [16 scalar | 4 vector-channel factors]; any other
+ * multiple of 4 = the GINE row of that many channels. */
+int cgvp_dropout_masks(const cgvp_rng* rng, int32_t num_masks, int64_t num_nodes, int32_t width,
+                       float* out, void* stream);
+
 /* ONE launch for a whole GVPConvLayer.forward (gvp_layers.py:400-415), MFMA kernels
  * only: cgvp_conv_fwd followed, on each wave's own target nodes and straight from
  * its LDS rows, by cgvp_node_update_fwd[_train].  `dh` is optional (the aggregated
@@ -163,8 +185,8 @@ int cgvp_conv_layer_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
                         const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,
                         const int32_t* esrc, const int32_t* edst, int64_t num_nodes,
                         int64_t num_edges, int32_t aggr_mean, const float* mask0,
-                        const float* mask1, int32_t with_head, float* dh, float* h_out, float* out,
-                        void* stream);
+                        const float* mask1, const cgvp_rng* rng, int32_t with_head, float* dh,
+                        float* h_out, float* out, void* stream);
 
 /* Training-mode variant of cgvp_node_update_fwd (MFMA kernels only): `mask0` /
  * `mask1` are the dropout masks of gvp_layers.Dropout (gvp_layers.py:187-219) for
@@ -173,8 +195,8 @@ int cgvp_conv_layer_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
  * either may be NULL (= no dropout). */
 int cgvp_node_update_fwd_train(const cgvp_dims* dims, const cgvp_layout* layout, const float* image,
                                int32_t layer, const float* h, const float* dh, const float* mask0,
-                               const float* mask1, int64_t num_nodes, int32_t with_head, float* h_out,
-                               float* out, void* stream);
+                               const float* mask1, const cgvp_rng* rng, int64_t num_nodes,
+                               int32_t with_head, float* h_out, float* out, void* stream);
 
 /* ---------------------------------------------------------------- BACKWARD
  * Autograd of the three forward stages (what torch.autograd derives from
@@ -217,7 +239,7 @@ int cgvp_bwd_reduce(const cgvp_segment* segs, int32_t nsegs, float* grad_params,
  * that follows and set its g_src_zeroed to save that call's memset launch. */
 int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image,
                          int32_t layer, const float* h, const float* dh, const float* mask0,
-                         const float* mask1, const float* h_out, const float* g_out,
+                         const float* mask1, const cgvp_rng* rng, const float* h_out, const float* g_out,
                          const float* g_up0, const float* g_up1, const float* g_up2,
                          int64_t num_nodes, int32_t with_head, float* g_dh, float* g_h,
                          float* zero_out, float* grad_params, float* workspace, cgvp_segment* segs,
@@ -272,8 +294,8 @@ int cgvp_gine_conv_fwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
                        int32_t edge_dim, const int32_t* rowptr, const int32_t* eperm,
                        const int32_t* esrc, const int32_t* edst, int64_t num_nodes,
                        int64_t num_edges, int32_t cin, int32_t chid, int32_t cout,
-                       const cgvp_gine_w* w, float act_slope, const float* mask, int32_t variant,
-                       float* out, void* stream);
+                       const cgvp_gine_w* w, float act_slope, const float* mask, const cgvp_rng* rng,
+                       int32_t variant, float* out, void* stream);
 
 /* Backward of cgvp_gine_conv_fwd.  `mask` (optional, [N][cout]) is the dropout
  * mask molecule_gnn.py:262 applies to the layer output during training (also an
@@ -295,8 +317,8 @@ int cgvp_gine_conv_bwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
                        const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
                        const int32_t* edst, int64_t num_nodes, int64_t num_edges, int32_t cin,
                        int32_t chid, int32_t cout, const cgvp_gine_w* w, float act_slope,
-                       const float* mask, const float* g_out, float* g_x, float* grad_layer,
-                       float* workspace, int32_t max_workgroups, void* stream);
+                       const float* mask, const cgvp_rng* rng, const float* g_out, float* g_x,
+                       float* grad_layer, float* workspace, int32_t max_workgroups, void* stream);
 
 /* Library self-description (checked by the loader and the CPU test-suite). */
 int cgvp_abi_version(void);

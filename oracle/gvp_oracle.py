@@ -215,14 +215,17 @@ def gine_conv(P, pfx, x, edge_index, edge_attr, act="leaky_relu"):
 
 
 def molecule_gine_forward(P, x, edge_index, ntypes, etypes, eattr, num_ntypes=11, num_etypes=5,
-                          num_convs=2, act="leaky_relu", pfx="", return_stages=False):
-    """molecule_gnn.py:254-268 (HomoMoleculeGNN_GINE.forward), eval mode."""
+                          num_convs=2, act="leaky_relu", pfx="", return_stages=False, masks=None):
+    """molecule_gnn.py:254-268 (HomoMoleculeGNN_GINE.forward), eval mode; `masks` (one [N, width] tensor of
+    dropout factors per layer but the last, or None) supplies the training-mode dropout of :262 explicitly."""
     dt = x.dtype
     x = torch.cat([F.one_hot(ntypes, num_ntypes).to(dt), x], -1)                # :127-140
     eattr = torch.cat([F.one_hot(etypes, num_etypes).to(dt), eattr], -1)
     stages = {}
     for l in range(num_convs):
         x = _act(act)(gine_conv(P, f"{pfx}conv_list.{l}.", x, edge_index, eattr, act))
+        if masks is not None and l < num_convs - 1 and masks[l] is not None:
+            x = x * masks[l]                                                    # :262 dropout between layers
         stages[f"conv{l}"] = x
     return (x, stages) if return_stages else x
 

@@ -56,21 +56,24 @@ def test_fake_kernels_propagate_shapes_without_a_gpu(protein_params, molecule_pa
         N, E = 77, 250
         args = (params, f(N, 17), f(N, 3, 3), f(N, dt=torch.int64), f(E, 32), f(E, 1, 3), f(E, dt=torch.int64),
                 f(2, E, dt=torch.int64), CFG)
-        out, state, masks = torch.ops.caster_gvp.lba_encoder(*args, 0.2, True)
-        assert out.shape == (N, 64) and state.shape == (5, N, 28) and masks.shape == (4, N, 20)
-        out, state, masks = torch.ops.caster_gvp.lba_encoder(*args, 0.0, False)
-        assert out.shape == (N, 64) and state.numel() == 0 and masks.numel() == 0
-        g, gxs, gxv = torch.ops.caster_gvp.lba_encoder_backward(f(N, 64), *args[:8], f(5, N, 28), f(0), CFG, True)
+        out, state, masks, seed = torch.ops.caster_gvp.lba_encoder(*args, 0.2, True)
+        assert out.shape == (N, 64) and state.shape == (5, N, 28) and masks.numel() == 0      # masks live in the kernels
+        assert seed.shape == (2,) and seed.dtype == torch.int64
+        out, state, masks, seed = torch.ops.caster_gvp.lba_encoder(*args, 0.0, False)
+        assert out.shape == (N, 64) and state.numel() == 0 and masks.numel() == 0 and seed.numel() == 0
+        g, gxs, gxv = torch.ops.caster_gvp.lba_encoder_backward(f(N, 64), *args[:8], f(5, N, 28), f(0),
+                                                                f(2, dt=torch.int64), CFG, 0.2, True)
         assert g.shape == (15117,) and gxs.shape == (N, 17) and gxv.shape == (N, 3, 3)
         keys = ("eps", "nn.lins.0.weight", "nn.lins.0.bias", "nn.lins.1.weight", "nn.lins.1.bias", "lin.weight", "lin.bias")
         mparams = [f(*molecule_params[f"conv_list.{l}.{k}"].shape) for l in range(2) for k in keys]
         Na, Ea = 40, 130
         margs = (mparams, f(Na, 41), f(Na, dt=torch.int64), f(Ea, 9), f(Ea, dt=torch.int64), f(2, Ea, dt=torch.int64),
                  [52, 16, 64], 11, 5, 0.01)
-        out, hidden, mk = torch.ops.caster_gvp.gine_encoder(*margs, 0.2, True)
-        assert out.shape == (Na, 64) and [tuple(h.shape) for h in hidden] == [(Na, 16)] and mk[0].shape == (Na, 16)
-        gflat, gx = torch.ops.caster_gvp.gine_encoder_backward(f(Na, 64), *margs[:6], hidden, mk, [52, 16, 64], 11, 5,
-                                                               0.01, True, 0)
+        out, hidden, mk, mseed = torch.ops.caster_gvp.gine_encoder(*margs, 0.2, True)
+        assert out.shape == (Na, 64) and [tuple(h.shape) for h in hidden] == [(Na, 16)] and mk[0].numel() == 0
+        assert mseed.shape == (2,)
+        gflat, gx = torch.ops.caster_gvp.gine_encoder_backward(f(Na, 64), *margs[:6], hidden, mk, mseed, [52, 16, 64],
+                                                               11, 5, 0.01, 0.2, True, 0)
         assert gflat.shape == (7390,) and gx.shape == (Na, 41)
 
 

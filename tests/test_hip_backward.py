@@ -117,7 +117,7 @@ def test_training_dropout_with_pinned_masks(protein_params, monkeypatch):
     N = gb.num_nodes
     gen = torch.Generator().manual_seed(0)
     pinned = [((torch.rand(N, 20, generator=gen) < 0.8).float() / 0.8) for _ in range(4)]
-    monkeypatch.setattr(autograd_ops, "_dropout_masks", lambda count, n, p, dev: torch.stack(pinned).to(dev))
+    monkeypatch.setattr(autograd_ops, "PINNED_MASKS", lambda count, n, width, p, dev: torch.stack(pinned).to(dev))
     model = _encoder(protein_params).train()
     d = ds.to_torch(gb)
     dd = _to(d)
@@ -130,11 +130,91 @@ def test_training_dropout_with_pinned_masks(protein_params, monkeypatch):
     assert rel_err(out, ref) < 2e-5
     (ref * r).sum().backward()
     _check_grads(model, {k: v.grad for k, v in P.items() if v.numel()})
-    # and the masks torch draws have the right statistics (per node x channel, scale 1/(1-p))
-    monkeypatch.undo()
-    m = autograd_ops._dropout_masks(1, 20000, 0.2, DEV)[0]
+
+
+def test_in_kernel_dropout_statistics_and_determinism():
+    """The factors the kernels generate (Philox keyed by seed / offset / mask id / node / channel): 0 or 1/(1-p),
+    drop rate p, independent across masks, nodes and channels, a pure function of the seed."""
+    from gvp_hip import autograd_ops, ops
+    torch.manual_seed(7)
+    seed = autograd_ops.draw_seed(DEV)
+    m = ops.dropout_masks(seed, 0.2, 0, 4, 20000, 20)
+    assert m.shape == (4, 20000, 20)
     assert set(np.unique(m.cpu().numpy()).round(4)) == {0.0, 1.25}
-    assert abs(float((m == 0).float().mean()) - 0.2) < 0.01
+    drop = (m == 0).float()
+    assert abs(float(drop.mean()) - 0.2) < 0.005
+    assert float((drop.mean(dim=(1, 2)) - 0.2).abs().max()) < 0.01          # every mask
+    assert float((drop.mean(dim=(0, 1)) - 0.2).abs().max()) < 0.01          # every channel
+    a, b = drop[0].flatten(), drop[1].flatten()                               # two masks of one step: uncorrelated
+    assert abs(float(((a - a.mean()) * (b - b.mean())).mean())) < 0.005
+    assert abs(float(((drop[0, :-1] - 0.2) * (drop[0, 1:] - 0.2)).mean())) < 0.005   # neighbouring nodes
+    assert torch.equal(m, ops.dropout_masks(seed, 0.2, 0, 4, 20000, 20))      # deterministic in the seed
+    assert torch.equal(m[2:], ops.dropout_masks(seed, 0.2, 2, 2, 20000, 20))  # mask id = stream + index
+    assert not torch.equal(m, ops.dropout_masks(seed + 1, 0.2, 0, 4, 20000, 20))
+    # the same generator compiled with g++ (pinned to the published Philox4x32-10 known answers in
+    # tests/test_host_math.py) yields the same factors: the GPU masks are exactly that function
+    import ctypes, subprocess, tempfile
+    from conftest import REPO
+    so = os.path.join(tempfile.mkdtemp(), "host_rng.so")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-o", so,
+                           os.path.join(REPO, "tests", "host_math", "host_rng.cpp")])
+    host = np.zeros((3000, 20), np.float32)
+    sv = [int(v) for v in seed.cpu()]
+    ctypes.CDLL(so).host_dropout_mask(ctypes.c_ulonglong(sv[0]), ctypes.c_ulonglong(sv[1]), 1, ctypes.c_longlong(3000), 20,
+                                      ctypes.c_float(0.2), host.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(host, m[1, :3000].cpu().numpy())
+    g = ops.dropout_masks(seed, 0.5, 0, 1, 5000, 64)                          # GINE row width
+    assert set(np.unique(g.cpu().numpy()).round(4)) == {0.0, 2.0} and abs(float((g == 0).float().mean()) - 0.5) < 0.01
+
+
+def test_training_step_with_in_kernel_dropout_matches_oracle(protein_params, molecule_params):
+    """Production training mode (masks generated INSIDE the forward kernels and regenerated inside the backward
+    kernels): export the factors for the step's seed and run the oracle with exactly those -- forward and every
+    gradient of both encoders must agree."""
+    from gvp_hip import autograd_ops, ops
+    from models.molecule_gnn import SelectableMoleculeModelWrapper
+    pb, mb = ds.pair_batch(4, 13, lengths=[50, 37, 64, 45])
+    pd, md = ds.to_torch(pb), ds.to_torch(mb)
+    # ---- protein
+    model = _encoder(protein_params).train()
+    dd = _to(pd)
+    torch.manual_seed(123)
+    out = model(dd["x"], dd["edge_index"], dd["ntypes"], dd["etypes"], eattr=dd["eattr"])
+    torch.manual_seed(123)
+    seed = autograd_ops.draw_seed(DEV)                     # the same draw the op made
+    masks = ops.dropout_masks(seed, 0.2, 0, 4, pb.num_nodes, 20).cpu()
+    r = torch.randn(out.shape, generator=torch.Generator().manual_seed(4))
+    (out * r.to(DEV)).sum().backward()
+    P = {k: v.detach().cpu().clone().requires_grad_(v.numel() > 0) for k, v in model.gnn_model.state_dict().items()}
+    ref = O.protein_lba_forward(P, pd["x"], pd["edge_index"], pd["ntypes"], pd["etypes"], pd["eattr"],
+                                masks=[(masks[0], masks[1]), (masks[2], masks[3])])
+    assert rel_err(out, ref) < 2e-5
+    (ref * r).sum().backward()
+    _check_grads(model, {k: v.grad for k, v in P.items() if v.numel()})
+    ev = model.eval()(dd["x"], dd["edge_index"], dd["ntypes"], dd["etypes"], eattr=dd["eattr"])
+    assert rel_err(ev, ref) > 1e-2                          # dropout really was applied
+    # ---- drug (dropout between the two GINE layers, molecule_gnn.py:262)
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))["molecule_gnn_kwargs"]
+    mol = SelectableMoleculeModelWrapper(**kw)
+    mol.load_state_dict({"gnn_model." + k: v for k, v in molecule_params.items()})
+    mol = mol.to(DEV).train()
+    dm = _to(md)
+    gx = dm["x"].clone().requires_grad_()
+    torch.manual_seed(321)
+    mout = mol(gx, dm["edge_index"], dm["ntypes"], dm["etypes"], eattr=dm["eattr"])
+    torch.manual_seed(321)
+    mseed = autograd_ops.draw_seed(DEV)
+    mmask = ops.dropout_masks(mseed, 0.2, 0, 1, mb.num_nodes, 16).cpu()
+    Q = {k: v.clone().requires_grad_(True) for k, v in molecule_params.items()}
+    xr = md["x"].clone().requires_grad_()
+    mref = O.molecule_gine_forward(Q, xr, md["edge_index"], md["ntypes"], md["etypes"], md["eattr"], masks=[mmask[0]])
+    assert rel_err(mout, mref) < 2e-5
+    r2 = torch.randn(mref.shape, generator=torch.Generator().manual_seed(5))
+    (mref * r2).sum().backward()
+    (mout * r2.to(DEV)).sum().backward()
+    for name, p in mol.gnn_model.named_parameters():
+        assert rel_err(p.grad, Q[name].grad) < 2e-4, name
+    assert rel_err(gx.grad, xr.grad) < 2e-4
 
 
 def test_adam_step_moves_the_arena(protein_params):

@@ -55,18 +55,30 @@ def _batches(lengths, seed):
     return ds.to_torch(p), ds.to_torch(m)
 
 
-def _worker(rank, world, port, pretrained, shards, q):
+GRAD_KEYS = ("output_layer.weight", "pm_embed_lin.weight", "protein_lins.0.weight", "residue_lins.0.weight",
+             "cross_attn_module.cross_attn_layers.0.embed1_to_2.in_proj_weight", "atom_lins.0.bias",
+             "protein_gnn.params.gvp_to_scalar/ws/bias", "protein_gnn.params.conv_list/0/conv/message_func/0/ws/weight",
+             "molecule_gnn.params.conv_list/0/lin/weight", "molecule_gnn.params.conv_list/1/eps")
+
+
+def _grads(model):
+    named = dict(model.named_parameters())
+    return {k: named[k].grad.detach().clone().numpy() for k in GRAD_KEYS}
+
+
+def _worker(rank, world, port, pretrained, shards, pass_counts, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.manual_seed(0)
-        model = _build(pretrained).enable_pair_parallel()
+        model = _build(pretrained).enable_pair_parallel(
+            pair_counts=[len(s) for s in shards] if pass_counts else None)
         pd, md = _batches(shards[rank], 100 + rank)
         y, _ = model(pd, md)
         y.square().sum().backward()
-        g = model.output_layer.weight.grad.clone()
-        ge = model.protein_gnn.params["gvp_to_scalar/ws/bias"].grad.clone()
-        q.put((rank, y.detach().numpy(), g.numpy(), ge.numpy()))
+        local = _grads(model)                       # before the reduce: encoder gradients are rank-local
+        model.reduce_pair_parallel_grads()
+        q.put((rank, y.detach().numpy(), local, _grads(model)))
     finally:
         dist.destroy_process_group()
 
@@ -78,12 +90,13 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-def test_pair_parallel_world2_matches_single_process(pretrained):
-    shards = [[40, 33, 52, 28], [47, 30]]                 # ragged: 4 + 2 pairs
+@pytest.mark.parametrize("shards,pass_counts", [([[40, 33, 52, 28], [47, 30]], True),      # ragged: 4 + 2 pairs
+                                                ([[40, 33, 52], [47, 30, 28]], False)])    # equal shards, no counts
+def test_pair_parallel_world2_matches_single_process(pretrained, shards, pass_counts):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, pretrained, shards, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, pretrained, shards, pass_counts, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}
@@ -94,18 +107,29 @@ def test_pair_parallel_world2_matches_single_process(pretrained):
         p.join(60)
         assert p.exitcode == 0
 
-    # single process: the same six pairs through the head in one go
+    # single process: the same six pairs; the loss sum(y^2) is separable over pairs, so the whole-batch
+    # gradient is the sum of the per-shard backward passes
     model = _build(pretrained)
     outs = []
     for rank, lens in enumerate(shards):
         pd, md = _batches(lens, 100 + rank)
-        outs.append(model(pd, md)[0].detach().numpy())
-    full = np.concatenate(outs)                          # pairs are independent: per-shard == whole batch
+        y = model(pd, md)[0]
+        y.square().sum().backward()
+        outs.append(y.detach().numpy())
+    full, ref = np.concatenate(outs), _grads(model)
     for rank in (0, 1):
         y = res[rank][0]
         assert y.shape == (6, 1)                         # every rank holds ALL predictions
         assert np.allclose(y, full, rtol=1e-5, atol=1e-6)
     assert np.allclose(res[0][0], res[1][0])
-    # the head is replicated: identical head gradients; encoder gradients are local and non-zero
-    assert np.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-7)
-    assert np.abs(res[0][2]).max() > 0 and np.abs(res[1][2]).max() > 0
+    for k in GRAD_KEYS:
+        scale = np.abs(ref[k]).max()
+        assert scale > 0, k
+        for rank in (0, 1):                              # after the reduce: every rank holds the 6-pair gradient
+            assert np.abs(res[rank][2][k] - ref[k]).max() <= 2e-4 * scale + 1e-7, (k, rank)
+    # before the reduce: head gradients are already complete, encoder gradients are rank-local (and differ)
+    for k in ("output_layer.weight", "pm_embed_lin.weight"):
+        assert np.abs(res[0][1][k] - ref[k]).max() <= 2e-4 * np.abs(ref[k]).max() + 1e-7
+    k = "protein_gnn.params.gvp_to_scalar/ws/bias"
+    assert np.abs(res[0][1][k] - ref[k]).max() > 1e-3 * np.abs(ref[k]).max()
+    assert np.abs(res[0][1][k] + res[1][1][k] - ref[k]).max() <= 2e-4 * np.abs(ref[k]).max() + 1e-7

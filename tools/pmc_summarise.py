@@ -1,8 +1,12 @@
 """Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same bench command) into
 profiles/<round>/pmc_traffic.json: HBM bytes per launch of every kernel, corrected as MI355X_MICROARCH.md's
 HBM section prescribes (counters in KiB; gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x -> doubled;
-WRITE_SIZE exact).  Usage: python tools/pmc_summarise.py <fetch_dir> <write_dir> <out.json>"""
+WRITE_SIZE exact).  Usage: python tools/pmc_summarise.py <fetch_dir> <write_dir> <out.json> [workload description]
+The file records a digest of the kernel sources it was measured on; bench.py reports `roofline.traffic` from it only
+while that digest matches the sources it runs."""
 import csv, glob, json, os, re, sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 
 def per_kernel(d, counter):
@@ -21,6 +25,8 @@ def per_kernel(d, counter):
 
 def main():
     fetch, write, out = sys.argv[1:4]
+    workload = sys.argv[4] if len(sys.argv) > 4 else "davis_b64 (N=19200, E=57484), fwd+bwd, eager"
+    import bench
     fe, wr = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(fe) | set(wr)):
@@ -29,7 +35,7 @@ def main():
         f, w = fe.get(k, 0.0), wr.get(k, 0.0)
         kernels[k] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
                       "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
-    doc = {"workload": "davis_b64 (N=19200, E=57484), fwd+bwd, eager",
+    doc = {"workload": workload, "kernel_source_digest": bench.kernel_source_digest(),
            "collected": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of bench.py --no-graph",
            "correction": "MI355X_MICROARCH.md HBM section: counters in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of "
                          "wide coalesced 16-B/lane reads -> doubled; WRITE_SIZE exact (incl. float atomics)",
