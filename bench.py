@@ -141,6 +141,9 @@ def main():
     to = lambda d: {k: (tuple(t.to(dev) for t in v) if isinstance(v, tuple) else v.to(dev)) for k, v in d.items()}
     pdata_cpu, mdata_cpu = ds.to_torch(pb), ds.to_torch(mb)
     pdata, mdata = to(pdata_cpu), to(mdata_cpu)
+    # joint scope: graph offsets as PyG Batch objects carry them (the head then has no data-dependent shape)
+    jp = dict(pdata, ptr=torch.as_tensor(pb.ptr).to(dev))
+    jm = dict(mdata, ptr=torch.as_tensor(mb.ptr).to(dev))
     ops.CSR_CACHE_ENABLED = bool(args.cache_csr or args.collate_csr)
     side = torch.cuda.Stream(device=dev)
     collate = None
@@ -170,6 +173,10 @@ def main():
     pair_local = torch.randn(wl["pairs"], 512, device=dev, generator=gen)
     pair_all = torch.empty(wl["pairs"] * world, 512, device=dev)
     grad_bucket = torch.zeros(n_enc, device=dev)
+    all_params = [p for p in model.parameters() if p.numel()]
+    pre_ids = {id(p) for p in model.pre_gather_parameters()}
+    pre_idx = [i for i, p in enumerate(all_params) if id(p) in pre_ids]      # rank-local gradients under pair parallelism
+    joint_bucket = torch.zeros(sum(all_params[i].numel() for i in pre_idx), device=dev)
     if args.scope == "joint" and collectives and (world > 1 or force_coll):
         model.enable_pair_parallel()
 
@@ -199,14 +206,13 @@ def main():
         if collate:
             collate[1][0].collate(collate[1][1], attach_to=mdata["edge_index"])
             collate[0][0].collate(collate[0][1], attach_to=pdata["edge_index"])
-        pred, _ = model(pdata, mdata)
+        pred, _ = model(jp, jm)
         if not train:
             return pred
-        for p in model.parameters():
-            p.grad = None
         loss = torch.nn.functional.mse_loss(pred, target[:pred.shape[0]])
-        loss.backward()
-        return loss
+        # every gradient of the model (764,396 parameters); autograd.grad instead of .backward() keeps the step free of
+        # AccumulateGrad nodes, so it captures into a HIP graph like the encoder step
+        return torch.autograd.grad(loss, all_params)
 
     step = encoders_step if args.scope == "encoders" else joint_step
 
@@ -214,9 +220,10 @@ def main():
         """The per-step collectives of data-parallel training (issued eagerly after the compute of the step)."""
         if not collectives:
             return
-        if args.scope == "joint":
-            if train:
-                model.reduce_pair_parallel_grads()
+        if args.scope == "joint":           # the all-gather ran inside the model; what is left is the flat gradient reduce
+            if train and not rehearsal:
+                torch.cat([out[i].reshape(-1) for i in pre_idx], out=joint_bucket)
+                dist.all_reduce(joint_bucket)
             return
         if rehearsal:                                  # gloo on host copies (cuda:0 is shared by all ranks)
             gathered = [torch.empty(pair_local.shape) for _ in range(world)]
@@ -234,7 +241,9 @@ def main():
         out = step()
         torch.cuda.synchronize()
         graph = None
-        # the joint step is launched eagerly (its dense-padding head has data-dependent shapes: Lmax = int(counts.max()))
+        # --scope joint is launched eagerly: capturing the torch head (library GEMMs called from the autograd thread)
+        # into a HIP graph faulted on replay on this ROCm build (round 2, gpurun_out/r2_joint2.err); the encoders
+        # scope -- only this library's kernels -- replays from a graph
         if not args.no_graph and args.scope == "encoders" and args.only != "drug" and args.drug_stream == "side":
             s = torch.cuda.Stream(device=dev)
             s.wait_stream(torch.cuda.current_stream())

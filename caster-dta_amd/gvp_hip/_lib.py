@@ -15,11 +15,11 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CGVP_LIB_PATH: A/B builds of the same ABI (diagnostics); the default is the in-tree library
 LIB_PATH = os.environ.get("CGVP_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libcaster_gvp.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 # sha256 of include/caster_gvp.h with comments, blank space and the CGVP_ABI_VERSION line removed, as
 # `abi_header_digest()` computes it.  tests/test_abi.py fails when the header's declarations change
 # without CGVP_ABI_VERSION, ABI_VERSION and this digest being updated together.
-ABI_HEADER_SHA256 = "e1789dac7b210feef98a4df8e688c40783734cc3ce117ceee12e2d8e70d93b2a"
+ABI_HEADER_SHA256 = "aa80fb1941eb940eebb33ee68e6093a879231805b27d8e5ab27e253aebad62eb"
 
 
 class HipLibraryError(RuntimeError):
@@ -46,6 +46,14 @@ class Segment(C.Structure):
 class Rng(C.Structure):
     """cgvp_rng: in-kernel dropout -- device pointer to {seed, offset} (2 x uint64), drop probability, first stream id."""
     _fields_ = [("seed", C.c_void_p), ("p", C.c_float), ("stream", C.c_int32)]
+
+
+class AttnProblem(C.Structure):
+    """cgvp_attn_problem (one direction of the varlen cross attention)."""
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("q_ptr", C.c_void_p), ("k_ptr", C.c_void_p),
+                ("num_q", C.c_int64), ("num_k", C.c_int64), ("out", C.c_void_p), ("lse", C.c_void_p),
+                ("g_out", C.c_void_p), ("delta", C.c_void_p), ("g_q", C.c_void_p), ("g_k", C.c_void_p),
+                ("g_v", C.c_void_p), ("weights", C.c_void_p), ("weights_lq", C.c_int64), ("weights_lk", C.c_int64)]
 
 
 class GineW(C.Structure):
@@ -84,6 +92,9 @@ _SIGNATURES = {
     "cgvp_bwd_reduce": (C.c_int, [_P, _I32, _P, _P]),
     "cgvp_gine_conv_fwd": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32,
                                      _I32, C.POINTER(GineW), C.c_float, _P, C.POINTER(Rng), _I32, _P, _P]),
+    "cgvp_attn_fwd": (C.c_int, [C.POINTER(AttnProblem), _I32, _I64, _I32, C.c_float, _P]),
+    "cgvp_attn_bwd": (C.c_int, [C.POINTER(AttnProblem), _I32, _I64, _I32, C.c_float, _P]),
+    "cgvp_attn_weights": (C.c_int, [C.POINTER(AttnProblem), _I32, _I64, _I32, C.c_float, _P]),
     "cgvp_gine_bwd_workspace_floats": (C.c_int64, []),
     "cgvp_gine_conv_bwd": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32,
                                      C.POINTER(GineW), C.c_float, _P, C.POINTER(Rng), _P, _P, _P, _P, _I32, _P]),

@@ -1,10 +1,18 @@
 """`models.joint_gnn`: the caller of the hot path, with the reference's API
 (joint_gnn.py:15-288 JointGNN, :321-409 CrossAttentionModule, :411-451 stack).
 
-The two encoders (`protein_gnn`, `molecule_gnn`) are the MI355X kernels; what
-follows them -- per-node Linear, padding to a dense batch, residue<->atom
-cross-attention, masked pooling and the affinity MLP -- is stock torch.nn on the
-same device, with the reference's parameter names so checkpoints load strictly.
+The two encoders (`protein_gnn`, `molecule_gnn`) are the MI355X kernels.  The head
+keeps the reference's modules and parameter names (checkpoints load strictly) but
+runs on COMPACT rows: per-node Linear on [N, 128] / [Na, 128], the residue <-> atom
+cross attention as ONE varlen kernel launch for both directions
+(`caster_gvp::cross_attention`, csrc/attn_kernels.hip: no `to_dense_batch`
+padding, no key-padding masks, no [B, heads, Rmax, Amax] score tensor), the
+projections / feed-forward as library GEMMs on the compact rows, segment pooling
+by `batch`, then the affinity MLP.  With `ptr` offsets in the input dicts (what
+`forward_with_graphs` passes) the step has no data-dependent shape and no host
+synchronisation, so it captures into a HIP graph.  The reference's dense
+formulation (`to_dense_batch` + nn.MultiheadAttention) is kept for head shapes the
+kernel is not compiled for (head_dim != 16, attention dropout > 0).
 It does not import torch_geometric (`to_dense_batch` is restated below).
 
 Multi-GPU: independent protein/drug pairs shard across ranks (one process per
@@ -107,6 +115,10 @@ class JointGNN(nn.Module):
         self._pair_group = None
         self._pair_parallel = False
         self._pair_counts = None
+        # nn.MultiheadAttention's head-averaged weights (second return value): "auto" = computed in eval mode (what
+        # inference/evaluation.py:43-66 consumes), skipped in training (train_model.py:564 discards them);
+        # "always" / "never" force it.  Dense [B, Rmax, Amax] / [B, Amax, Rmax] as in the reference.
+        self.attention_weights = "auto"
 
     # ------------------------------------------------------------ multi-GPU
     def enable_pair_parallel(self, group=None, pair_counts=None):
@@ -179,8 +191,11 @@ class JointGNN(nn.Module):
     def _graphs_to_dicts(protein_graph, molecule_graph):
         def as_dict(g):
             ei = g.edge_index if getattr(g, "edge_index", None) is not None else g.adj_t
-            return {"x": g.x, "edge_index": ei, "ntypes": g.node_type, "etypes": g.edge_type,
-                    "eattr": g.edge_attr, "batch": g.batch}
+            d = {"x": g.x, "edge_index": ei, "ntypes": g.node_type, "etypes": g.edge_type,
+                 "eattr": g.edge_attr, "batch": g.batch}
+            if getattr(g, "ptr", None) is not None:       # PyG Batch objects carry it: spares the head a host sync
+                d["ptr"] = g.ptr
+            return d
         return as_dict(protein_graph), as_dict(molecule_graph)
 
     def _stack(self, t, lins, norms):
@@ -198,19 +213,57 @@ class JointGNN(nn.Module):
             return (dense - (~m) * 1.0e10).max(dim=1).values
         raise ValueError(self.element_pooling)
 
+    def _pool_rows(self, rows, batch, ptr):
+        """The same pooling on compact rows (graph b = rows ptr[b] .. ptr[b+1])."""
+        B = ptr.numel() - 1
+        if self.element_pooling in ("mean", "sum"):
+            out = rows.new_zeros(B, rows.shape[1]).index_add_(0, batch, rows)
+            if self.element_pooling == "mean":
+                out = out / (ptr[1:] - ptr[:-1]).to(rows.dtype).unsqueeze(-1)
+            return out
+        if self.element_pooling == "max":
+            idx = batch.unsqueeze(-1).expand_as(rows)
+            return rows.new_full((B, rows.shape[1]), float("-inf")).scatter_reduce(0, idx, rows, "amax")
+        raise ValueError(self.element_pooling)
+
+    @staticmethod
+    def _offsets(data, batch, rows):
+        """(batch vector, ptr offsets) of a compact row array; `ptr` from the dict when given (no host sync)."""
+        ptr = data.get("ptr", None)
+        if batch is None:
+            batch = torch.zeros(rows.shape[0], dtype=torch.long, device=rows.device)
+            if ptr is None:
+                ptr = torch.tensor([0, rows.shape[0]], dtype=torch.long, device=rows.device)
+        if ptr is None:
+            num = int(batch.max()) + 1 if batch.numel() else 0          # host sync; pass `ptr` to avoid it
+            counts = torch.bincount(batch, minlength=num)
+            ptr = torch.cat([counts.new_zeros(1), counts.cumsum(0)])
+        return batch, ptr.to(torch.long)
+
     def forward(self, protein_graph_data={}, molecule_graph_data={}):
         pbatch = protein_graph_data.get("batch", None)
         mbatch = molecule_graph_data.get("batch", None)
-        residue = self.protein_gnn(**protein_graph_data)          # MI355X kernels
-        atom = self.molecule_gnn(**molecule_graph_data)           # MI355X kernels
+        residue = self.protein_gnn(**{k: v for k, v in protein_graph_data.items() if k != "ptr"})    # MI355X kernels
+        atom = self.molecule_gnn(**{k: v for k, v in molecule_graph_data.items() if k != "ptr"})     # MI355X kernels
         residue = self._stack(residue, self.residue_lins, self.residue_norms)
         atom = self._stack(atom, self.atom_lins, self.atom_norms)
-        residue, rmask = to_dense_batch(residue, pbatch)
-        atom, amask = to_dense_batch(atom, mbatch)
         attn = None
-        if self.cross_attn_module is not None:
+        if self.cross_attn_module is None or self.cross_attn_module.varlen_supported(residue):
+            # compact rows end to end: varlen cross attention (one launch for both directions) + segment pooling
+            pbatch, rptr = self._offsets(protein_graph_data, pbatch, residue)
+            mbatch, aptr = self._offsets(molecule_graph_data, mbatch, atom)
+            if rptr.numel() != aptr.numel():
+                raise ValueError("protein and molecule batches hold different numbers of graphs")
+            if self.cross_attn_module is not None:
+                want = self.attention_weights == "always" or (self.attention_weights == "auto" and not self.training)
+                residue, atom, attn = self.cross_attn_module.forward_varlen(residue, atom, rptr, aptr, want)
+            protein, molecule = self._pool_rows(residue, pbatch, rptr), self._pool_rows(atom, mbatch, aptr)
+        else:
+            # the reference's dense formulation (head shapes the varlen kernel is not compiled for)
+            residue, rmask = to_dense_batch(residue, pbatch)
+            atom, amask = to_dense_batch(atom, mbatch)
             residue, atom, attn = self.cross_attn_module(residue, atom, rmask, amask)
-        protein, molecule = self._pool(residue, rmask), self._pool(atom, amask)
+            protein, molecule = self._pool(residue, rmask), self._pool(atom, amask)
         if self.include_post_pool_layernorm:
             protein, molecule = self.protein_post_pool_norm(protein), self.molecule_post_pool_norm(molecule)
         protein = self.dropout(self.activation(protein))
@@ -295,6 +348,55 @@ class CrossAttentionModule(nn.Module):
                                      nn.Dropout(feedforward_dropout), nn.Linear(d * dim_feedforward_scale, d))
             self.ff1, self.ff2 = ff(embed_dim_1), ff(embed_dim_2)
 
+    # ------------------------------------------------------------ varlen path (MI355X kernel)
+    def varlen_supported(self, rows):
+        """The varlen kernel is compiled for head_dim 16 without attention dropout, on CUDA fp32 rows."""
+        m1, m2 = self.embed1_to_2, self.embed2_to_1
+        return (rows.is_cuda and m1.head_dim == 16 and m2.head_dim == 16 and m1.embed_dim == m2.embed_dim
+                and m1.num_heads == m2.num_heads and not (self.training and (m1.dropout > 0 or m2.dropout > 0)))
+
+    @staticmethod
+    def _qkv(mha, x_q, x_kv):
+        """nn.MultiheadAttention's input projections on compact rows (three library GEMMs, contiguous outputs)."""
+        E = mha.embed_dim
+        b = mha.in_proj_bias
+        bq, bk, bv = (b[:E], b[E:2 * E], b[2 * E:]) if b is not None else (None, None, None)
+        if mha._qkv_same_embed_dim:
+            W = mha.in_proj_weight
+            wq, wk, wv = W[:E], W[E:2 * E], W[2 * E:]
+        else:
+            wq, wk, wv = mha.q_proj_weight, mha.k_proj_weight, mha.v_proj_weight
+        lin = nn.functional.linear
+        return lin(x_q, wq, bq), lin(x_kv, wk, bk), lin(x_kv, wv, bv)
+
+    def forward_varlen(self, embed_1, embed_2, ptr1, ptr2, need_weights=False):
+        """`forward` on compact rows: embed_1 [N1, D] with graph offsets ptr1, embed_2 [N2, D] with ptr2; every
+        graph b of side 1 attends to graph b of side 2 and vice versa (joint_gnn.py:376-398).  The softmax(QK^T)V
+        core of both directions is one launch of caster_gvp::cross_attention; projections and feed-forward are
+        GEMMs on the compact rows.  Returns (embed_1, embed_2, (w1, w2) or None)."""
+        from gvp_hip import attention_ops  # noqa: F401  (registers the ops)
+        n1, n2 = self.preattn_norm1(embed_1), self.preattn_norm2(embed_2)
+        q1, k1, v1 = self._qkv(self.embed1_to_2, n1, n2)
+        q2, k2, v2 = self._qkv(self.embed2_to_1, n2, n1)
+        heads = self.embed1_to_2.num_heads
+        o1, o2, lse1, lse2 = torch.ops.caster_gvp.cross_attention(q1, k1, v1, q2, k2, v2, ptr1, ptr2, heads)
+        a1, a2 = self.embed1_to_2.out_proj(o1), self.embed2_to_1.out_proj(o2)
+        weights = None
+        if need_weights:
+            l1 = int((ptr1[1:] - ptr1[:-1]).max()) if ptr1.numel() > 1 else 0      # inference only: host sync
+            l2 = int((ptr2[1:] - ptr2[:-1]).max()) if ptr2.numel() > 1 else 0
+            weights = tuple(torch.ops.caster_gvp.cross_attention_weights(q1.detach(), k1.detach(), lse1.detach(),
+                                                                         q2.detach(), k2.detach(), lse2.detach(),
+                                                                         ptr1, ptr2, heads, l1, l2))
+        if self.include_residual_stream:
+            embed_1 = embed_1 + self.ff_dropout(a1)
+            embed_1 = embed_1 + self.ff_dropout(self.ff1(self.ff_norm1(embed_1)))
+            embed_2 = embed_2 + self.ff_dropout(a2)
+            embed_2 = embed_2 + self.ff_dropout(self.ff2(self.ff_norm2(embed_2)))
+        else:
+            embed_1, embed_2 = a1, a2
+        return embed_1, embed_2, weights
+
     def forward(self, embed_1, embed_2, mask1, mask2, return_weights=True):
         n1, n2 = self.preattn_norm1(embed_1), self.preattn_norm2(embed_2)
         a1, w1 = self.embed1_to_2(n1, n2, n2, key_padding_mask=~mask2)
@@ -313,6 +415,16 @@ class StackedCrossAttentionModule(nn.Module):
     def __init__(self, cross_attn_base, num_layers):
         super().__init__()
         self.cross_attn_layers = nn.ModuleList([cross_attn_base() for _ in range(num_layers)])
+
+    def varlen_supported(self, rows):
+        return all(layer.varlen_supported(rows) for layer in self.cross_attn_layers)
+
+    def forward_varlen(self, embed_1, embed_2, ptr1, ptr2, need_weights=False):
+        weights = []
+        for layer in self.cross_attn_layers:
+            embed_1, embed_2, w = layer.forward_varlen(embed_1, embed_2, ptr1, ptr2, need_weights)
+            weights.append(w)
+        return embed_1, embed_2, (weights if need_weights else None)
 
     def forward(self, embed_1, embed_2, mask1, mask2, return_weights=True):
         weights = []

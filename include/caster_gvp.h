@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 15
+#define CGVP_ABI_VERSION 16
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
@@ -319,6 +319,37 @@ int cgvp_gine_conv_bwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
                        int32_t chid, int32_t cout, const cgvp_gine_w* w, float act_slope,
                        const float* mask, const cgvp_rng* rng, const float* g_out, float* g_x,
                        float* grad_layer, float* workspace, int32_t max_workgroups, void* stream);
+
+/* ------------------------------------------------------------ CROSS-ATTENTION CORE
+ * The part of nn.MultiheadAttention between its input and output projections, for the residue <-> atom cross
+ * attention of CrossAttentionModule (joint_gnn.py:321-409; called on to_dense_batch-padded tensors at
+ * joint_gnn.py:206-215 in the reference), on COMPACT row arrays with PyG ptr offsets instead of padded batches:
+ * for every pair b and head h
+ *     out[q] = softmax_k( scale * q[q] . k[k] ) v[k],   q in rows q_ptr[b] .. q_ptr[b+1], k in k_ptr[b] .. k_ptr[b+1]
+ * head_dim is 16 (embed 128 / 8 heads in CASTER-DTA; embed = 16 * heads in general); q / k / v / out are
+ * [rows][16 * heads] fp32 row-major (the projected tensors), lse [num_q][heads] is the log-sum-exp the backward
+ * needs.  A pair without keys yields zero rows.  One call takes up to TWO problems (the module's two directions run
+ * in one launch).  No attention dropout (the reference trains with attention_dropout = 0, train_model.py:317). */
+typedef struct {
+  const float* q; const float* k; const float* v;
+  const int64_t* q_ptr; const int64_t* k_ptr;   /* [num_pairs + 1] row offsets                            */
+  int64_t num_q, num_k;                          /* total rows of q and of k / v                           */
+  float* out; float* lse;                        /* forward outputs (inputs of the backward / weights)     */
+  const float* g_out;                            /* backward: d out [num_q][16 * heads]                    */
+  float* delta;                                  /* backward scratch [num_q][heads]                        */
+  float* g_q; float* g_k; float* g_v;            /* backward outputs, every row written                    */
+  float* weights; int64_t weights_lq, weights_lk; /* cgvp_attn_weights: dense [num_pairs][lq][lk], zero-filled by the caller */
+} cgvp_attn_problem;
+int cgvp_attn_fwd(const cgvp_attn_problem* problems, int32_t num_problems, int64_t num_pairs, int32_t heads,
+                  float scale, void* stream);
+/* d q, d k, d v from d out (two launches, no atomics: run-to-run reproducible). */
+int cgvp_attn_bwd(const cgvp_attn_problem* problems, int32_t num_problems, int64_t num_pairs, int32_t heads,
+                  float scale, void* stream);
+/* nn.MultiheadAttention's returned weights (need_weights=True, averaged over heads) in the reference's dense
+ * layout [num_pairs][weights_lq][weights_lk] (what inference/evaluation.py:43-66 slices per pair); needs the lse
+ * of cgvp_attn_fwd.  Inference only. */
+int cgvp_attn_weights(const cgvp_attn_problem* problems, int32_t num_problems, int64_t num_pairs, int32_t heads,
+                      float scale, void* stream);
 
 /* Library self-description (checked by the loader and the CPU test-suite). */
 int cgvp_abi_version(void);

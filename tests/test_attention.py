@@ -1,0 +1,153 @@
+"""Varlen residue <-> atom cross attention (csrc/attn_kernels.hip) against stock torch: the op on ragged
+batches vs a per-pair dense softmax(QK^T / 4) V, its backward vs torch autograd, the head-averaged weights vs
+nn.MultiheadAttention's, and the whole JointGNN (encoders + varlen head) vs the oracle incl. every gradient."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import davis_synth as ds
+from conftest import GOLDEN, rel_err
+from gvp_hip import attention_ops  # noqa: F401
+from oracle import gvp_oracle as O
+
+DEV = "cuda:0"
+H, E = 8, 128
+
+
+def _ragged(rl, al, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    N, Na = sum(rl), sum(al)
+    t = [torch.randn(n, E, generator=g) for n in (N, Na, Na, Na, N, N)]
+    rptr = torch.tensor([0] + list(np.cumsum(rl)), dtype=torch.long)
+    aptr = torch.tensor([0] + list(np.cumsum(al)), dtype=torch.long)
+    return [x.to(dev) for x in t], rptr.to(dev), aptr.to(dev)
+
+
+def _dense_ref(q, k, v, qp, kp):
+    """per pair, per head: softmax(q k^T / sqrt(16)) v; also the head-averaged weights per pair"""
+    out = torch.zeros_like(q)
+    ws = []
+    for b in range(len(qp) - 1):
+        qs, ks = slice(int(qp[b]), int(qp[b + 1])), slice(int(kp[b]), int(kp[b + 1]))
+        qb = q[qs].view(-1, H, 16).transpose(0, 1)
+        kb = k[ks].view(-1, H, 16).transpose(0, 1)
+        vb = v[ks].view(-1, H, 16).transpose(0, 1)
+        p = torch.softmax(qb @ kb.transpose(1, 2) / 4.0, dim=-1)
+        out[qs] = (p @ vb).transpose(0, 1).reshape(-1, E)
+        ws.append(p.mean(0))
+    return out, ws
+
+
+def test_fake_kernels_cpu():
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        f = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device="cuda")
+        o_r, o_a, l_r, l_a = torch.ops.caster_gvp.cross_attention(f(70, E), f(9, E), f(9, E), f(9, E), f(70, E), f(70, E),
+                                                                  f(3, dt=torch.long), f(3, dt=torch.long), H)
+        assert o_r.shape == (70, E) and o_a.shape == (9, E) and l_r.shape == (70, H) and l_a.shape == (9, H)
+        w_r, w_a = torch.ops.caster_gvp.cross_attention_weights(f(70, E), f(9, E), l_r, f(9, E), f(70, E), l_a,
+                                                                f(3, dt=torch.long), f(3, dt=torch.long), H, 40, 5)
+        assert w_r.shape == (2, 40, 5) and w_a.shape == (2, 5, 40)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rl,al", [([300] * 4, [40, 33, 51, 28]), ([1, 17, 16, 333, 64], [10, 1, 100, 16, 17]),
+                                   ([4128, 215], [96, 12])])
+def test_cross_attention_forward_backward_weights(rl, al):
+    (q_r, k_a, v_a, q_a, k_r, v_r), rptr, aptr = _ragged(rl, al, 5, DEV)
+    leaves = [t.clone().requires_grad_() for t in (q_r, k_a, v_a, q_a, k_r, v_r)]
+    o_r, o_a, lse_r, lse_a = torch.ops.caster_gvp.cross_attention(*leaves, rptr, aptr, H)
+    refl = [t.detach().double().cpu().requires_grad_() for t in leaves]
+    ref_r, w_r = _dense_ref(refl[0], refl[1], refl[2], rptr.cpu(), aptr.cpu())
+    ref_a, w_a = _dense_ref(refl[3], refl[4], refl[5], aptr.cpu(), rptr.cpu())
+    assert rel_err(o_r, ref_r) < 1e-5 and rel_err(o_a, ref_a) < 1e-5
+    g = torch.Generator().manual_seed(9)
+    g_r, g_a = torch.randn(o_r.shape, generator=g), torch.randn(o_a.shape, generator=g)
+    ((o_r * g_r.to(DEV)).sum() + (o_a * g_a.to(DEV)).sum()).backward()
+    ((ref_r * g_r.double()).sum() + (ref_a * g_a.double()).sum()).backward()
+    for got, want, name in zip(leaves, refl, ("q_r", "k_a", "v_a", "q_a", "k_r", "v_r")):
+        assert rel_err(got.grad, want.grad) < 2e-5, name
+    rmax, amax = max(rl), max(al)
+    d_r, d_a = torch.ops.caster_gvp.cross_attention_weights(q_r, k_a, lse_r.detach(), q_a, k_r, lse_a.detach(), rptr, aptr,
+                                                            H, rmax, amax)
+    assert d_r.shape == (len(rl), rmax, amax) and d_a.shape == (len(rl), amax, rmax)
+    for b, (lr, la) in enumerate(zip(rl, al)):
+        assert rel_err(d_r[b, :lr, :la], w_r[b]) < 1e-5 and rel_err(d_a[b, :la, :lr], w_a[b]) < 1e-5
+        assert float(d_r[b, lr:].abs().sum()) == 0 and float(d_r[b, :, la:].abs().sum()) == 0
+    # run-to-run reproducible (no atomics anywhere)
+    again = torch.ops.caster_gvp.cross_attention(*[t.detach() for t in leaves], rptr, aptr, H)
+    assert torch.equal(again[0], o_r.detach()) and torch.equal(again[1], o_a.detach())
+
+
+@pytest.mark.gpu
+def test_cross_attention_opcheck():
+    (q_r, k_a, v_a, q_a, k_r, v_r), rptr, aptr = _ragged([40, 33], [12, 20], 1, DEV)
+    args = tuple(t.clone().requires_grad_() for t in (q_r, k_a, v_a, q_a, k_r, v_r)) + (rptr, aptr, H)
+    torch.library.opcheck(torch.ops.caster_gvp.cross_attention.default, args)
+
+
+@pytest.mark.gpu
+def test_module_varlen_equals_dense_mha():
+    """CrossAttentionModule.forward_varlen on compact rows == its reference forward (to_dense_batch + stock
+    nn.MultiheadAttention with key-padding masks) on the same weights, including the returned weights."""
+    from models.joint_gnn import CrossAttentionModule, to_dense_batch
+    torch.manual_seed(0)
+    mod = CrossAttentionModule(128, 128, 8, 0.0, True, 2, 0.2).to(DEV).eval()
+    rl, al = [57, 120, 33], [21, 40, 17]
+    g = torch.Generator().manual_seed(3)
+    r, m = torch.randn(sum(rl), 128, generator=g).to(DEV), torch.randn(sum(al), 128, generator=g).to(DEV)
+    rb = torch.repeat_interleave(torch.arange(3), torch.tensor(rl)).to(DEV)
+    mb = torch.repeat_interleave(torch.arange(3), torch.tensor(al)).to(DEV)
+    rptr = torch.tensor([0] + list(np.cumsum(rl))).to(DEV)
+    aptr = torch.tensor([0] + list(np.cumsum(al))).to(DEV)
+    with torch.no_grad():
+        e1, e2, (w1, w2) = mod.forward_varlen(r, m, rptr, aptr, need_weights=True)
+        dr, rmask = to_dense_batch(r, rb)
+        dm, mmask = to_dense_batch(m, mb)
+        d1, d2, (x1, x2) = mod(dr, dm, rmask, mmask)
+    assert rel_err(e1, d1[rmask]) < 1e-5 and rel_err(e2, d2[mmask]) < 1e-5
+    assert w1.shape == x1.shape and w2.shape == x2.shape
+    for b, (lr, la) in enumerate(zip(rl, al)):
+        assert rel_err(w1[b, :lr, :la], x1[b, :lr, :la]) < 1e-5 and rel_err(w2[b, :la, :lr], x2[b, :la, :lr]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_joint_model_all_gradients_vs_oracle(pretrained):
+    """Encoders (HIP) + varlen head vs the oracle's dense formulation: prediction and the gradient of EVERY one of the
+    764,396 parameters on a ragged batch."""
+    from models.joint_gnn import JointGNN
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))
+    model = JointGNN(protein_gnn_kwargs=kw["protein_gnn_kwargs"], molecule_gnn_kwargs=kw["molecule_gnn_kwargs"],
+                     **kw["joint_gnn_kwargs"])
+    model.load_state_dict(pretrained, strict=True)
+    model = model.to(DEV).eval()
+    p, m = ds.pair_batch(5, 21, lengths=[40, 75, 33, 120, 64])
+    pd, md = ds.to_torch(p), ds.to_torch(m)
+    to = lambda d: {k: (tuple(t.to(DEV) for t in v) if isinstance(v, tuple) else v.to(DEV)) for k, v in d.items()}
+    dp, dm = to(pd), to(md)
+    dp["ptr"], dm["ptr"] = torch.as_tensor(p.ptr).to(DEV), torch.as_tensor(m.ptr).to(DEV)
+    y, attn = model(dp, dm)
+    assert attn is not None and attn[0][0].shape == (5, 120, int(np.diff(m.ptr).max()))
+    P = {k: v.clone().requires_grad_(v.numel() > 0) for k, v in pretrained.items()}
+    ref = O.joint_forward(P, pd, md)
+    assert rel_err(y, ref) < 1e-4
+    r = torch.randn(5, 1, generator=torch.Generator().manual_seed(2))
+    (y * r.to(DEV)).sum().backward()
+    (ref * r).sum().backward()
+    scale = max(float(v.grad.abs().max()) for v in P.values() if v.grad is not None)
+    n = 0
+    for name, q in model.named_parameters():
+        if not q.numel():
+            continue
+        want = P[name].grad
+        err = float((q.grad.cpu() - want).abs().max())
+        assert err <= 5e-4 * float(want.abs().max()) + 2e-6 * scale, (name, err, float(want.abs().max()))
+        n += 1
+    assert n >= 100
+    model.train()
+    model.attention_weights = "auto"
+    _, none = model(dp, dm)
+    assert none is None                                  # training: the weights are not materialised
