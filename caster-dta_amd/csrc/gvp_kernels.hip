@@ -629,21 +629,23 @@ int cgvp_conv_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float*
                   const float* image, int32_t layer,
                   const float* h, const float* e_s, const float* e_v, const int64_t* etypes,
                   const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
-                  const int32_t* edst, int64_t N, int64_t E, int32_t aggr_mean, float* dh,
-                  void* stream) {
+                  const int32_t* edst, int64_t N, int64_t E, int32_t aggr_mean, const float* e_in,
+                  float* e_out, float* dh, void* stream) {
   if (int rc = check_dims(dims)) return rc;
   if (N < 0 || E < 0 || !layout || !params) return CGVP_ERR_BAD_ARG;
   if (layer < 0 || layer >= num_convs_of(*layout)) return CGVP_ERR_BAD_ARG;
   if (N == 0) return 0;
   if (!h || !dh || !rowptr) return CGVP_ERR_BAD_ARG;
-  if (E > 0 && (!e_s || !e_v || !eperm || !esrc || !edst || (layout->nt_edge > 0 && !etypes))) return CGVP_ERR_BAD_ARG;
-  if (((uintptr_t)h & 15) || ((uintptr_t)e_s & 15)) return CGVP_ERR_BAD_ARG;   // float4 row loads
+  if (!image && (e_in || e_out)) return CGVP_ERR_BAD_ARG;      // the stored edge embedding is a feature of the MFMA kernels
+  if (E > 0 && (!esrc || !edst)) return CGVP_ERR_BAD_ARG;
+  if (E > 0 && !e_in && (!e_s || !e_v || !eperm || (layout->nt_edge > 0 && !etypes))) return CGVP_ERR_BAD_ARG;
+  if (((uintptr_t)h & 15) || ((uintptr_t)e_s & 15) || ((uintptr_t)e_in & 15) || ((uintptr_t)e_out & 15)) return CGVP_ERR_BAD_ARG;   // float4 row loads
   if (image) {
     QuadOffsets o;
     if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
     if (int rc = quad::conv(layout->nt_edge, image + o.conv0 + layer * o.layer_stride, h, e_s, e_v, etypes, rowptr,
                             eperm, esrc, edst, N, E, aggr_mean ? 1 : 0, dh, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
-                            nullptr, gvp::RngArgs{nullptr, 0.f, 0}, (hipStream_t)stream)) return rc;
+                            nullptr, gvp::RngArgs{nullptr, 0.f, 0}, e_in, e_in ? nullptr : e_out, (hipStream_t)stream)) return rc;
     return launch_status();
   }
   // target nodes per workgroup: aim at ~48 of the 64 edge lanes per chunk
@@ -667,22 +669,24 @@ int cgvp_conv_layer_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
                         const float* h, const float* e_s, const float* e_v, const int64_t* etypes,
                         const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc, const int32_t* edst,
                         int64_t N, int64_t E, int32_t aggr_mean, const float* mask0, const float* mask1,
-                        const cgvp_rng* rng, int32_t with_head, float* dh, float* h_out, float* out, void* stream) {
+                        const cgvp_rng* rng, int32_t with_head, const float* e_in, float* e_out, float* dh,
+                        float* h_out, float* out, void* stream) {
   if (int rc = check_dims(dims)) return rc;
   if (int rc = check_rng(rng)) return rc;
   if (N < 0 || E < 0 || !layout || !image) return CGVP_ERR_BAD_ARG;
   if (layer < 0 || layer >= num_convs_of(*layout)) return CGVP_ERR_BAD_ARG;
   if (N == 0) return 0;
   if (!h || !rowptr || (with_head ? !out : !h_out)) return CGVP_ERR_BAD_ARG;
-  if (E > 0 && (!e_s || !e_v || !eperm || !esrc || !edst || (layout->nt_edge > 0 && !etypes))) return CGVP_ERR_BAD_ARG;
-  const void* al[] = {h, e_s, dh, h_out, out, mask0, mask1};
+  if (E > 0 && (!esrc || !edst)) return CGVP_ERR_BAD_ARG;
+  if (E > 0 && !e_in && (!e_s || !e_v || !eperm || (layout->nt_edge > 0 && !etypes))) return CGVP_ERR_BAD_ARG;
+  const void* al[] = {h, e_s, dh, h_out, out, mask0, mask1, e_in, e_out};
   for (const void* q : al) if ((uintptr_t)q & 15) return CGVP_ERR_BAD_ARG;
   QuadOffsets o;
   if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
   if (int rc = quad::conv(layout->nt_edge, image + o.conv0 + layer * o.layer_stride, h, e_s, e_v, etypes, rowptr, eperm,
                           esrc, edst, N, E, aggr_mean ? 1 : 0, dh, with_head ? 2 : 1,
                           image + o.node0 + layer * o.layer_stride, image + o.head, h_out, out, mask0, mask1,
-                          rng_args(rng, 2 * layer), (hipStream_t)stream)) return rc;
+                          rng_args(rng, 2 * layer), e_in, e_in ? nullptr : e_out, (hipStream_t)stream)) return rc;
   return launch_status();
 }
 
@@ -738,6 +742,7 @@ int64_t cgvp_bwd_workspace_floats(const cgvp_dims* dims, const cgvp_layout* layo
   if (int rc = quad::bwd_block_sizes(layout->nt_node, layout->nt_edge, &emb, &ce, &ct, &nd, &hd)) return rc;
   int mx = emb > ct ? emb : ct;
   mx = mx > nd + hd ? mx : nd + hd;
+  mx = mx > 2 * ce ? mx : 2 * ce;            // the edge stage runs two workgroups per CU (2 x kBwdMaxGrid slab rows)
   return (int64_t)kBwdMaxGrid * mx;
 }
 
@@ -780,19 +785,18 @@ int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const
 }
 
 int cgvp_conv_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image, int32_t layer,
-                  const float* h, const float* e_s, const float* e_v, const int64_t* etypes,
-                  const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc, const int32_t* edst,
-                  int64_t N, int64_t E, int32_t aggr_mean, const float* g_dh, float* g_src, int32_t g_src_zeroed,
-                  float* g_dst, float* grad_params, float* workspace, cgvp_segment* segs, int32_t* nsegs,
-                  void* stream) {
+                  const float* h, const float* e_emb, const int32_t* rowptr, const int32_t* esrc,
+                  const int32_t* edst, int64_t N, int64_t E, int32_t aggr_mean, const float* g_dh, float* g_src,
+                  int32_t g_src_zeroed, float* g_dst, float* g_e, float* grad_params, float* workspace,
+                  cgvp_segment* segs, int32_t* nsegs, void* stream) {
   if (int rc = check_dims(dims)) return rc;
   if (N < 0 || E < 0 || !layout || !image || !grad_params || !workspace) return CGVP_ERR_BAD_ARG;
   const int nc = num_convs_of(*layout);
   if (layer < 0 || layer >= nc) return CGVP_ERR_BAD_ARG;
   if (N == 0) return 0;
   if (!h || !g_dh || !g_src || !g_dst || !rowptr) return CGVP_ERR_BAD_ARG;
-  if (E > 0 && (!e_s || !e_v || !eperm || !esrc || !edst || (layout->nt_edge > 0 && !etypes))) return CGVP_ERR_BAD_ARG;
-  const void* al[] = {h, e_s, g_dh, g_src, g_dst};
+  if (E > 0 && (!e_emb || !g_e || !esrc || !edst)) return CGVP_ERR_BAD_ARG;
+  const void* al[] = {h, e_emb, g_dh, g_src, g_dst, g_e};
   for (const void* q : al) if ((uintptr_t)q & 15) return CGVP_ERR_BAD_ARG;
   QuadOffsets o;
   if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, nc, &o)) return rc;
@@ -804,12 +808,37 @@ int cgvp_conv_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float*
     if (err != hipSuccess) return (int)err;
   }
   if (int rc = quad::conv_bwd(layout->nt_edge, image + o.conv0 + layer * o.layer_stride,
-                              image + o.convT0 + layer * o.layerT_stride, h, e_s, e_v, etypes, rowptr, eperm, esrc,
-                              edst, N, E, aggr_mean ? 1 : 0, g_dh, g_src, g_dst, workspace, &grid, st)) return rc;
-  cgvp_segment sg[2] = {{workspace, grid, ct, 0, layout->conv0 - layout->edge_gvp, layout->edge_gvp},
-                        {workspace, grid, ct, ce, conv_ln0(), layout->conv0 + layer * layout->conv_stride}};
-  if (segs && nsegs) { segs[0] = sg[0]; segs[1] = sg[1]; *nsegs = 2; }
-  else quad::reduce_segments(sg, 2, grad_params, st);
+                              image + o.convT0 + layer * o.layerT_stride, h, e_emb, rowptr, esrc, edst, N, E,
+                              aggr_mean ? 1 : 0, g_dh, g_src, g_dst, g_e, workspace, &grid, st)) return rc;
+  cgvp_segment sg[1] = {{workspace, grid, ct, 0, conv_ln0(), layout->conv0 + layer * layout->conv_stride}};
+  if (segs && nsegs) { segs[0] = sg[0]; *nsegs = 1; }
+  else quad::reduce_segments(sg, 1, grad_params, st);
+  return launch_status();
+}
+
+int cgvp_edge_embed_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image, const float* e_s,
+                        const float* e_v, const int64_t* etypes, const int32_t* eperm, int64_t E,
+                        const float* const* g_e, int32_t num_g, float* grad_params, float* workspace,
+                        cgvp_segment* segs, int32_t* nsegs, void* stream) {
+  if (int rc = check_dims(dims)) return rc;
+  if (E < 0 || !layout || !image || !grad_params || !workspace || !g_e || num_g < 1) return CGVP_ERR_BAD_ARG;
+  if (segs && nsegs) *nsegs = 0;
+  if (E == 0) return 0;
+  if (!e_s || !e_v || !eperm || (layout->nt_edge > 0 && !etypes)) return CGVP_ERR_BAD_ARG;
+  if ((uintptr_t)e_s & 15) return CGVP_ERR_BAD_ARG;
+  for (int l = 0; l < num_g; ++l) if (!g_e[l] || ((uintptr_t)g_e[l] & 15)) return CGVP_ERR_BAD_ARG;
+  const int nc = num_convs_of(*layout);
+  QuadOffsets o;
+  if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, nc, &o)) return rc;
+  int emb, ce, ct, nd, hd, grid = 0;
+  if (int rc = quad::bwd_block_sizes(layout->nt_node, layout->nt_edge, &emb, &ce, &ct, &nd, &hd)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  // gvp_edge's fragments are the head of every conv slice (identical in all layers): layer 0's is used
+  if (int rc = quad::edge_embed_bwd(layout->nt_edge, image + o.conv0, image + o.convT0, e_s, e_v, etypes, eperm, E, g_e,
+                                    num_g, workspace, &grid, st)) return rc;
+  cgvp_segment sg[1] = {{workspace, grid, ce, 0, layout->conv0 - layout->edge_gvp, layout->edge_gvp}};
+  if (segs && nsegs) { segs[0] = sg[0]; *nsegs = 1; }
+  else quad::reduce_segments(sg, 1, grad_params, st);
   return launch_status();
 }
 

@@ -68,14 +68,14 @@ __device__ __forceinline__ void zero_block(float* gblk, int lane) {
   for (int k = lane; k < BLK / 4; k += WAVE) reinterpret_cast<f4*>(gblk)[k] = f4{0.f, 0.f, 0.f, 0.f};
 }
 // slab row of this workgroup = sum of its waves' private blocks (stride PW floats apart)
-template <int BLK, int PW>
+template <int BLK, int PW, int WPB_ = 8>
 __device__ __forceinline__ void write_slab_row(float* slab, const float* blocks) {
   __syncthreads();
   float* out = slab + (size_t)blockIdx.x * BLK;
-  for (int k = threadIdx.x; k < BLK; k += BW_TPB) {
+  for (int k = threadIdx.x; k < BLK; k += WAVE * WPB_) {
     float t = 0.f;
 #pragma unroll
-    for (int ww = 0; ww < BW_WPB; ++ww) t += blocks[ww * PW + k];
+    for (int ww = 0; ww < WPB_; ++ww) t += blocks[ww * PW + k];
     out[k] = t;
   }
 }
@@ -365,38 +365,54 @@ __global__ __launch_bounds__(BW_TPB, 2) void head_bwd_kernel(HeadBArgs a) {
 }
 
 // ===================================================================== conv
-// Gradient block: [gvp_edge.0 | gvp_edge.1 (64)] then [message_func.0 | .1 | .2].
+// The edge embedding (gvp_edge + LayerNorm, protein_gnn.py:376) is NOT part of this kernel: the first conv layer's
+// forward stored it in sorted-edge order (EROW floats per edge), this kernel reads it as an input of message_func.0
+// and writes its gradient d e to `g_e` (same layout); edge_bwd_kernel below back-propagates the SUM of the layers'
+// d e through LayerNorm and gvp_edge once per step.  (Round 1 recomputed the embedding and ran its backward and
+// weight gradients inside every conv layer's backward: 32 + ~70 of that kernel's 319 MFMAs per 16 edges, a
+// 4.8 KB slice of every wave's private gradient block and 14.6 KB of LDS images.)
+// Gradient block: [message_func.0 | .1 | .2].
+constexpr int EROW = quad::kEdgeRow;
 template <int NTE>
 struct ConvBlk {
-  static constexpr int E_GVP = 0, E_LN = LEdgeGvp::size(NTE), E_SIZE = pad4(E_LN + 2 * ES);
-  static constexpr int M0 = E_SIZE, M1 = M0 + LMsg0::size(0), M2 = M1 + LMsg::size(0), SIZE = pad4(M2 + LMsg::size(0));
+  static constexpr int M0 = 0, M1 = M0 + LMsg0::size(0), M2 = M1 + LMsg::size(0), SIZE = pad4(M2 + LMsg::size(0));
 };
-// One workgroup of 8 waves per CU (2 per SIMD) owning all 160 KB of LDS:
-//   [forward slices | transposed slices | per wave: private gradient block, g_src scratch]
-constexpr int CB_WPB = BW_WPB, CB_TPB = BW_TPB, CB_MAX_GRID = BW_MAX_GRID;
+// One workgroup of 8 waves per CU (2 per SIMD):
+//   [message slices of the forward image | of the transposed image | per wave: private gradient block, scratch]
+#ifndef CGVP_CONV_BWD_WAVES
+#define CGVP_CONV_BWD_WAVES 8       // 12 (3 waves per SIMD, 168 VGPRs with 16 spilled) measured 56 us vs 43 us per launch at davis_b64: not worth it
+#endif
+constexpr int CB_WPB = CGVP_CONV_BWD_WAVES, CB_TPB = WAVE * CB_WPB, CB_MAX_GRID = BW_MAX_GRID;
 constexpr int CB_SCR = TSCR_FLOATS;                  // per wave: operand-transpose scratch; also half a tile of [28]-rows + 16 ids (g_src)
 static_assert(CB_SCR >= (TILE / 2) * ROW + TILE, "g_src transpose fits the scratch");
 template <int NTE>
-constexpr int conv_bwd_lds_floats() { return BW_TPB + Image<0, NTE>::CV_SIZE + Image<0, NTE>::TC_SIZE + CB_WPB * (ConvBlk<NTE>::SIZE + CB_SCR); }
+struct ConvBImg {
+  typedef Image<0, NTE> IM;
+  static constexpr int F0 = IM::CV_M0, FSIZE = IM::CV_SIZE - IM::CV_M0;       // forward message slices
+  static constexpr int T0 = IM::TC_M0, TSIZE = IM::TC_SIZE - IM::TC_M0;       // transposed message slices
+};
+template <int NTE>
+constexpr int conv_bwd_lds_floats() { return CB_TPB + ConvBImg<NTE>::FSIZE + ConvBImg<NTE>::TSIZE + CB_WPB * (ConvBlk<NTE>::SIZE + CB_SCR); }
 static_assert(conv_bwd_lds_floats<1>() * 4 <= 160 * 1024 && conv_bwd_lds_floats<0>() * 4 <= 160 * 1024, "conv backward LDS plan exceeds the CU");
 
 struct ConvBArgs {
   const float* img; const float* imgT;
-  const float* h; const float* e_s; const float* e_v; const int64_t* etypes;
-  const int32_t* rowptr; const int32_t* eperm; const int32_t* esrc; const int32_t* edst;
-  int64_t N; int npw; int mean; const float* g_dh; float* g_src; float* g_dst; float* slab;
+  const float* h; const float* e_emb;
+  const int32_t* rowptr; const int32_t* esrc; const int32_t* edst;
+  int64_t N; int npw; int mean; const float* g_dh; float* g_src; float* g_dst; float* g_e; float* slab;
 };
 
 template <int NTE>
-__global__ __launch_bounds__(CB_TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
+__global__ __launch_bounds__(CB_TPB, CB_WPB / 4) void conv_bwd_kernel(ConvBArgs a) {
   typedef Image<0, NTE> IM;
+  typedef ConvBImg<NTE> BI;
   typedef ConvBlk<NTE> B;
   constexpr int PW = B::SIZE + CB_SCR;                                // per-wave LDS floats
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* img = lds + BW_TPB;
-  float* imgT = img + IM::CV_SIZE;
+  float* img = lds + CB_TPB - BI::F0;                                 // indexed with the IM::CV_* offsets of the message slices
+  float* imgT = lds + CB_TPB + BI::FSIZE - BI::T0;                    // ... and IM::TC_*
   const int lane0 = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float* blocks = imgT + IM::TC_SIZE;
+  float* blocks = lds + CB_TPB + BI::FSIZE + BI::TSIZE;
   float* gblk = blocks + w * PW;                                      // this wave's private gradient block (AccPriv)
   float* scr = gblk + B::SIZE;
 #ifdef CGVP_MFMA_TRANSPOSE
@@ -404,8 +420,8 @@ __global__ __launch_bounds__(CB_TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
 #else
   float* const CB_TSCR = scr;
 #endif
-  stage_slice<IM::CV_SIZE, CB_TPB>(img, a.img, threadIdx.x);
-  stage_slice<IM::TC_SIZE, CB_TPB>(imgT, a.imgT, threadIdx.x);
+  stage_slice<BI::FSIZE, CB_TPB>(lds + CB_TPB, a.img + BI::F0, threadIdx.x);
+  stage_slice<BI::TSIZE, CB_TPB>(lds + CB_TPB + BI::FSIZE, a.imgT + BI::T0, threadIdx.x);
   for (int k = lane0; k < B::SIZE / 4; k += WAVE) reinterpret_cast<f4*>(gblk)[k] = f4{0.f, 0.f, 0.f, 0.f};
   STAMP(0);
   __syncthreads();
@@ -431,25 +447,19 @@ __global__ __launch_bounds__(CB_TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
       const int lane = opaque_lane(lane0), i = lane & 15, g = lane >> 4;
       const int32_t p = base + i;
       const bool active = p < e1;
-      // ---- gather (as the forward)
+      // ---- gather: stored edge embedding (sequential) + source / target rows + d(aggregated message)
       f4 es0 = zero, es1 = zero, sj = zero, si = zero, d_ms = zero;
       float ev[3] = {0.f, 0.f, 0.f}, vj[3] = {0.f, 0.f, 0.f}, vi[3] = {0.f, 0.f, 0.f}, d_mv[3] = {0.f, 0.f, 0.f};
-      int et[1] = {0};
       int32_t src = 0, dst = -1;
       if (active) {
-        const int32_t eid = a.eperm[p];
         src = a.esrc[p];
         dst = a.edst[p];
-        const float* er = a.e_s + (int64_t)eid * EDGE_IN_S;
+        const float* er = a.e_emb + (int64_t)p * EROW;
         es0 = *reinterpret_cast<const f4*>(er + 4 * g);
         es1 = *reinterpret_cast<const f4*>(er + 16 + 4 * g);
         if (g == 0) {
 #pragma unroll
-          for (int d = 0; d < 3; ++d) ev[d] = a.e_v[(int64_t)eid * 3 + d];
-        }
-        if (NTE > 0) {
-          et[0] = (int)a.etypes[eid];
-          et[0] = et[0] < 0 ? 0 : (et[0] >= NTE ? NTE - 1 : et[0]);
+          for (int d = 0; d < 3; ++d) ev[d] = er[ES + d];
         }
         const float* hj = a.h + (int64_t)src * ROW;
         const float* hi = a.h + (int64_t)dst * ROW;
@@ -468,24 +478,12 @@ __global__ __launch_bounds__(CB_TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
         }
       }
       STAMP(2);
-      // ---- recompute the forward of the tile, keeping every GVP's cache
-      float bse[1][8], bve[1][3][1];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { bse[0][r] = es0[r]; bse[0][4 + r] = es1[r]; }
-#pragma unroll
-      for (int d = 0; d < 3; ++d) bve[0][d][0] = ev[d];
-      f4 e_pre[1][2];
-      float ev_pre[1][3][1];
-      typename QEdge<NTE>::Cache ce[1];
-      QEdge<NTE>::template forward<1>(img + IM::CV_EDGE, lane, et, bse, bve, e_pre, ev_pre, ce);
-      f4 e_s[2] = {e_pre[0][0], e_pre[0][1]};
-      float e_v[3][1] = {{ev_pre[0][0][0]}, {ev_pre[0][1][0]}, {ev_pre[0][2][0]}};
-      ln_quad<ES, EV>(img + IM::CV_ELN, lane, e_s, e_v);
+      // ---- recompute the three message GVPs of the tile, keeping every GVP's cache
       float b0[1][16], bv0[1][3][3], b1[1][4], bv1[1][3][1], b2[1][4], bv2[1][3][1];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { b0[0][r] = sj[r]; b0[0][4 + r] = e_s[0][r]; b0[0][8 + r] = e_s[1][r]; b0[0][12 + r] = si[r]; }
+      for (int r = 0; r < 4; ++r) { b0[0][r] = sj[r]; b0[0][4 + r] = es0[r]; b0[0][8 + r] = es1[r]; b0[0][12 + r] = si[r]; }
 #pragma unroll
-      for (int d = 0; d < 3; ++d) { bv0[0][d][0] = vj[d]; bv0[0][d][1] = vi[d]; bv0[0][d][2] = e_v[d][0]; }
+      for (int d = 0; d < 3; ++d) { bv0[0][d][0] = vj[d]; bv0[0][d][1] = vi[d]; bv0[0][d][2] = ev[d]; }
       f4 s1[1][1], s2[1][1], s3[1][1];
       float v1[1][3][1], v2[1][3][1], v3[1][3][1];
       QMsg0::Cache c0[1];
@@ -534,17 +532,15 @@ __global__ __launch_bounds__(CB_TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
         QMsg0::weight_grads<AccPriv>(gblk + B::M0, first, lane, 0, active, b0[0], bv0[0], c0[0], gr, CB_TSCR);
       }
       STAMP(4);
-      // ---- edge embedding: LayerNorm and GVP (weight gradients only; raw edge features get none)
-      {
-        f4 d_es[2] = {f4{d_b0[4], d_b0[5], d_b0[6], d_b0[7]}, f4{d_b0[8], d_b0[9], d_b0[10], d_b0[11]}};
-        float d_ev[3][1] = {{d_bv0[0][2]}, {d_bv0[1][2]}, {d_bv0[2][2]}};
-        f4 dga[2], dbe[2];
-        ln_quad_bwd<ES, EV>(img + IM::CV_ELN, lane, e_pre[0], ev_pre[0], d_es, d_ev, dga, dbe);
-        ln_param_grads<AccPriv, ES>(gblk + B::E_LN, first, lane, active, dga, dbe);
-        float d_in[8], d_inv[3][1];
-        typename QEdge<NTE>::Grads gr;
-        QEdge<NTE>::backward(imgT + IM::TC_EDGE, lane, ce[0], d_es, d_ev, d_in, d_inv, gr);
-        QEdge<NTE>::template weight_grads<AccPriv>(gblk + B::E_GVP, first, lane, et[0], active, bse[0], bve[0], ce[0], gr, CB_TSCR);
+      // ---- d(edge embedding) of this layer -> g_e (plain stores, sorted-edge order)
+      if (active) {
+        float* gr_ = a.g_e + (int64_t)p * EROW;
+        *reinterpret_cast<f4*>(gr_ + 4 * g) = f4{d_b0[4], d_b0[5], d_b0[6], d_b0[7]};
+        *reinterpret_cast<f4*>(gr_ + 16 + 4 * g) = f4{d_b0[8], d_b0[9], d_b0[10], d_b0[11]};
+        if (g == 0) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) gr_[ES + d] = d_bv0[d][2];
+        }
       }
       STAMP(5);
       // ---- d h[src]: unsorted sources -> float atomics on the zero-initialised g_src.  The rows
@@ -606,8 +602,97 @@ __global__ __launch_bounds__(CB_TPB, 2) void conv_bwd_kernel(ConvBArgs a) {
     STAMP(7);
   }
   STAMP(8);
-  write_slab_row<B::SIZE, PW>(a.slab, blocks);
+  write_slab_row<B::SIZE, PW, CB_WPB>(a.slab, blocks);
   STAMP(9);
+}
+
+// ===================================================================== edge embedding
+// Backward of gvp_edge = Sequential(GVP, LayerNorm) (protein_gnn.py:331-335, :376) for a tile of 16 sorted edges,
+// ONCE per step: the upstream gradient is the sum of the conv layers' d e buffers.  Raw edge features get no
+// gradient, so only what the weight gradients need is back-propagated.
+// Gradient block: [gvp_edge.0 | gvp_edge.1 (gamma, beta)].
+template <int NTE>
+struct EdgeBlk {
+  static constexpr int GVP = 0, LN = LEdgeGvp::size(NTE), SIZE = pad4(LN + 2 * ES);
+};
+constexpr int EB_MAX_LAYERS = 8;
+struct EdgeBArgs {
+  const float* img; const float* imgT;
+  const float* e_s; const float* e_v; const int64_t* etypes; const int32_t* eperm; int64_t E;
+  const float* g_e[EB_MAX_LAYERS]; int n_g; float* slab;
+};
+template <int NTE>
+constexpr int edge_bwd_lds_floats() { return BW_TPB + Image<0, NTE>::CV_M0 + Image<0, NTE>::TC_M0 + BW_WPB * (EdgeBlk<NTE>::SIZE + TSCR_FLOATS); }
+
+template <int NTE>
+__global__ __launch_bounds__(BW_TPB, 2) void edge_bwd_kernel(EdgeBArgs a) {
+  typedef Image<0, NTE> IM;
+  typedef EdgeBlk<NTE> B;
+  constexpr int PW = B::SIZE + TSCR_FLOATS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* img = lds + BW_TPB;                      // [QEdge | edge LN]  (= the first CV_M0 floats of the conv slice)
+  float* imgT = img + IM::CV_M0;                  // QEdge transposed  (= the first TC_M0 floats of the convT slice)
+  const int lane0 = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* blocks = imgT + IM::TC_M0;
+  float* gblk = blocks + w * PW;
+  float* tscr = gblk + B::SIZE;
+  stage_slice<IM::CV_M0, BW_TPB>(img, a.img, threadIdx.x);
+  stage_slice<IM::TC_M0, BW_TPB>(imgT, a.imgT, threadIdx.x);
+  for (int k = lane0; k < B::SIZE / 4; k += WAVE) reinterpret_cast<f4*>(gblk)[k] = f4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  const bool first = false;
+  const int64_t tiles = (a.E + TILE - 1) / TILE;
+  for (int64_t t = (int64_t)w * gridDim.x + blockIdx.x; t < tiles; t += (int64_t)gridDim.x * BW_WPB) {
+    const int lane = opaque_lane(lane0), i = lane & 15, g = lane >> 4;
+    const int64_t p = t * TILE + i;
+    const bool active = p < a.E;
+    f4 es0 = zero, es1 = zero;
+    float ev[3] = {0.f, 0.f, 0.f};
+    int et[1] = {0};
+    f4 d_es[2] = {zero, zero};
+    float d_ev[3][1] = {{0.f}, {0.f}, {0.f}};
+    if (active) {
+      const int32_t eid = a.eperm[p];
+      const float* er = a.e_s + (int64_t)eid * EDGE_IN_S;
+      es0 = *reinterpret_cast<const f4*>(er + 4 * g);
+      es1 = *reinterpret_cast<const f4*>(er + 16 + 4 * g);
+      if (g == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) ev[d] = a.e_v[(int64_t)eid * 3 + d];
+      }
+      if (NTE > 0) {
+        et[0] = (int)a.etypes[eid];
+        et[0] = et[0] < 0 ? 0 : (et[0] >= NTE ? NTE - 1 : et[0]);
+      }
+      for (int l = 0; l < a.n_g; ++l) {                    // sum of the conv layers' d(edge embedding)
+        const float* gr_ = a.g_e[l] + p * EROW;
+        d_es[0] += *reinterpret_cast<const f4*>(gr_ + 4 * g);
+        d_es[1] += *reinterpret_cast<const f4*>(gr_ + 16 + 4 * g);
+        if (g == 0) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) d_ev[d][0] += gr_[ES + d];
+        }
+      }
+    }
+    float bse[1][8], bve[1][3][1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { bse[0][r] = es0[r]; bse[0][4 + r] = es1[r]; }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) bve[0][d][0] = ev[d];
+    f4 e_pre[1][2];
+    float ev_pre[1][3][1];
+    typename QEdge<NTE>::Cache ce[1];
+    QEdge<NTE>::template forward<1>(img + IM::CV_EDGE, lane, et, bse, bve, e_pre, ev_pre, ce);
+    f4 dga[2], dbe[2];
+    ln_quad_bwd<ES, EV>(img + IM::CV_ELN, lane, e_pre[0], ev_pre[0], d_es, d_ev, dga, dbe);
+    ln_param_grads<AccPriv, ES>(gblk + B::LN, first, lane, active, dga, dbe);
+    float d_in[8], d_inv[3][1];
+    typename QEdge<NTE>::Grads gr;
+    QEdge<NTE>::backward(imgT + IM::TC_EDGE, lane, ce[0], d_es, d_ev, d_in, d_inv, gr);
+    QEdge<NTE>::template weight_grads<AccPriv>(gblk + B::GVP, first, lane, et[0], active, bse[0], bve[0], ce[0], gr, tscr);
+  }
+  write_slab_row<B::SIZE, PW>(a.slab, blocks);
 }
 
 // ===================================================================== node embed
@@ -763,8 +848,8 @@ namespace quad {
 int bwd_block_sizes(int nt_node, int nt_edge, int* emb, int* conv_edge, int* conv_total, int* node, int* head) {
   if (nt_node == 0) *emb = EmbBlk<0>::SIZE; else if (nt_node == 20) *emb = EmbBlk<20>::SIZE;
   else if (nt_node == 21) *emb = EmbBlk<21>::SIZE; else return CGVP_ERR_UNSUPPORTED_DIMS;
-  if (nt_edge == 0) { *conv_edge = ConvBlk<0>::E_SIZE; *conv_total = ConvBlk<0>::SIZE; }
-  else if (nt_edge == 1) { *conv_edge = ConvBlk<1>::E_SIZE; *conv_total = ConvBlk<1>::SIZE; }
+  if (nt_edge == 0) { *conv_edge = EdgeBlk<0>::SIZE; *conv_total = ConvBlk<0>::SIZE; }     // edge_bwd / conv_bwd blocks
+  else if (nt_edge == 1) { *conv_edge = EdgeBlk<1>::SIZE; *conv_total = ConvBlk<1>::SIZE; }
   else return CGVP_ERR_UNSUPPORTED_DIMS;
   *node = NODE_GB;
   *head = HEAD_GB;
@@ -816,10 +901,9 @@ int head_bwd(const float* img_head, const float* imgT_head, const float* h_out, 
 
 template <int NTE>
 int conv_bwd_impl(ConvBArgs& a, int* grid, hipStream_t st) {
-  typedef Image<0, NTE> IM;
-  const int64_t groups = (a.N + a.npw - 1) / a.npw;
-  const int64_t cwg = (groups + CB_WPB - 1) / CB_WPB;
-  const int G = (int)(cwg < 1 ? 1 : (cwg > CB_MAX_GRID ? CB_MAX_GRID : cwg));     // one workgroup per CU, one slab row each
+  const int64_t ngroups = (a.N + a.npw - 1) / a.npw;
+  const int64_t wgs = (ngroups + CB_WPB - 1) / CB_WPB;
+  const int G = (int)(wgs < 1 ? 1 : (wgs > CB_MAX_GRID ? CB_MAX_GRID : wgs));
   *grid = G;
   const size_t lds = (size_t)conv_bwd_lds_floats<NTE>() * sizeof(float);
   if (hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_kernel<NTE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return (int)err;
@@ -827,17 +911,40 @@ int conv_bwd_impl(ConvBArgs& a, int* grid, hipStream_t st) {
   return 0;
 }
 
-int conv_bwd(int nt_edge, const float* img, const float* imgT, const float* h, const float* e_s, const float* e_v,
-             const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
-             const int32_t* edst, int64_t N, int64_t E, int mean, const float* g_dh, float* g_src, float* g_dst,
-             float* slab, int* grid, hipStream_t st) {
+int conv_bwd(int nt_edge, const float* img, const float* imgT, const float* h, const float* e_emb,
+             const int32_t* rowptr, const int32_t* esrc, const int32_t* edst, int64_t N, int64_t E, int mean,
+             const float* g_dh, float* g_src, float* g_dst, float* g_e, float* slab, int* grid, hipStream_t st) {
+  // targets per wave: two 16-edge tiles' worth (the forward's 32-edge passes), as in quad::conv
   int64_t deg = N > 0 ? (E + N - 1) / N : 1;
   if (deg < 1) deg = 1;
   int npw = (int)((2 * TILE - 2) / deg);
-  npw = npw < 1 ? 1 : npw;
-  ConvBArgs a{img, imgT, h, e_s, e_v, etypes, rowptr, eperm, esrc, edst, N, npw, mean, g_dh, g_src, g_dst, slab};
+  npw = npw < 1 ? 1 : (npw > WAVE ? WAVE : npw);
+  ConvBArgs a{img, imgT, h, e_emb, rowptr, esrc, edst, N, npw, mean, g_dh, g_src, g_dst, g_e, slab};
   if (nt_edge == 0) return conv_bwd_impl<0>(a, grid, st);
   if (nt_edge == 1) return conv_bwd_impl<1>(a, grid, st);
+  return CGVP_ERR_UNSUPPORTED_DIMS;
+}
+
+template <int NTE>
+int edge_bwd_impl(EdgeBArgs& a, int* grid, hipStream_t st) {
+  // 66 KB of LDS and ~115 VGPRs per workgroup: TWO workgroups share a CU (4 waves per SIMD), so up to 2 x 240 slab rows
+  const int64_t tiles = (a.E + TILE - 1) / TILE;
+  const int G = (int)(tiles < 1 ? 1 : (tiles > 2 * BW_MAX_GRID ? 2 * BW_MAX_GRID : tiles));
+  *grid = G;
+  const size_t lds = (size_t)edge_bwd_lds_floats<NTE>() * sizeof(float);
+  if (hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_bwd_kernel<NTE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return (int)err;
+  hipLaunchKernelGGL(edge_bwd_kernel<NTE>, dim3(G), dim3(BW_TPB), lds, st, a);
+  return 0;
+}
+
+int edge_embed_bwd(int nt_edge, const float* img, const float* imgT, const float* e_s, const float* e_v,
+                   const int64_t* etypes, const int32_t* eperm, int64_t E, const float* const* g_e, int n_g,
+                   float* slab, int* grid, hipStream_t st) {
+  if (n_g < 1 || n_g > EB_MAX_LAYERS) return CGVP_ERR_BAD_ARG;
+  EdgeBArgs a{img, imgT, e_s, e_v, etypes, eperm, E, {}, n_g, slab};
+  for (int l = 0; l < n_g; ++l) a.g_e[l] = g_e[l];
+  if (nt_edge == 0) return edge_bwd_impl<0>(a, grid, st);
+  if (nt_edge == 1) return edge_bwd_impl<1>(a, grid, st);
   return CGVP_ERR_UNSUPPORTED_DIMS;
 }
 

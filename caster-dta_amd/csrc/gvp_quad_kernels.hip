@@ -295,7 +295,14 @@ struct ConvQArgs {
   const int32_t* rowptr; const int32_t* eperm; const int32_t* esrc; const int32_t* edst;
   int64_t N; int npw; int mean; float* dh;
   NodeQArgs node;     // FUSE > 0: the node update of the same layer runs on the wave's own targets (h = this->h)
+  // EDGE EMBEDDING STORE (sorted-edge order, EROW floats per edge = [e_s 32 | e_v 3 | pad]): gvp_edge + LayerNorm
+  // (protein_gnn.py:376) does not depend on the layer, so the first conv layer may write it (e_out) and later layers
+  // and the backward kernels read it (e_in) instead of re-deriving it from the raw features
+  const float* e_in; float* e_out;
 };
+constexpr int EROW = 36;
+// EMODE of the conv kernel: 0 = derive the edge embedding from the raw features (and keep it in registers),
+// 1 = derive it and also store it to e_out, 2 = read it from e_in (raw features untouched)
 
 constexpr int CTN = 2;                 // edge tiles processed in lockstep per pass (32 edges)
 
@@ -310,7 +317,7 @@ struct ConvIn {
 
 // Gather the inputs of the pass starting at sorted-edge position `base`:
 // CSR tables -> raw edge features (original edge order) + source / target rows.
-template <int NTE>
+template <int NTE, int EMODE>
 __device__ __forceinline__ void conv_gather(const ConvQArgs& a, int32_t base, int32_t e1, int lane, ConvIn& in) {
   const int i = lane & 15, g = lane >> 4;
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -320,7 +327,7 @@ __device__ __forceinline__ void conv_gather(const ConvQArgs& a, int32_t base, in
     const int32_t p = base + j * TILE + i;
     in.active[j] = p < e1;
     in.dst[j] = in.active[j] ? a.edst[p] : -1;
-    eid[j] = in.active[j] ? a.eperm[p] : 0;
+    eid[j] = (EMODE != 2 && in.active[j]) ? a.eperm[p] : 0;
     src[j] = in.active[j] ? a.esrc[p] : 0;
   }
 #pragma unroll
@@ -330,16 +337,26 @@ __device__ __forceinline__ void conv_gather(const ConvQArgs& a, int32_t base, in
 #pragma unroll
     for (int d = 0; d < 3; ++d) in.ev[j][d] = in.vj[j][d] = in.vi[j][d] = 0.f;
     if (in.active[j]) {
-      const float* er = a.e_s + (int64_t)eid[j] * EDGE_IN_S;
-      in.es0[j] = *reinterpret_cast<const f4*>(er + 4 * g);
-      in.es1[j] = *reinterpret_cast<const f4*>(er + 16 + 4 * g);
-      if (g == 0) {
+      if (EMODE == 2) {                                // stored embedding, sequential in sorted-edge order
+        const float* er = a.e_in + (int64_t)(base + j * TILE + i) * EROW;
+        in.es0[j] = *reinterpret_cast<const f4*>(er + 4 * g);
+        in.es1[j] = *reinterpret_cast<const f4*>(er + 16 + 4 * g);
+        if (g == 0) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) in.ev[j][d] = a.e_v[(int64_t)eid[j] * 3 + d];
-      }
-      if (NTE > 0) {
-        in.et[j] = (int)a.etypes[eid[j]];
-        in.et[j] = in.et[j] < 0 ? 0 : (in.et[j] >= NTE ? NTE - 1 : in.et[j]);
+          for (int d = 0; d < 3; ++d) in.ev[j][d] = er[ES + d];
+        }
+      } else {
+        const float* er = a.e_s + (int64_t)eid[j] * EDGE_IN_S;
+        in.es0[j] = *reinterpret_cast<const f4*>(er + 4 * g);
+        in.es1[j] = *reinterpret_cast<const f4*>(er + 16 + 4 * g);
+        if (g == 0) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) in.ev[j][d] = a.e_v[(int64_t)eid[j] * 3 + d];
+        }
+        if (NTE > 0) {
+          in.et[j] = (int)a.etypes[eid[j]];
+          in.et[j] = in.et[j] < 0 ? 0 : (in.et[j] >= NTE ? NTE - 1 : in.et[j]);
+        }
       }
       const float* hj = a.h + (int64_t)src[j] * ROW;
       const float* hi = a.h + (int64_t)in.dst[j] * ROW;
@@ -353,8 +370,8 @@ __device__ __forceinline__ void conv_gather(const ConvQArgs& a, int32_t base, in
 
 // Message of CTN tiles: raw edge features -> gvp_edge + LayerNorm (in registers)
 // -> cat with source / target node rows -> 3 message GVPs.
-template <int NTE>
-__device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, int lane,
+template <int NTE, int EMODE>
+__device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, int lane, float* e_out, int32_t base,
                                            f4 (&m_s)[CTN], float (&m_v)[CTN][3]) {
   typedef Image<0, NTE> IM;
   const f4 (&es0)[CTN] = in.es0; const f4 (&es1)[CTN] = in.es1; const f4 (&sj)[CTN] = in.sj; const f4 (&si)[CTN] = in.si;
@@ -364,7 +381,14 @@ __device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, i
   // gvp_edge + LayerNorm, in registers (protein_gnn.py:376)
   f4 e_s[CTN][2];
   float e_v[CTN][3][1];
-  {
+  if (EMODE == 2) {
+#pragma unroll
+    for (int j = 0; j < CTN; ++j) {
+      e_s[j][0] = es0[j]; e_s[j][1] = es1[j];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) e_v[j][d][0] = ev[j][d];
+    }
+  } else {
     float bs[CTN][8], bv[CTN][3][1];
 #pragma unroll
     for (int j = 0; j < CTN; ++j) {
@@ -377,6 +401,17 @@ __device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, i
     QEdge<NTE>::template forward<CTN>(img + IM::CV_EDGE, lane, et, bs, bv, e_s, e_v, c);
 #pragma unroll
     for (int j = 0; j < CTN; ++j) ln_quad<ES, EV>(img + IM::CV_ELN, lane, e_s[j], e_v[j]);
+    if (EMODE == 1) {
+      const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+      for (int j = 0; j < CTN; ++j)
+        if (in.active[j]) {
+          float* er = e_out + (int64_t)(base + j * TILE + i) * EROW;
+          *reinterpret_cast<f4*>(er + 4 * g) = e_s[j][0];
+          *reinterpret_cast<f4*>(er + 16 + 4 * g) = e_s[j][1];
+          if (g == 0) *reinterpret_cast<f4*>(er + ES) = f4{e_v[j][0][0], e_v[j][1][0], e_v[j][2][0], 0.f};   // + zero pad
+        }
+    }
   }
   STAMP(5);
   // message_func.0 on cat((s_j, V_j), edge, (s_i, V_i))   (gvp_layers.py:306)
@@ -435,7 +470,7 @@ __device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, i
 // segment total into the wave's private LDS accumulator.  Ownership makes the
 // result independent of scheduling: no atomics on HBM, bitwise reproducible.
 // FUSE: 0 = conv only; 1 = + node update; 2 = + node update with the output head
-template <int NTE, int FUSE>
+template <int NTE, int FUSE, int EMODE>
 __global__ __launch_bounds__(TPB) void conv_quad_kernel(ConvQArgs a) {
   typedef Image<0, NTE> IM;
   typedef Image<0, 0> IMN;
@@ -453,7 +488,7 @@ __global__ __launch_bounds__(TPB) void conv_quad_kernel(ConvQArgs a) {
   // The first pass's gathers (3 dependent hops) are issued BEFORE the image is
   // staged so that their latency hides behind the staging traffic and barrier.
   ConvIn in;
-  conv_gather<NTE>(a, e0, e1, lane, in);
+  conv_gather<NTE, EMODE>(a, e0, e1, lane, in);
   stage_slice<IM::CV_SIZE>(img, a.img, threadIdx.x);
   if (FUSE > 0) stage_slice<IMN::ND_SIZE>(nd_img, a.node.img_node, threadIdx.x);
   if (FUSE == 2) stage_slice<IMN::HD_SIZE>(nd_img + IMN::ND_SIZE, a.node.img_head, threadIdx.x);
@@ -464,13 +499,13 @@ __global__ __launch_bounds__(TPB) void conv_quad_kernel(ConvQArgs a) {
 
   const int i = lane & 15, g = lane >> 4;
   for (int32_t base = e0; base < e1; base += CTN * TILE) {
-    if (base != e0) conv_gather<NTE>(a, base, e1, lane, in);
+    if (base != e0) conv_gather<NTE, EMODE>(a, base, e1, lane, in);
     const int32_t (&dst)[CTN] = in.dst;
     const bool (&active)[CTN] = in.active;
     f4 m_s[CTN];
     float m_v[CTN][3];
     STAMP(3);
-    conv_tiles<NTE>(img, in, lane, m_s, m_v);
+    conv_tiles<NTE, EMODE>(img, in, lane, a.e_out, base, m_s, m_v);
     STAMP(6);
 #pragma unroll
     for (int j = 0; j < CTN; ++j) {
@@ -590,13 +625,19 @@ int node_embed(int nt_node, const float* img, const float* x_s, const float* x_v
   return 0;
 }
 
-template <int NTE, int FUSE>
-void conv_launch(const ConvQArgs& a, dim3 grid, hipStream_t st) {
+template <int NTE, int FUSE, int EMODE>
+void conv_launch_e(const ConvQArgs& a, dim3 grid, hipStream_t st) {
   const size_t lds = (size_t)(Image<0, NTE>::CV_SIZE + (FUSE == 0 ? 0 : Image<0, 0>::ND_SIZE + (FUSE == 2 ? Image<0, 0>::HD_SIZE : 0)) +
                               WPB * WAVE * ROW) * sizeof(float);
   if (lds > 64 * 1024)      // a failure here resurfaces as the launch error launch_status() reports
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_quad_kernel<NTE, FUSE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((conv_quad_kernel<NTE, FUSE>), grid, dim3(TPB), lds, st, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_quad_kernel<NTE, FUSE, EMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((conv_quad_kernel<NTE, FUSE, EMODE>), grid, dim3(TPB), lds, st, a);
+}
+template <int NTE, int FUSE>
+void conv_launch(const ConvQArgs& a, dim3 grid, hipStream_t st) {
+  if (a.e_in) conv_launch_e<NTE, FUSE, 2>(a, grid, st);
+  else if (a.e_out) conv_launch_e<NTE, FUSE, 1>(a, grid, st);
+  else conv_launch_e<NTE, FUSE, 0>(a, grid, st);
 }
 
 // fuse: 0 = conv only (dh required); 1 / 2 = the layer's node update (2: with the output head) in the same launch
@@ -604,14 +645,14 @@ int conv(int nt_edge, const float* img, const float* h, const float* e_s, const 
          const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
          const int32_t* edst, int64_t N, int64_t E, int mean, float* dh, int fuse, const float* img_node,
          const float* img_head, float* h_out, float* out, const float* mask0, const float* mask1, gvp::RngArgs rng,
-         hipStream_t st) {
+         const float* e_in, float* e_out, hipStream_t st) {
   // target nodes per wave: one pass of CTN lockstep 16-edge tiles (~30 edges) per wave
   int64_t deg = N > 0 ? (E + N - 1) / N : 1;
   if (deg < 1) deg = 1;
   int npw = (int)((CTN * TILE - 2) / deg);
   npw = npw < 1 ? 1 : (npw > WAVE ? WAVE : npw);
   ConvQArgs a{img, h, e_s, e_v, etypes, rowptr, eperm, esrc, edst, N, npw, mean, dh,
-              NodeQArgs{img_node, img_head, h, nullptr, N, h_out, out, mask0, mask1, rng}};
+              NodeQArgs{img_node, img_head, h, nullptr, N, h_out, out, mask0, mask1, rng}, e_in, e_out};
   const int64_t groups = (N + npw - 1) / npw;
   const dim3 grid((unsigned)((groups + WPB - 1) / WPB));
   if (nt_edge != 0 && nt_edge != 1) return CGVP_ERR_UNSUPPORTED_DIMS;

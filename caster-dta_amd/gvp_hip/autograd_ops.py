@@ -32,7 +32,7 @@ import torch
 from torch import Tensor
 
 from . import _lib, ops
-from .ops import ROW, _f32, _i64, _ptr, _stream
+from .ops import EROW, ROW, _f32, _i64, _ptr, _stream
 
 MROW = 20   # dropout mask row: 16 scalar-channel + 4 vector-channel factors
 # `cfg` argument of the LBA ops: the nine cgvp_dims fields, then these
@@ -95,10 +95,12 @@ def fragment_image(params, flat, layout, dims):
 @torch.library.custom_op("caster_gvp::lba_encoder", mutates_args=(), device_types="cuda")
 def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tensor, e_s: Tensor, e_v: Tensor,
                    etypes: Tensor, edge_index: Tensor, cfg: List[int], dropout_p: float,
-                   save_state: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+                   save_state: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
     """-> (out [N, out_s], state [2 L + 1, N, 28] = h_0..h_{L-1}, dh_0..dh_{L-1}, head input,
-           masks (empty unless the PINNED_MASKS test hook is set: [2 L, N, 20]), seed int64[2] (empty without dropout)).
-    save_state=False is the inference launch sequence (state / masks / seed come back empty)."""
+           masks (empty unless the PINNED_MASKS test hook is set: [2 L, N, 20]), seed int64[2] (empty without dropout),
+           e_emb [E, 36]: the edge embedding store in sorted-edge order (layer 0 writes it, later layers and the
+           backward read it)).
+    save_state=False is the inference launch sequence (state / masks / seed / e_emb come back empty)."""
     if ops.VARIANT != "mfma" and save_state:
         raise NotImplementedError("training / gradients need the MFMA kernels (CGVP_VARIANT=mfma)")
     L = _lib.lib()
@@ -116,7 +118,8 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
     if not save_state:
         out = ops.lba_encoder_forward(flat, layout, dims, nc, x_s, x_v, ntypes, e_s, e_v, etypes, csr,
                                       aggr_mean=mean, image=image)
-        return out, torch.empty(0, **f32), torch.empty(0, **f32), torch.empty(0, dtype=torch.int64, device=dev)
+        return (out, torch.empty(0, **f32), torch.empty(0, **f32), torch.empty(0, dtype=torch.int64, device=dev),
+                torch.empty(0, **f32))
     if tuple(x_s.shape) != (N, dims.node_in_s) or tuple(x_v.shape) != (N, dims.node_in_v, 3) or \
             tuple(e_s.shape) != (E, dims.edge_in_s) or tuple(e_v.shape) != (E, dims.edge_in_v, 3):
         raise NotImplementedError("feature shapes do not match the compiled CASTER-DTA configuration")
@@ -131,6 +134,7 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
     elif dropout_p > 0:
         seed = draw_seed(dev)
     out = torch.empty(N, dims.out_s, **f32)
+    e_emb = torch.empty(max(E, 1), EROW, **f32)
     with torch.cuda.device(dev):
         st = _stream()
         d, lay, P, I = C.byref(dims), C.byref(layout), _ptr(flat), _ptr(image)
@@ -139,24 +143,25 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
         for l in range(nc):
             last = l == nc - 1
             rng = ops.make_rng(seed, dropout_p, 2 * l)
+            e_in, e_out = _ptr(e_emb if l > 0 else None), _ptr(e_emb if l == 0 else None)
             if ops.fuse_layer(N, E):
                 with ops._timed("conv_fwd"):
                     _lib.check(L.cgvp_conv_layer_fwd(d, lay, I, l, _ptr(hs[l]), _ptr(e_s), _ptr(e_v), _ptr(et),
                                                      _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc),
                                                      _ptr(csr.edst), N, E, 1 if mean else 0,
                                                      _ptr(mk[l][0]), _ptr(mk[l][1]), ops._rng_ref(rng),
-                                                     1 if last else 0, _ptr(dhs[l]), _ptr(h_last if last else hs[l + 1]), _ptr(out),
+                                                     1 if last else 0, e_in, e_out, _ptr(dhs[l]), _ptr(h_last if last else hs[l + 1]), _ptr(out),
                                                      st), "cgvp_conv_layer_fwd")
                 continue
             with ops._timed("conv_fwd"):
                 _lib.check(L.cgvp_conv_fwd(d, lay, P, I, l, _ptr(hs[l]), _ptr(e_s), _ptr(e_v), _ptr(et),
                                            _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst),
-                                           N, E, 1 if mean else 0, _ptr(dhs[l]), st), "cgvp_conv_fwd")
+                                           N, E, 1 if mean else 0, e_in, e_out, _ptr(dhs[l]), st), "cgvp_conv_fwd")
             _lib.check(L.cgvp_node_update_fwd_train(d, lay, I, l, _ptr(hs[l]), _ptr(dhs[l]), _ptr(mk[l][0]),
                                                     _ptr(mk[l][1]), ops._rng_ref(rng), N, 1 if last else 0,
                                                     _ptr(h_last if last else hs[l + 1]), _ptr(out), st),
                        "cgvp_node_update_fwd_train")
-    return out, state, masks, seed
+    return out, state, masks, seed, e_emb
 
 
 @lba_encoder_op.register_fake
@@ -165,17 +170,18 @@ def _(params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, cfg, dropout_p, sa
     out = x_s.new_empty((N, cfg[8]), dtype=torch.float32)
     e32, e64 = x_s.new_empty((0,), dtype=torch.float32), x_s.new_empty((0,), dtype=torch.int64)
     if not save_state:
-        return out, e32, e32, e64
+        return out, e32, e32, e64, x_s.new_empty((0,), dtype=torch.float32)
     pinned = dropout_p > 0 and PINNED_MASKS is not None
     masks = x_s.new_empty((2 * nc, N, MROW), dtype=torch.float32) if pinned else e32
     seed = x_s.new_empty((2,), dtype=torch.int64) if dropout_p > 0 and not pinned else e64
-    return out, x_s.new_empty((2 * nc + 1, N, ROW), dtype=torch.float32), masks, seed
+    e_emb = x_s.new_empty((torch.sym_max(e_s.shape[0], 1), EROW), dtype=torch.float32)
+    return out, x_s.new_empty((2 * nc + 1, N, ROW), dtype=torch.float32), masks, seed, e_emb
 
 
 @torch.library.custom_op("caster_gvp::lba_encoder_backward", mutates_args=(), device_types="cuda")
 def lba_encoder_backward_op(g_out: Tensor, params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tensor,
                             e_s: Tensor, e_v: Tensor, etypes: Tensor, edge_index: Tensor, state: Tensor,
-                            masks: Tensor, seed: Tensor, cfg: List[int], dropout_p: float,
+                            masks: Tensor, seed: Tensor, e_emb: Tensor, cfg: List[int], dropout_p: float,
                             need_x: bool) -> Tuple[Tensor, Tensor, Tensor]:
     """-> (grad arena [layout.total], g_x_s [N, 17], g_x_v [N, 3, 3]) (the latter two empty unless need_x)."""
     L = _lib.lib()
@@ -197,8 +203,9 @@ def lba_encoder_backward_op(g_out: Tensor, params: List[Tensor], x_s: Tensor, x_
     # every stage writes its per-workgroup partial weight-gradient blocks into its own region of
     # one workspace; a single reduce launch at the end sums them all in a fixed order
     wsz = int(L.cgvp_bwd_workspace_floats(C.byref(dims), C.byref(layout)))
-    nstage = 2 * nc + 1
+    nstage = 2 * nc + 2
     ws_all = torch.empty(nstage * wsz, **f32)
+    g_e = torch.empty(nc, max(E, 1), EROW, **f32)         # d(edge embedding) of every conv layer, summed by the edge stage
     segs = (_lib.Segment * (2 * nstage))()
     nseg, stage = 0, 0
     cnt = C.c_int32(0)
@@ -234,9 +241,9 @@ def lba_encoder_backward_op(g_out: Tensor, params: List[Tensor], x_s: Tensor, x_
             take()
             g_dst = torch.empty(N, ROW, **f32)
             with ops._timed("conv_bwd"):
-                _lib.check(L.cgvp_conv_bwd(d, lay, I, l, _ptr(hs[l]), _ptr(e_s), _ptr(e_v), _ptr(et),
-                                           _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst), N, E,
-                                           1 if mean else 0, _ptr(g_dh), _ptr(g_src), 1, _ptr(g_dst),
+                _lib.check(L.cgvp_conv_bwd(d, lay, I, l, _ptr(hs[l]), _ptr(e_emb),
+                                           _ptr(csr.rowptr), _ptr(csr.esrc), _ptr(csr.edst), N, E,
+                                           1 if mean else 0, _ptr(g_dh), _ptr(g_src), 1, _ptr(g_dst), _ptr(g_e[l]),
                                            _ptr(gparams), _ptr(region()),
                                            C.byref(segs, nseg * C.sizeof(_lib.Segment)), C.byref(cnt), st),
                            "cgvp_conv_bwd")
@@ -247,12 +254,19 @@ def lba_encoder_backward_op(g_out: Tensor, params: List[Tensor], x_s: Tensor, x_
                                          C.byref(segs, nseg * C.sizeof(_lib.Segment)), C.byref(cnt), st),
                    "cgvp_node_embed_bwd")
         take()
+        if E > 0:
+            ge = (C.c_void_p * nc)(*[g_e[l].data_ptr() for l in range(nc)])
+            _lib.check(L.cgvp_edge_embed_bwd(d, lay, I, _ptr(e_s), _ptr(e_v), _ptr(et), _ptr(csr.eperm), E, ge, nc,
+                                             _ptr(gparams), _ptr(region()),
+                                             C.byref(segs, nseg * C.sizeof(_lib.Segment)), C.byref(cnt), st),
+                       "cgvp_edge_embed_bwd")
+            take()
         _lib.check(L.cgvp_bwd_reduce(segs, nseg, _ptr(gparams), st), "cgvp_bwd_reduce")
     return gparams, (g_x_s if need_x else torch.empty(0, **f32)), (g_x_v if need_x else torch.empty(0, **f32))
 
 
 @lba_encoder_backward_op.register_fake
-def _(g_out, params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, seed, cfg, dropout_p, need_x):
+def _(g_out, params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, seed, e_emb, cfg, dropout_p, need_x):
     total = sum(p.numel() for p in params)
     gp = x_s.new_empty((total,), dtype=torch.float32)
     if need_x:
@@ -262,12 +276,12 @@ def _(g_out, params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, mask
 
 def _lba_setup(ctx, inputs, output):
     params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, cfg, dropout_p, save_state = inputs
-    out, state, masks, seed = output
+    out, state, masks, seed, e_emb = output
     if not save_state:
         raise RuntimeError("caster_gvp::lba_encoder was run with save_state=False; gradients need save_state=True")
     ctx.cfg, ctx.dropout_p = cfg, dropout_p
     ctx.shapes = [tuple(p.shape) for p in params]
-    ctx.save_for_backward(x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, seed, *params)
+    ctx.save_for_backward(x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, seed, e_emb, *params)
 
 
 def _numel(shape):
@@ -277,11 +291,11 @@ def _numel(shape):
     return n
 
 
-def _lba_backward(ctx, g_out, g_state, g_masks, g_seed):
-    x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, seed, *params = ctx.saved_tensors
+def _lba_backward(ctx, g_out, g_state, g_masks, g_seed, g_e_emb):
+    x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, seed, e_emb, *params = ctx.saved_tensors
     need_x = bool(ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
     gflat, g_x_s, g_x_v = torch.ops.caster_gvp.lba_encoder_backward(
-        g_out.contiguous(), params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, seed, ctx.cfg,
+        g_out.contiguous(), params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, seed, e_emb, ctx.cfg,
         ctx.dropout_p, need_x)
     grads = [g.view(s) for g, s in zip(torch.split(gflat, [_numel(s) for s in ctx.shapes]), ctx.shapes)]
     return (grads, g_x_s if need_x else None, g_x_v if need_x else None, None, None, None, None, None, None, None,
@@ -302,7 +316,7 @@ def lba_encoder(model, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, train_dro
            model.hidden_channels[0], model.hidden_channels[1], model.edge_hidden_channels[0],
            model.edge_hidden_channels[1], model.out_channels[0], model.num_ntypes, model.num_etypes,
            model.num_convs, 1 if model.aggr == "mean" else 0]
-    out, _, _, _ = torch.ops.caster_gvp.lba_encoder(
+    out, _, _, _, _ = torch.ops.caster_gvp.lba_encoder(
         model._arena.params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, cfg,
         float(model.dropout_rate) if train_dropout else 0.0, save_state)
     return out

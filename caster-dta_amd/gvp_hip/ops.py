@@ -16,6 +16,7 @@ from ._lib import Dims, GineW, Layout, Rng
 CASTER_DIMS = dict(node_in_s=17, node_in_v=3, edge_in_s=32, edge_in_v=1, hidden_s=16, hidden_v=4,
                    edge_hidden_s=32, edge_hidden_v=1, out_s=64)
 ROW = 28  # merged node row: 16 scalars + 4x3 vector channels
+EROW = 36  # stored edge embedding row (CGVP_EDGE_ROW): 32 scalars + 1x3 vector + pad, sorted-edge order
 
 
 def _stream():
@@ -269,6 +270,8 @@ def lba_encoder_forward(params, layout, dims, num_convs, x_s, x_v, ntypes, e_s, 
     dev = x_s.device
     h = torch.empty(N, ROW, dtype=torch.float32, device=dev)
     h2 = torch.empty(N, ROW, dtype=torch.float32, device=dev)
+    # edge embedding store: layer 0 writes gvp_edge + LayerNorm of every edge (sorted order), later layers read it
+    e_emb = torch.empty(max(E, 1), EROW, dtype=torch.float32, device=dev) if (VARIANT == "mfma" and num_convs > 1) else None
     dh = torch.empty(N, ROW, dtype=torch.float32, device=dev)
     out = torch.empty(N, dims.out_s, dtype=torch.float32, device=dev)
     stages = {}
@@ -291,8 +294,9 @@ def lba_encoder_forward(params, layout, dims, num_convs, x_s, x_v, ntypes, e_s, 
                     _lib.check(L.cgvp_conv_layer_fwd(d, lay, I, layer, _ptr(h), _ptr(e_s), _ptr(e_v), _ptr(et),
                                                      _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc),
                                                      _ptr(csr.edst), N, E, 1 if aggr_mean else 0, C.c_void_p(0),
-                                                     C.c_void_p(0), None, 1 if last else 0, C.c_void_p(0),
-                                                     _ptr(None if last else h2), _ptr(out), st),
+                                                     C.c_void_p(0), None, 1 if last else 0,
+                                                     _ptr(e_emb if layer > 0 else None), _ptr(e_emb if layer == 0 else None),
+                                                     C.c_void_p(0), _ptr(None if last else h2), _ptr(out), st),
                                "cgvp_conv_layer_fwd")
                 if not last:
                     h, h2 = h2, h
@@ -300,7 +304,8 @@ def lba_encoder_forward(params, layout, dims, num_convs, x_s, x_v, ntypes, e_s, 
             with _timed("conv_fwd"):
                 _lib.check(L.cgvp_conv_fwd(d, lay, P, I, layer, _ptr(h), _ptr(e_s), _ptr(e_v), _ptr(et),
                                            _ptr(csr.rowptr), _ptr(csr.eperm), _ptr(csr.esrc), _ptr(csr.edst),
-                                           N, E, 1 if aggr_mean else 0, _ptr(dh), st), "cgvp_conv_fwd")
+                                           N, E, 1 if aggr_mean else 0, _ptr(e_emb if layer > 0 else None),
+                                           _ptr(e_emb if layer == 0 else None), _ptr(dh), st), "cgvp_conv_fwd")
             if return_stages:
                 stages[f"conv{layer}_dh"] = dh.clone()
             last = layer == num_convs - 1

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 16
+#define CGVP_ABI_VERSION 17
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
@@ -130,16 +130,23 @@ int cgvp_node_embed_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
 
 /* GVPConv.forward (gvp_layers.py:291-308) of conv layer `layer` for every edge
  * plus the reduction over target nodes (aggr 'sum'/'add' or 'mean'), with
- * gvp_edge (protein_gnn.py:376) fused in: the edge embedding is recomputed in
- * registers from the raw edge features and never written to HBM.
+ * gvp_edge (protein_gnn.py:376) fused in.
  * h [N][28]; e_s [E][32], e_v [E][1][3], etypes [E] in ORIGINAL edge order; CSR
  * tables from cgvp_csr_from_coo.  -> dh [N][28] (every row written, zero for
- * isolated nodes). */
+ * isolated nodes).
+ * EDGE EMBEDDING STORE (MFMA kernels; both optional).  gvp_edge + LayerNorm does not depend on the conv layer.
+ * With e_out != NULL the call also writes it, in SORTED-edge order (the CSR position p, not the original edge
+ * id): CGVP_EDGE_ROW floats per edge = [e_s 32 | e_v 3 | pad].  With e_in != NULL the call reads that store
+ * sequentially instead of gathering and re-embedding the raw features (e_s / e_v / etypes / eperm are then
+ * unused and may be NULL).  The host code lets layer 0 write it and every later layer -- and every conv
+ * backward -- read it: this is exactly SURVEY 8(d)'s byte model (embed writes 140 B/edge, each conv reads them). */
+#define CGVP_EDGE_ROW 36
 int cgvp_conv_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* params,
                   const float* image, int32_t layer, const float* h, const float* e_s,
                   const float* e_v, const int64_t* etypes, const int32_t* rowptr,
                   const int32_t* eperm, const int32_t* esrc, const int32_t* edst,
-                  int64_t num_nodes, int64_t num_edges, int32_t aggr_mean, float* dh, void* stream);
+                  int64_t num_nodes, int64_t num_edges, int32_t aggr_mean, const float* e_in,
+                  float* e_out, float* dh, void* stream);
 
 /* Rest of GVPConvLayer.forward in eval mode (gvp_layers.py:407-410):
  * h_out = LN1(y + FF(y)), y = LN0(h + dh).  When `with_head` != 0 also applies
@@ -185,8 +192,8 @@ int cgvp_conv_layer_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
                         const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,
                         const int32_t* esrc, const int32_t* edst, int64_t num_nodes,
                         int64_t num_edges, int32_t aggr_mean, const float* mask0,
-                        const float* mask1, const cgvp_rng* rng, int32_t with_head, float* dh,
-                        float* h_out, float* out, void* stream);
+                        const float* mask1, const cgvp_rng* rng, int32_t with_head, const float* e_in,
+                        float* e_out, float* dh, float* h_out, float* out, void* stream);
 
 /* Training-mode variant of cgvp_node_update_fwd (MFMA kernels only): `mask0` /
  * `mask1` are the dropout masks of gvp_layers.Dropout (gvp_layers.py:187-219) for
@@ -245,19 +252,27 @@ int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const
                          float* zero_out, float* grad_params, float* workspace, cgvp_segment* segs,
                          int32_t* nsegs, void* stream);
 
-/* d/d(h, weights) of cgvp_conv_fwd given g_dh = d(loss)/d(dh).  Gradients w.r.t.
- * the node rows arrive in two buffers that the consumer sums: g_src [N][28]
- * (scatter over the unsorted sources; float atomics; zeroed by this call unless
- * g_src_zeroed != 0) and
- * g_dst [N][28] (segmented sums over the sorted targets; every row written).
- * Raw edge features receive no gradient. */
+/* d/d(h, edge embedding, message weights) of cgvp_conv_fwd given g_dh = d(loss)/d(dh).  `e_emb` is the edge
+ * embedding store the forward wrote ([E][CGVP_EDGE_ROW], sorted-edge order).  Gradients w.r.t. the node rows
+ * arrive in two buffers that the consumer sums: g_src [N][28] (scatter over the unsorted sources; float atomics;
+ * zeroed by this call unless g_src_zeroed != 0) and g_dst [N][28] (segmented sums over the sorted targets; every
+ * row written).  g_e [E][CGVP_EDGE_ROW] receives this layer's d(edge embedding) (plain stores, every row); the
+ * gradients of gvp_edge's own weights come from ONE cgvp_edge_embed_bwd over all layers' g_e. */
 int cgvp_conv_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image, int32_t layer,
-                  const float* h, const float* e_s, const float* e_v, const int64_t* etypes,
-                  const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
+                  const float* h, const float* e_emb, const int32_t* rowptr, const int32_t* esrc,
                   const int32_t* edst, int64_t num_nodes, int64_t num_edges, int32_t aggr_mean,
-                  const float* g_dh, float* g_src, int32_t g_src_zeroed, float* g_dst,
+                  const float* g_dh, float* g_src, int32_t g_src_zeroed, float* g_dst, float* g_e,
                   float* grad_params, float* workspace, cgvp_segment* segs, int32_t* nsegs,
                   void* stream);
+
+/* Backward of gvp_edge = Sequential(GVP, LayerNorm) (protein_gnn.py:331-335, :376), once per step: the upstream
+ * gradient of edge p is the SUM over g_e[0 .. num_g) of row p (the buffers the conv backward calls wrote).  Raw
+ * edge features receive no gradient; only gvp_edge.0 / gvp_edge.1 weight gradients are produced (ADDED into
+ * grad_params, or described in `segs` for the deferred reduction).  `g_e` is a HOST array of device pointers. */
+int cgvp_edge_embed_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image,
+                        const float* e_s, const float* e_v, const int64_t* etypes, const int32_t* eperm,
+                        int64_t num_edges, const float* const* g_e, int32_t num_g, float* grad_params,
+                        float* workspace, cgvp_segment* segs, int32_t* nsegs, void* stream);
 
 /* d/d(x_s, x_v, weights) of cgvp_node_embed_fwd; upstream = sum of g_up0..2.
  * g_x_s [N][17] / g_x_v [N][3][3] may both be NULL (inputs without gradient). */
