@@ -22,7 +22,7 @@ namespace quad {
 int offsets(int nt_node, int nt_edge, int num_convs, QuadOffsets* o);
 int prepare(const gvp::EncLayout& L, int num_convs, const float* params, float* image, hipStream_t st);
 int node_embed(int nt_node, const float* img, const float* x_s, const float* x_v, const int64_t* ntypes,
-               int64_t N, float* h, hipStream_t st);
+               int64_t N, float* h, unsigned long long* rng_state, unsigned long long* rng_out, hipStream_t st);
 int conv(int nt_edge, const float* img, const float* h, const float* e_s, const float* e_v,
          const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
          const int32_t* edst, int64_t N, int64_t E, int mean, float* dh, int fuse, const float* img_node,
@@ -66,6 +66,6 @@ int gine_fwd(int cin, int chid, int cout, int nt, int net, int ed, const float* 
              const int32_t* esrc, const int32_t* edst, int64_t N, const cgvp_gine_w* w, float slope,
              const float* mask, gvp::RngArgs rng, float* out, hipStream_t st);
 int reduce_slab(const float* slab, int rows, int stride, int col0, int len, float* dst, hipStream_t st);
-int reduce_segments(const cgvp_segment* segs, int nsegs, float* grad_params, hipStream_t st);
+int reduce_segments(const cgvp_segment* segs, int nsegs, float* grad_params, hipStream_t st, int overwrite = 0);
 int bwd_block_sizes(int nt_node, int nt_edge, int* emb, int* conv_edge, int* conv_total, int* node, int* head);
 }  // namespace quad

@@ -522,6 +522,13 @@ static gvp::RngArgs rng_args(const cgvp_rng* rng, int base) {
   return gvp::RngArgs{reinterpret_cast<const unsigned long long*>(rng->seed), rng->p, rng->stream};
 }
 
+__global__ void rng_next_kernel(unsigned long long* state, unsigned long long* out) {
+  const unsigned long long off = state[1] + 1;
+  state[1] = off;
+  out[0] = state[0];
+  out[1] = off;
+}
+
 struct MaskArgs { gvp::RngArgs rng; int num_masks; int64_t N; int width; float* out; };
 __global__ __launch_bounds__(256) void dropout_masks_kernel(MaskArgs a) {
   const int64_t per = a.N * (a.width / 4), total = per * a.num_masks;
@@ -529,10 +536,19 @@ __global__ __launch_bounds__(256) void dropout_masks_kernel(MaskArgs a) {
     const int m = (int)(t / per);
     const int64_t r = t - (int64_t)m * per, n = r / (a.width / 4);
     const int blk = (int)(r - n * (a.width / 4));
-    float f[4];
-    gvp::dropout4(a.rng.seed[0], a.rng.seed[1], a.rng.stream + m, n, blk, a.rng.p, f);
-    float* o = a.out + ((int64_t)m * a.N + n) * a.width + 4 * blk;
-    o[0] = f[0]; o[1] = f[1]; o[2] = f[2]; o[3] = f[3];
+    float* row = a.out + ((int64_t)m * a.N + n) * a.width;
+    if (a.width == 20) {                 // protein row: quarter g = blk of [16 scalar | 4 vector-channel] (blk 4 is covered by 0..3)
+      if (blk < 4) {
+        float fs[4], fv;
+        gvp::dropout_row20(a.rng.seed[0], a.rng.seed[1], a.rng.stream + m, n, blk, a.rng.p, fs, fv);
+        row[4 * blk] = fs[0]; row[4 * blk + 1] = fs[1]; row[4 * blk + 2] = fs[2]; row[4 * blk + 3] = fs[3];
+        row[16 + blk] = fv;
+      }
+    } else {
+      float f[4];
+      gvp::dropout4(a.rng.seed[0], a.rng.seed[1], a.rng.stream + m, n, blk, a.rng.p, f);
+      row[4 * blk] = f[0]; row[4 * blk + 1] = f[1]; row[4 * blk + 2] = f[2]; row[4 * blk + 3] = f[3];
+    }
   }
 }
 
@@ -601,16 +617,20 @@ int cgvp_lba_prepare(const cgvp_dims* dims, const cgvp_layout* layout, const flo
 
 int cgvp_node_embed_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* params,
                         const float* image, const float* x_s, const float* x_v, const int64_t* ntypes,
-                        int64_t N, float* h, void* stream) {
+                        int64_t N, float* h, uint64_t* rng_state, uint64_t* rng_out, void* stream) {
   if (int rc = check_dims(dims)) return rc;
   if (N < 0 || !layout || !params || (layout->nt_node > 0 && N > 0 && !ntypes)) return CGVP_ERR_BAD_ARG;
-  if (N == 0) return 0;
+  if ((rng_state != nullptr) != (rng_out != nullptr) || (rng_state && !image)) return CGVP_ERR_BAD_ARG;
+  if (((uintptr_t)rng_state & 7) || ((uintptr_t)rng_out & 7)) return CGVP_ERR_BAD_ARG;
+  if (N == 0) return rng_state ? cgvp_rng_next(rng_state, rng_out, stream) : 0;
   if (!x_s || !x_v || !h) return CGVP_ERR_BAD_ARG;
   if (image) {
     if ((uintptr_t)h & 15) return CGVP_ERR_BAD_ARG;
     QuadOffsets o;
     if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
-    if (int rc = quad::node_embed(layout->nt_node, image + o.emb, x_s, x_v, ntypes, N, h, (hipStream_t)stream)) return rc;
+    if (int rc = quad::node_embed(layout->nt_node, image + o.emb, x_s, x_v, ntypes, N, h,
+                                  reinterpret_cast<unsigned long long*>(rng_state),
+                                  reinterpret_cast<unsigned long long*>(rng_out), (hipStream_t)stream)) return rc;
     return launch_status();
   }
   NodeEmbedArgs a{params, cvt(*layout), x_s, x_v, ntypes, N, h};
@@ -895,6 +915,13 @@ int cgvp_gine_conv_fwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
   return launch_status();
 }
 
+int cgvp_rng_next(uint64_t* state, uint64_t* out, void* stream) {
+  if (!state || !out || ((uintptr_t)state & 7) || ((uintptr_t)out & 7)) return CGVP_ERR_BAD_ARG;
+  hipLaunchKernelGGL(rng_next_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream,
+                     reinterpret_cast<unsigned long long*>(state), reinterpret_cast<unsigned long long*>(out));
+  return launch_status();
+}
+
 int cgvp_dropout_masks(const cgvp_rng* rng, int32_t num_masks, int64_t N, int32_t width, float* out, void* stream) {
   if (!rng || !rng->seed || !out || num_masks < 1 || N < 0 || width < 4 || (width & 3)) return CGVP_ERR_BAD_ARG;
   if (int rc = check_rng(rng)) return rc;
@@ -906,9 +933,9 @@ int cgvp_dropout_masks(const cgvp_rng* rng, int32_t num_masks, int64_t N, int32_
   return launch_status();
 }
 
-int cgvp_bwd_reduce(const cgvp_segment* segs, int32_t nsegs, float* grad_params, void* stream) {
+int cgvp_bwd_reduce(const cgvp_segment* segs, int32_t nsegs, float* grad_params, int32_t overwrite, void* stream) {
   if (!segs || nsegs < 0 || nsegs > CGVP_MAX_SEGS || !grad_params) return CGVP_ERR_BAD_ARG;
-  quad::reduce_segments(segs, nsegs, grad_params, (hipStream_t)stream);
+  quad::reduce_segments(segs, nsegs, grad_params, (hipStream_t)stream, overwrite ? 1 : 0);
   return launch_status();
 }
 

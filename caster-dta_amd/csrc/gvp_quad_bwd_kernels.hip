@@ -135,11 +135,9 @@ __device__ __forceinline__ void node_dropout(const float* mask, const gvp::RngAr
     mv = mask[n * MROW + NS + g];
   } else if (rng.seed) {
     const unsigned long long seed = rng.seed[0], off = rng.seed[1];
-    float fs[4], fv[4];
-    gvp::dropout4(seed, off, rng.stream + which, n, g, rng.p, fs);
-    gvp::dropout4(seed, off, rng.stream + which, n, NS / 4, rng.p, fv);
+    float fs[4];
+    gvp::dropout_row20(seed, off, rng.stream + which, n, g, rng.p, fs, mv);
     ms = f4{fs[0], fs[1], fs[2], fs[3]};
-    mv = g == 0 ? fv[0] : g == 1 ? fv[1] : g == 2 ? fv[2] : fv[3];
   }
 }
 struct NodeBArgs {
@@ -818,7 +816,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
 }
 
 struct SegTable { cgvp_segment s[CGVP_MAX_SEGS]; };
-__global__ __launch_bounds__(RED_COLS * RED_RG) void reduce_segments_kernel(SegTable t, float* __restrict__ grad) {
+__global__ __launch_bounds__(RED_COLS * RED_RG) void reduce_segments_kernel(SegTable t, float* __restrict__ grad, int overwrite) {
   __shared__ float part[RED_RG][RED_COLS];
   const cgvp_segment sg = t.s[blockIdx.y];
   const int c = threadIdx.x & (RED_COLS - 1), rg = threadIdx.x / RED_COLS;
@@ -833,7 +831,8 @@ __global__ __launch_bounds__(RED_COLS * RED_RG) void reduce_segments_kernel(SegT
     float tt = 0.f;
 #pragma unroll
     for (int k = 0; k < RED_RG; ++k) tt += part[k][c];
-    atomicAdd(grad + sg.dst + j, tt);    // segments of different layers may share a destination (gvp_edge)
+    if (overwrite) grad[sg.dst + j] = tt;     // the caller guarantees disjoint destinations that cover what it reads
+    else atomicAdd(grad + sg.dst + j, tt);    // ADD semantics of the per-call reductions
   }
 }
 
@@ -856,13 +855,13 @@ int bwd_block_sizes(int nt_node, int nt_edge, int* emb, int* conv_edge, int* con
   return 0;
 }
 
-int reduce_segments(const cgvp_segment* segs, int nsegs, float* grad_params, hipStream_t st) {
+int reduce_segments(const cgvp_segment* segs, int nsegs, float* grad_params, hipStream_t st, int overwrite) {
   if (nsegs <= 0) return 0;
   SegTable t;
   int maxlen = 0;
   for (int i = 0; i < nsegs; ++i) { t.s[i] = segs[i]; maxlen = segs[i].len > maxlen ? segs[i].len : maxlen; }
   hipLaunchKernelGGL(reduce_segments_kernel, dim3((maxlen + RED_COLS - 1) / RED_COLS, nsegs), dim3(RED_COLS * RED_RG), 0,
-                     st, t, grad_params);
+                     st, t, grad_params, overwrite);
   return 0;
 }
 

@@ -115,6 +115,9 @@ __global__ void lba_prepare_kernel(const float* __restrict__ P, EncLayout L, int
 // ------------------------------------------------------------------ embed
 struct EmbedQArgs {
   const float* img; const float* x_s; const float* x_v; const int64_t* ntypes; int64_t N; float* h;
+  // dropout generator hand-off (optional): the FIRST kernel of an encoder pass advances the persistent {seed, offset}
+  // and leaves this pass's pair in rng_out, which the later kernels of the pass (and its backward) read
+  unsigned long long* rng_state; unsigned long long* rng_out;
 };
 
 template <int NTN>
@@ -123,6 +126,12 @@ __global__ __launch_bounds__(TPB) void embed_quad_kernel(EmbedQArgs a) {
   typedef QNode<NTN> Q;
   __shared__ __attribute__((aligned(16))) float lds[IM::EMB_SIZE];
   stage_slice<IM::EMB_SIZE>(lds, a.img, threadIdx.x);
+  if (a.rng_state && blockIdx.x == 0 && threadIdx.x == 0) {
+    const unsigned long long off = a.rng_state[1] + 1;
+    a.rng_state[1] = off;
+    a.rng_out[0] = a.rng_state[0];
+    a.rng_out[1] = off;
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
@@ -175,11 +184,9 @@ __device__ __forceinline__ void node_dropout(const float* mask, const gvp::RngAr
     mv = mask[n * MROW + NS + g];
   } else if (rng.seed) {
     const unsigned long long seed = rng.seed[0], off = rng.seed[1];
-    float fs[4], fv[4];
-    gvp::dropout4(seed, off, rng.stream + which, n, g, rng.p, fs);
-    gvp::dropout4(seed, off, rng.stream + which, n, NS / 4, rng.p, fv);
+    float fs[4];
+    gvp::dropout_row20(seed, off, rng.stream + which, n, g, rng.p, fs, mv);
     ms = f4{fs[0], fs[1], fs[2], fs[3]};
-    mv = g == 0 ? fv[0] : g == 1 ? fv[1] : g == 2 ? fv[2] : fv[3];
   }
 }
 
@@ -613,8 +620,8 @@ int prepare(const EncLayout& L, int num_convs, const float* params, float* image
 }
 
 int node_embed(int nt_node, const float* img, const float* x_s, const float* x_v, const int64_t* ntypes,
-               int64_t N, float* h, hipStream_t st) {
-  EmbedQArgs a{img, x_s, x_v, ntypes, N, h};
+               int64_t N, float* h, unsigned long long* rng_state, unsigned long long* rng_out, hipStream_t st) {
+  EmbedQArgs a{img, x_s, x_v, ntypes, N, h, rng_state, rng_out};
   const dim3 grid((unsigned)((N + WPB * TILE - 1) / (WPB * TILE)));
   switch (nt_node) {
     case 0: hipLaunchKernelGGL(embed_quad_kernel<0>, grid, dim3(TPB), 0, st, a); break;

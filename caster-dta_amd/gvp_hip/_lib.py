@@ -15,11 +15,11 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CGVP_LIB_PATH: A/B builds of the same ABI (diagnostics); the default is the in-tree library
 LIB_PATH = os.environ.get("CGVP_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libcaster_gvp.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 # sha256 of include/caster_gvp.h with comments, blank space and the CGVP_ABI_VERSION line removed, as
 # `abi_header_digest()` computes it.  tests/test_abi.py fails when the header's declarations change
 # without CGVP_ABI_VERSION, ABI_VERSION and this digest being updated together.
-ABI_HEADER_SHA256 = "5b19f181c2b961dac8edab0a7146c614bdcbda6aaab57641fd39b6e15a44c059"
+ABI_HEADER_SHA256 = "c41d39f5bcb062b31c7e63ca5121070fcc4a9744d07cbc2b16547144e6593d81"
 
 
 class HipLibraryError(RuntimeError):
@@ -72,7 +72,8 @@ _SIGNATURES = {
     "cgvp_lba_layout": (C.c_int, [C.POINTER(Dims), _I32, _I32, _I32, C.POINTER(Layout)]),
     "cgvp_lba_image_floats": (C.c_int64, [C.POINTER(Dims), C.POINTER(Layout)]),
     "cgvp_lba_prepare": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _P]),
-    "cgvp_node_embed_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _P, _P, _P, _I64, _P, _P]),
+    "cgvp_node_embed_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "cgvp_rng_next": (C.c_int, [_P, _P, _P]),
     "cgvp_conv_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P,
                                 _P, _I64, _I64, _I32, _P, _P, _P, _P]),
     "cgvp_node_update_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _I32, _P, _P, _I64, _I32,
@@ -91,7 +92,7 @@ _SIGNATURES = {
                                       _P, _P, _P, _P, _P]),
     "cgvp_node_embed_bwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P,
                                       _P, _P, _P, _P, _P]),
-    "cgvp_bwd_reduce": (C.c_int, [_P, _I32, _P, _P]),
+    "cgvp_bwd_reduce": (C.c_int, [_P, _I32, _P, _I32, _P]),
     "cgvp_gine_conv_fwd": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32,
                                      _I32, C.POINTER(GineW), C.c_float, _P, C.POINTER(Rng), _I32, _P, _P]),
     "cgvp_attn_fwd": (C.c_int, [C.POINTER(AttnProblem), _I32, _I64, _I32, C.c_float, _P]),

@@ -48,8 +48,37 @@ PINNED_MASKS = None
 
 
 def draw_seed(device):
-    """{seed, offset} for the in-kernel generator: int64[2] on the device, from torch's CUDA generator."""
+    """A fresh {seed, offset} pair: int64[2] on the device, from torch's CUDA generator."""
     return torch.randint(0, 1 << 62, (2,), dtype=torch.int64, device=device)
+
+
+# Persistent generator state per (kind of encoder, device): {seed, offset} on the device.  It is drawn from torch's CUDA
+# generator the first time it is needed -- and again whenever `torch.manual_seed` / `torch.cuda.manual_seed` has
+# changed the generator's seed since -- and from then on every training pass advances `offset` ON THE DEVICE (inside
+# the pass's first kernel for the protein encoder, by a 1-thread launch for the drug encoder), leaving the pass's own
+# pair in a small output tensor that its later kernels and its backward read.  No torch RNG launch per step, and a
+# HIP-graph replay advances the state like an eager step does.
+_RNG_STATE = {}
+_LAST_SEED = {}
+
+
+def rng_state(kind, device):
+    key = (kind, device.index)
+    gen_seed = torch.cuda.default_generators[device.index].initial_seed()
+    hit = _RNG_STATE.get(key)
+    if hit is None or hit[0] != gen_seed:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the dropout generator state must exist before HIP-graph capture: run one training "
+                               "step eagerly first (any warm-up does)")
+        hit = (gen_seed, draw_seed(device))
+        _RNG_STATE[key] = hit
+    return hit[1]
+
+
+def last_seed(kind):
+    """The {seed, offset} pair of the latest training pass of `kind` ('lba' / 'gine') -- tests export the factors
+    the kernels used from it (ops.dropout_masks)."""
+    return _LAST_SEED[kind]
 
 
 def make_cfg(dims, num_ntypes, num_etypes, num_convs, aggr_mean):
@@ -132,13 +161,16 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
         masks = PINNED_MASKS(2 * nc, N, MROW, dropout_p, dev)
         mk = [(masks[2 * l], masks[2 * l + 1]) for l in range(nc)]
     elif dropout_p > 0:
-        seed = draw_seed(dev)
+        seed = torch.empty(2, dtype=torch.int64, device=dev)      # filled by the node-embed kernel (below)
+        _LAST_SEED["lba"] = seed
+    rstate = rng_state("lba", dev) if seed.numel() else None
     out = torch.empty(N, dims.out_s, **f32)
     e_emb = torch.empty(max(E, 1), EROW, **f32)
     with torch.cuda.device(dev):
         st = _stream()
         d, lay, P, I = C.byref(dims), C.byref(layout), _ptr(flat), _ptr(image)
-        _lib.check(L.cgvp_node_embed_fwd(d, lay, P, I, _ptr(x_s), _ptr(x_v), _ptr(nt), N, _ptr(hs[0]), st),
+        _lib.check(L.cgvp_node_embed_fwd(d, lay, P, I, _ptr(x_s), _ptr(x_v), _ptr(nt), N, _ptr(hs[0]),
+                                         _ptr(rstate), _ptr(seed if rstate is not None else None), st),
                    "cgvp_node_embed_fwd")
         for l in range(nc):
             last = l == nc - 1
@@ -199,7 +231,7 @@ def lba_encoder_backward_op(g_out: Tensor, params: List[Tensor], x_s: Tensor, x_
     mk = [(masks[2 * l], masks[2 * l + 1]) for l in range(nc)] if masks.numel() else [(None, None)] * nc
     g_out = _f32(g_out, "grad_output")
     f32 = dict(dtype=torch.float32, device=dev)
-    gparams = torch.zeros(layout.total, **f32)
+    gparams = torch.empty(layout.total, **f32)        # every element is STORED by the final reduce (disjoint segments)
     # every stage writes its per-workgroup partial weight-gradient blocks into its own region of
     # one workspace; a single reduce launch at the end sums them all in a fixed order
     wsz = int(L.cgvp_bwd_workspace_floats(C.byref(dims), C.byref(layout)))
@@ -261,7 +293,9 @@ def lba_encoder_backward_op(g_out: Tensor, params: List[Tensor], x_s: Tensor, x_
                                              C.byref(segs, nseg * C.sizeof(_lib.Segment)), C.byref(cnt), st),
                        "cgvp_edge_embed_bwd")
             take()
-        _lib.check(L.cgvp_bwd_reduce(segs, nseg, _ptr(gparams), st), "cgvp_bwd_reduce")
+        if E == 0:                                    # no edge stage: gvp_edge's gradient block is not covered by a segment
+            gparams[layout.edge_gvp:layout.conv0].zero_()
+        _lib.check(L.cgvp_bwd_reduce(segs, nseg, _ptr(gparams), 1, st), "cgvp_bwd_reduce")
     return gparams, (g_x_s if need_x else torch.empty(0, **f32)), (g_x_v if need_x else torch.empty(0, **f32))
 
 
@@ -340,7 +374,10 @@ def gine_encoder_op(params: List[Tensor], x: Tensor, ntypes: Tensor, eattr: Tens
     hs, masks = [x], []
     seed = x.new_empty(0, dtype=torch.int64)
     if dropout_p > 0 and nl > 1 and PINNED_MASKS is None:
-        seed = draw_seed(x.device)
+        seed = torch.empty(2, dtype=torch.int64, device=x.device)
+        _LAST_SEED["gine"] = seed
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().cgvp_rng_next(_ptr(rng_state("gine", x.device)), _ptr(seed), _stream()), "cgvp_rng_next")
     for l in range(nl):
         mask, rng = None, None
         if dropout_p > 0 and l < nl - 1:

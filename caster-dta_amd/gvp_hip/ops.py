@@ -282,7 +282,7 @@ def lba_encoder_forward(params, layout, dims, num_convs, x_s, x_v, ntypes, e_s, 
     with torch.cuda.device(dev):
         st = _stream()
         d, lay, P, I = C.byref(dims), C.byref(layout), _ptr(params), _ptr(image)
-        _lib.check(L.cgvp_node_embed_fwd(d, lay, P, I, _ptr(x_s), _ptr(x_v), _ptr(nt), N, _ptr(h), st),
+        _lib.check(L.cgvp_node_embed_fwd(d, lay, P, I, _ptr(x_s), _ptr(x_v), _ptr(nt), N, _ptr(h), None, None, st),
                    "cgvp_node_embed_fwd")
         if return_stages:
             stages["node_embed"] = h.clone()

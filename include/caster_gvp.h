@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 17
+#define CGVP_ABI_VERSION 18
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
@@ -124,9 +124,12 @@ int cgvp_lba_prepare(const cgvp_dims* dims, const cgvp_layout* layout, const flo
 
 /* gvp_node = Sequential(GVP, LayerNorm) on one-hot(ntypes) ++ x_s, x_v
  * (protein_gnn.py:368-375).  x_s [N][17], x_v [N][3][3], ntypes [N] -> h [N][28]. */
+/* rng_state / rng_out (both or neither; MFMA kernels): as the FIRST kernel of an encoder pass this call can advance the
+ * persistent dropout generator without a launch of its own -- see cgvp_rng_next. */
 int cgvp_node_embed_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* params,
                         const float* image, const float* x_s, const float* x_v,
-                        const int64_t* ntypes, int64_t num_nodes, float* h, void* stream);
+                        const int64_t* ntypes, int64_t num_nodes, float* h, uint64_t* rng_state,
+                        uint64_t* rng_out, void* stream);
 
 /* GVPConv.forward (gvp_layers.py:291-308) of conv layer `layer` for every edge
  * plus the reduction over target nodes (aggr 'sum'/'add' or 'mean'), with
@@ -171,6 +174,12 @@ typedef struct {
   float p;                /* drop probability, 0 <= p < 1                */
   int32_t stream;         /* id of the first mask this call draws        */
 } cgvp_rng;
+
+/* Advance a persistent generator state: state = {seed, offset} (device, 2 x uint64) gets offset + 1 and the new pair
+ * is copied to `out` (device, 2 x uint64), which is what this pass's cgvp_rng.seed points at -- so a forward, its
+ * backward and a HIP-graph replay of both agree on the factors while successive passes differ.  One 1-thread launch;
+ * cgvp_node_embed_fwd does the same inside its own launch. */
+int cgvp_rng_next(uint64_t* state, uint64_t* out, void* stream);
 
 /* The factors the kernels would apply, written out for inspection (statistics tests; checking a training
  * step against the CPU oracle run with the same masks): out [num_masks][N][width], mask m of the call =
@@ -233,7 +242,9 @@ typedef struct {
 } cgvp_segment;
 #define CGVP_MAX_SEGS_PER_CALL 2
 #define CGVP_MAX_SEGS 32
-int cgvp_bwd_reduce(const cgvp_segment* segs, int32_t nsegs, float* grad_params, void* stream);
+/* overwrite != 0: STORE the sums instead of adding them (for segment lists whose destinations are disjoint and cover
+ * every element the caller reads: grad_params then needs no zero-fill launch). */
+int cgvp_bwd_reduce(const cgvp_segment* segs, int32_t nsegs, float* grad_params, int32_t overwrite, void* stream);
 
 /* d/d(h, dh, weights) of cgvp_node_update_fwd[_train].  Upstream gradient: with
  * the head, g_out [N][64] together with h_out [N][28], the h_out the forward call

@@ -178,10 +178,8 @@ def test_training_step_with_in_kernel_dropout_matches_oracle(protein_params, mol
     # ---- protein
     model = _encoder(protein_params).train()
     dd = _to(pd)
-    torch.manual_seed(123)
     out = model(dd["x"], dd["edge_index"], dd["ntypes"], dd["etypes"], eattr=dd["eattr"])
-    torch.manual_seed(123)
-    seed = autograd_ops.draw_seed(DEV)                     # the same draw the op made
+    seed = autograd_ops.last_seed("lba")                   # {seed, offset} of this pass, written by its first kernel
     masks = ops.dropout_masks(seed, 0.2, 0, 4, pb.num_nodes, 20).cpu()
     r = torch.randn(out.shape, generator=torch.Generator().manual_seed(4))
     (out * r.to(DEV)).sum().backward()
@@ -200,10 +198,8 @@ def test_training_step_with_in_kernel_dropout_matches_oracle(protein_params, mol
     mol = mol.to(DEV).train()
     dm = _to(md)
     gx = dm["x"].clone().requires_grad_()
-    torch.manual_seed(321)
     mout = mol(gx, dm["edge_index"], dm["ntypes"], dm["etypes"], eattr=dm["eattr"])
-    torch.manual_seed(321)
-    mseed = autograd_ops.draw_seed(DEV)
+    mseed = autograd_ops.last_seed("gine")
     mmask = ops.dropout_masks(mseed, 0.2, 0, 1, mb.num_nodes, 16).cpu()
     Q = {k: v.clone().requires_grad_(True) for k, v in molecule_params.items()}
     xr = md["x"].clone().requires_grad_()
