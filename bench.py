@@ -33,14 +33,20 @@ WORKLOADS = {
     "kiba_b32": dict(pairs=32, lengths="kiba", thresh=4.0, thresh_type="dist"),
     # configs[3]: 1000-residue proteins, 20 edges/residue (kNN 20), replicated x64 to fill the device
     "long_graph_x64": dict(pairs=64, length=1000, thresh=20, thresh_type="num"),
+    # configs[4], one rank's share: BindingDB-scale synthetic (32 pairs, mean ~558 residues), CASTER-DTA(4,4) = four
+    # conv layers in both encoders (seeded random weights: no (4,4) checkpoint ships); meant for --dtype bf16
+    "bindingdb_b32_44": dict(pairs=32, lengths="bindingdb", thresh=4.0, thresh_type="dist", convs=4),
 }
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32: 64 FLOP/clk/SIMD = the fp32 vector rate
 # Matrix-core work of the conv kernels per 16-edge tile (MFMA issues of 16x16x4 = 2,048 FLOP
 # each) and the algorithmic MACs per edge behind them (edge embed 1,126 + message 2,543 = 3,669;
 # the backward recomputes the forward and back-propagates data and weights: 3x).
-MFMA_PER_TILE = {"conv_fwd": 103, "conv_bwd": 319}
-MAC_PER_EDGE = {"conv_fwd": 3669, "conv_bwd": 3 * 3669}
+# Counted in the gfx950 ISA of the kernels (v_mfma in one tile body): conv backward 230 since the edge embedding moved to
+# its own once-per-step kernel (319 in round 1); forward 103 in the layer that derives the edge embedding, 71 in layers
+# that read the store.  Useful MACs per edge of the conv backward: 3 x the message GVPs' 2,543.
+MFMA_PER_TILE = {"conv_fwd": 103, "conv_bwd": 230}
+MAC_PER_EDGE = {"conv_fwd": 3669, "conv_bwd": 3 * 2543}
 
 
 def parse():
@@ -67,6 +73,9 @@ def parse():
                     help="diagnostic: 'main' runs the drug encoder on the protein stream (no overlap)")
     ap.add_argument("--only", default=None, choices=["protein", "drug"],
                     help="diagnostic: time one encoder alone (the reported metric needs both; never the default)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="activation storage of the protein encoder (bf16 = BASELINE config 5: bf16 storage / fp32 "
+                         "accumulate; gradients and weights stay fp32; the drug encoder stays fp32 storage)")
     ap.add_argument("--cpu-runs", type=int, default=20, help="timed CPU-baseline runs per thread count (median)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (0 = choose for ~10-30 s)")
     return ap.parse_args()
@@ -133,7 +142,8 @@ def main():
     wl = WORKLOADS[args.workload]
     train = args.mode == "fwdbwd"
     dropout_on = train and not args.eval_mode
-    model, state = entry._load_model(dev)
+    convs = wl.get("convs", 2)
+    model, state = entry._load_model(dev, num_convs=convs)
     model.train(dropout_on)
     lengths = ds.real_lengths(wl["lengths"], wl["pairs"], seed=1000 + rank) if "lengths" in wl else None
     pb, mb = ds.pair_batch(wl["pairs"], seed=rank, length=wl.get("length", 300), thresh=wl["thresh"],
@@ -141,6 +151,8 @@ def main():
     to = lambda d: {k: (tuple(t.to(dev) for t in v) if isinstance(v, tuple) else v.to(dev)) for k, v in d.items()}
     pdata_cpu, mdata_cpu = ds.to_torch(pb), ds.to_torch(mb)
     pdata, mdata = to(pdata_cpu), to(mdata_cpu)
+    if args.dtype == "bf16":                      # features held in HBM as bf16 (a dataset stored that way)
+        pdata = dict(pdata, x=tuple(t.bfloat16() for t in pdata["x"]), eattr=tuple(t.bfloat16() for t in pdata["eattr"]))
     # joint scope: graph offsets as PyG Batch objects carry them (the head then has no data-dependent shape)
     jp = dict(pdata, ptr=torch.as_tensor(pb.ptr).to(dev))
     jm = dict(mdata, ptr=torch.as_tensor(mb.ptr).to(dev))
@@ -166,6 +178,8 @@ def main():
         p.requires_grad_(train)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     g_res = torch.randn(pb.num_nodes, 64, device=dev, generator=gen)     # upstream gradients of the embeddings
+    if args.dtype == "bf16":
+        g_res = g_res.bfloat16()
     g_atm = torch.randn(mb.num_nodes, 64, device=dev, generator=gen)
     target = torch.randn(wl["pairs"] * world, 1, device=dev, generator=gen)
     # payloads of the N > 1 collectives in --scope encoders: the tensor joint_gnn.py:272 all-gathers (synthetic
@@ -293,7 +307,8 @@ def main():
                 by.setdefault(name, []).append(a.elapsed_time(b) * 1e-3)
             ops.KERNEL_EVENTS = None
             N, E = pb.num_nodes, pb.num_edges
-            conv_bytes = 224 * N + 156 * E            # algorithmic bytes of one conv launch
+            # algorithmic bytes of one conv launch (bf16 storage: float terms halved, 16 B/edge of indices kept)
+            conv_bytes = (224 * N + 156 * E) if args.dtype == "f32" else (112 * N + 86 * E)
             # dominant kernel = the conv kernel with the largest share of the step (backward when training);
             # backward counted as 2x the forward bytes (fwd + bwd = 3x forward)
             if by:
@@ -344,11 +359,13 @@ def main():
             "metric": f"graph-pairs/sec (Davis-shaped protein+drug), {what} " + ("fwd+bwd" if train else "forward"),
             "value": round(value, 1), "unit": "graph-pairs/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic Davis-shaped graphs (davis_synth, seed=rank); pretrained CASTER-DTA(2,2) weights",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic Davis-shaped graphs (davis_synth, seed=rank); " + (
+                "pretrained CASTER-DTA(2,2) weights" if convs == 2 else f"seeded random CASTER-DTA({convs},{convs}) weights"),
             "config": {"workload": args.workload, "pairs_per_gpu": wl["pairs"], "residues_per_gpu": pb.num_nodes,
                        "protein_edges_per_gpu": pb.num_edges, "atoms_per_gpu": mb.num_nodes,
-                       "drug_edges_per_gpu": mb.num_edges, "encoder": "CASTER-DTA(2,2)", "pass": args.mode,
+                       "drug_edges_per_gpu": mb.num_edges, "encoder": f"CASTER-DTA({convs},{convs})", "pass": args.mode,
+                       "activation_storage": "bf16 (protein encoder; fp32 accumulate, fp32 gradients)" if args.dtype == "bf16" else "fp32",
                        "scope": args.scope, "train_mode": bool(dropout_on), "dropout_p": 0.2 if dropout_on else 0.0,
                        "csr_build_in_step": ("collate" if args.collate_csr else not args.cache_csr),
                        "hip_graph": graph is not None, "kernels": ops.VARIANT, "parallelism": par},
@@ -408,8 +425,9 @@ def cpu_baseline(args, wl, state, pb, mb, train):
     leaves = [v for v in list(pp.values()) + list(mp.values()) if v.requires_grad]
 
     def cpu_step():
-        res = O.protein_lba_forward(pp, pd["x"], pd["edge_index"], pd["ntypes"], pd["etypes"], pd["eattr"])
-        atm = O.molecule_gine_forward(mp, md["x"], md["edge_index"], md["ntypes"], md["etypes"], md["eattr"])
+        nc = wl.get("convs", 2)
+        res = O.protein_lba_forward(pp, pd["x"], pd["edge_index"], pd["ntypes"], pd["etypes"], pd["eattr"], num_convs=nc)
+        atm = O.molecule_gine_forward(mp, md["x"], md["edge_index"], md["ntypes"], md["etypes"], md["eattr"], num_convs=nc)
         if train:
             torch.autograd.grad([res, atm], leaves, [gr, ga])
 

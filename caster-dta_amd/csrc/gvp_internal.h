@@ -22,15 +22,15 @@ namespace quad {
 int offsets(int nt_node, int nt_edge, int num_convs, QuadOffsets* o);
 int prepare(const gvp::EncLayout& L, int num_convs, const float* params, float* image, hipStream_t st);
 int node_embed(int nt_node, const float* img, const float* x_s, const float* x_v, const int64_t* ntypes,
-               int64_t N, float* h, unsigned long long* rng_state, unsigned long long* rng_out, hipStream_t st);
+               int64_t N, float* h, unsigned long long* rng_state, unsigned long long* rng_out, int bf16, hipStream_t st);
 int conv(int nt_edge, const float* img, const float* h, const float* e_s, const float* e_v,
          const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
          const int32_t* edst, int64_t N, int64_t E, int mean, float* dh, int fuse, const float* img_node,
          const float* img_head, float* h_out, float* out, const float* mask0, const float* mask1, gvp::RngArgs rng,
-         const float* e_in, float* e_out, hipStream_t st);
+         const float* e_in, float* e_out, int bf16, hipStream_t st);
 int node_update(const float* img_node, const float* img_head, const float* h, const float* dh, int64_t N,
                 int with_head, float* h_out, float* out, const float* mask0, const float* mask1, gvp::RngArgs rng,
-                hipStream_t st);
+                int bf16, hipStream_t st);
 
 // ---- backward (gvp_quad_bwd_kernels.hip).  Weight gradients are written as one
 // partial block per workgroup into `slab` ([grid][block floats]); `grid` returns
@@ -38,20 +38,20 @@ int node_update(const float* img_node, const float* img_head, const float* h, co
 int node_update_bwd(const float* img_node, const float* imgT_node, const float* h, const float* dh,
                     const float* mask0, const float* mask1, gvp::RngArgs rng, const float* g_up0, const float* g_up1,
                     const float* g_up2, int64_t N, float* g_dh, float* g_h, float* zero_rows, float* slab, int* grid,
-                    hipStream_t st);
+                    int bf16, hipStream_t st);
 int head_bwd(const float* img_head, const float* imgT_head, const float* h_out, const float* g_out, int64_t N,
-             float* g_h_out, float* slab, int* grid, hipStream_t st);
+             float* g_h_out, float* slab, int* grid, int bf16, hipStream_t st);
 int conv_bwd(int nt_edge, const float* img, const float* imgT, const float* h, const float* e_emb,
              const int32_t* rowptr, const int32_t* esrc, const int32_t* edst, int64_t N, int64_t E, int mean,
-             const float* g_dh, float* g_src, float* g_dst, float* g_e, float* slab, int* grid, hipStream_t st);
+             const float* g_dh, float* g_src, float* g_dst, float* g_e, float* slab, int* grid, int bf16, hipStream_t st);
 // backward of gvp_edge + LayerNorm from the summed d(edge embedding) of the conv layers (weight gradients only)
 int edge_embed_bwd(int nt_edge, const float* img, const float* imgT, const float* e_s, const float* e_v,
                    const int64_t* etypes, const int32_t* eperm, int64_t E, const float* const* g_e, int n_g,
-                   float* slab, int* grid, hipStream_t st);
+                   float* slab, int* grid, int bf16, hipStream_t st);
 constexpr int kEdgeRow = 36;              // floats per edge of the stored edge embedding: [e_s 32 | e_v 3 | pad]
 int node_embed_bwd(int nt_node, const float* img, const float* imgT, const float* x_s, const float* x_v,
                    const int64_t* ntypes, int64_t N, const float* g_up0, const float* g_up1, const float* g_up2,
-                   float* g_x_s, float* g_x_v, float* slab, int* grid, hipStream_t st);
+                   float* g_x_s, float* g_x_v, float* slab, int* grid, int bf16, hipStream_t st);
 // GINE layer backward on 16-atom MFMA tiles (gine_quad_kernels.hip): one slab row per workgroup
 // (`rows` x `row_len` floats, state_dict order of the layer).
 constexpr int kGineBwdMaxGrid = 256;      // upper bound (workspace sizing)

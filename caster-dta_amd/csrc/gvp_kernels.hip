@@ -27,8 +27,10 @@ inline int check_dims(const cgvp_dims* d) {
       d->edge_in_v != EDGE_IN_V || d->hidden_s != NS || d->hidden_v != NV ||
       d->edge_hidden_s != ES || d->edge_hidden_v != EV || d->out_s != OUT)
     return CGVP_ERR_UNSUPPORTED_DIMS;
+  if (d->storage != CGVP_F32 && d->storage != CGVP_BF16) return CGVP_ERR_UNSUPPORTED_DIMS;
   return 0;
 }
+inline int is_bf16(const cgvp_dims* d) { return d->storage == CGVP_BF16 ? 1 : 0; }
 
 inline EncLayout cvt(const cgvp_layout& l) {
   EncLayout L;
@@ -630,9 +632,10 @@ int cgvp_node_embed_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
     if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
     if (int rc = quad::node_embed(layout->nt_node, image + o.emb, x_s, x_v, ntypes, N, h,
                                   reinterpret_cast<unsigned long long*>(rng_state),
-                                  reinterpret_cast<unsigned long long*>(rng_out), (hipStream_t)stream)) return rc;
+                                  reinterpret_cast<unsigned long long*>(rng_out), is_bf16(dims), (hipStream_t)stream)) return rc;
     return launch_status();
   }
+  if (is_bf16(dims)) return CGVP_ERR_UNSUPPORTED_DIMS;      // bf16 storage is a feature of the MFMA kernels
   NodeEmbedArgs a{params, cvt(*layout), x_s, x_v, ntypes, N, h};
   const dim3 grid((unsigned)((N + WAVE - 1) / WAVE));
   hipStream_t st = (hipStream_t)stream;
@@ -665,9 +668,11 @@ int cgvp_conv_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float*
     if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
     if (int rc = quad::conv(layout->nt_edge, image + o.conv0 + layer * o.layer_stride, h, e_s, e_v, etypes, rowptr,
                             eperm, esrc, edst, N, E, aggr_mean ? 1 : 0, dh, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
-                            nullptr, gvp::RngArgs{nullptr, 0.f, 0}, e_in, e_in ? nullptr : e_out, (hipStream_t)stream)) return rc;
+                            nullptr, gvp::RngArgs{nullptr, 0.f, 0}, e_in, e_in ? nullptr : e_out, is_bf16(dims),
+                            (hipStream_t)stream)) return rc;
     return launch_status();
   }
+  if (is_bf16(dims)) return CGVP_ERR_UNSUPPORTED_DIMS;
   // target nodes per workgroup: aim at ~48 of the 64 edge lanes per chunk
   int64_t deg = (E + N - 1) / N;
   if (deg < 1) deg = 1;
@@ -706,7 +711,7 @@ int cgvp_conv_layer_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
   if (int rc = quad::conv(layout->nt_edge, image + o.conv0 + layer * o.layer_stride, h, e_s, e_v, etypes, rowptr, eperm,
                           esrc, edst, N, E, aggr_mean ? 1 : 0, dh, with_head ? 2 : 1,
                           image + o.node0 + layer * o.layer_stride, image + o.head, h_out, out, mask0, mask1,
-                          rng_args(rng, 2 * layer), e_in, e_in ? nullptr : e_out, (hipStream_t)stream)) return rc;
+                          rng_args(rng, 2 * layer), e_in, e_in ? nullptr : e_out, is_bf16(dims), (hipStream_t)stream)) return rc;
   return launch_status();
 }
 
@@ -725,9 +730,10 @@ int cgvp_node_update_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const
     if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
     if (int rc = quad::node_update(image + o.node0 + layer * o.layer_stride, image + o.head, h, dh, N,
                                    with_head ? 1 : 0, h_out, out, nullptr, nullptr, gvp::RngArgs{nullptr, 0.f, 0},
-                                   (hipStream_t)stream)) return rc;
+                                   is_bf16(dims), (hipStream_t)stream)) return rc;
     return launch_status();
   }
+  if (is_bf16(dims)) return CGVP_ERR_UNSUPPORTED_DIMS;
   NodeUpdateArgs a{params, cvt(*layout), layer, h, dh, N, h_out, out};
   dim3 grid((unsigned)((N + WAVE - 1) / WAVE));
   if (with_head) hipLaunchKernelGGL(node_update_kernel<true>, grid, dim3(WAVE), 0, (hipStream_t)stream, a);
@@ -751,7 +757,7 @@ int cgvp_node_update_fwd_train(const cgvp_dims* dims, const cgvp_layout* layout,
   if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
   if (int rc = quad::node_update(image + o.node0 + layer * o.layer_stride, image + o.head, h, dh, N,
                                  with_head ? 1 : 0, h_out, out, mask0, mask1, rng_args(rng, 2 * layer),
-                                 (hipStream_t)stream)) return rc;
+                                 is_bf16(dims), (hipStream_t)stream)) return rc;
   return launch_status();
 }
 
@@ -789,12 +795,12 @@ int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const
   float* head_slab = workspace + (size_t)kBwdMaxGrid * nd;
   if (with_head) {
     // the head's d h_out lands in g_dh and is consumed in place as the node stage's upstream
-    if (int rc = quad::head_bwd(image + o.head, image + o.headT, h_out, g_out, N, g_dh, head_slab, &hgrid, st)) return rc;
+    if (int rc = quad::head_bwd(image + o.head, image + o.headT, h_out, g_out, N, g_dh, head_slab, &hgrid, is_bf16(dims), st)) return rc;
     g_up0 = g_dh; g_up1 = nullptr; g_up2 = nullptr;
   }
   if (int rc = quad::node_update_bwd(image + o.node0 + layer * o.layer_stride, image + o.nodeT0 + layer * o.layerT_stride,
                                      h, dh, mask0, mask1, rng_args(rng, 2 * layer), g_up0, g_up1, g_up2, N, g_dh, g_h, zero_out,
-                                     workspace, &grid, st)) return rc;
+                                     workspace, &grid, is_bf16(dims), st)) return rc;
   const int node_len = conv_ff1() + LFf1::size(0) - conv_ln0();          // norm.0 .. end of ff_func.1
   cgvp_segment sg[2] = {{workspace, grid, nd, 0, node_len, layout->conv0 + layer * layout->conv_stride + conv_ln0()},
                         {head_slab, hgrid, hd, 0, layout->total - layout->ln_out, layout->ln_out}};
@@ -829,7 +835,7 @@ int cgvp_conv_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float*
   }
   if (int rc = quad::conv_bwd(layout->nt_edge, image + o.conv0 + layer * o.layer_stride,
                               image + o.convT0 + layer * o.layerT_stride, h, e_emb, rowptr, esrc, edst, N, E,
-                              aggr_mean ? 1 : 0, g_dh, g_src, g_dst, g_e, workspace, &grid, st)) return rc;
+                              aggr_mean ? 1 : 0, g_dh, g_src, g_dst, g_e, workspace, &grid, is_bf16(dims), st)) return rc;
   cgvp_segment sg[1] = {{workspace, grid, ct, 0, conv_ln0(), layout->conv0 + layer * layout->conv_stride}};
   if (segs && nsegs) { segs[0] = sg[0]; *nsegs = 1; }
   else quad::reduce_segments(sg, 1, grad_params, st);
@@ -855,7 +861,7 @@ int cgvp_edge_embed_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
   hipStream_t st = (hipStream_t)stream;
   // gvp_edge's fragments are the head of every conv slice (identical in all layers): layer 0's is used
   if (int rc = quad::edge_embed_bwd(layout->nt_edge, image + o.conv0, image + o.convT0, e_s, e_v, etypes, eperm, E, g_e,
-                                    num_g, workspace, &grid, st)) return rc;
+                                    num_g, workspace, &grid, is_bf16(dims), st)) return rc;
   cgvp_segment sg[1] = {{workspace, grid, ce, 0, layout->conv0 - layout->edge_gvp, layout->edge_gvp}};
   if (segs && nsegs) { segs[0] = sg[0]; *nsegs = 1; }
   else quad::reduce_segments(sg, 1, grad_params, st);
@@ -878,7 +884,7 @@ int cgvp_node_embed_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
   if (int rc = quad::bwd_block_sizes(layout->nt_node, layout->nt_edge, &emb, &ce, &ct, &nd, &hd)) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (int rc = quad::node_embed_bwd(layout->nt_node, image + o.emb, image + o.embT, x_s, x_v, ntypes, N, g_up0, g_up1,
-                                    g_up2, g_x_s, g_x_v, workspace, &grid, st)) return rc;
+                                    g_up2, g_x_s, g_x_v, workspace, &grid, is_bf16(dims), st)) return rc;
   cgvp_segment sg[1] = {{workspace, grid, emb, 0, layout->edge_gvp - layout->node_gvp, layout->node_gvp}};
   if (segs && nsegs) { segs[0] = sg[0]; *nsegs = 1; }
   else quad::reduce_segments(sg, 1, grad_params, st);

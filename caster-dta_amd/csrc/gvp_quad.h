@@ -39,6 +39,44 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int P1 = 0, P2 = 1;
 constexpr int ceil4(int x) { return (x + 3) / 4; }
 
+// ---- activation storage type (cgvp_dims.storage): what the ACTIVATION buffers in HBM hold -- node / edge features,
+// node rows h / dh between stages, the edge-embedding store, the residue embeddings `out`.  fp32 (default) or bf16
+// ("bf16 storage / fp32 accumulate": every load widens to fp32, all arithmetic, LayerNorm statistics, MFMA
+// accumulation and every GRADIENT buffer stay fp32; stores round to nearest even).  The argument structs keep
+// `float*` fields for both; Io<ST> reinterprets them, indices are in ELEMENTS.
+struct bf16s {};
+template <typename ST> struct Io;
+template <> struct Io<float> {
+  static __device__ __forceinline__ f4 ld4(const float* p, int64_t i) { return *reinterpret_cast<const f4*>(p + i); }
+  static __device__ __forceinline__ float ld(const float* p, int64_t i) { return p[i]; }
+  static __device__ __forceinline__ void st4(float* p, int64_t i, f4 v) { *reinterpret_cast<f4*>(p + i) = v; }
+  static __device__ __forceinline__ void st(float* p, int64_t i, float v) { p[i] = v; }
+  // the value a consumer of the stored element will read back (identity in fp32): a kernel that stores an activation
+  // AND keeps using it in registers continues with this, so forward and backward see the same numbers
+  static __device__ __forceinline__ float rt(float v) { return v; }
+  static __device__ __forceinline__ f4 rt4(f4 v) { return v; }
+};
+template <> struct Io<bf16s> {
+  static __device__ __forceinline__ float widen(uint32_t hi16) { return __uint_as_float(hi16); }
+  static __device__ __forceinline__ uint16_t narrow(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  static __device__ __forceinline__ f4 ld4(const float* p, int64_t i) {        // 4 consecutive bf16 = one 8-byte load
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p) + i);
+    return f4{widen(u.x << 16), widen(u.x & 0xffff0000u), widen(u.y << 16), widen(u.y & 0xffff0000u)};
+  }
+  static __device__ __forceinline__ float ld(const float* p, int64_t i) {
+    return widen((uint32_t)reinterpret_cast<const uint16_t*>(p)[i] << 16);
+  }
+  static __device__ __forceinline__ void st4(float* p, int64_t i, f4 v) {
+    uint2 u;
+    u.x = (uint32_t)narrow(v[0]) | ((uint32_t)narrow(v[1]) << 16);
+    u.y = (uint32_t)narrow(v[2]) | ((uint32_t)narrow(v[3]) << 16);
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p) + i) = u;
+  }
+  static __device__ __forceinline__ void st(float* p, int64_t i, float v) { reinterpret_cast<uint16_t*>(p)[i] = narrow(v); }
+  static __device__ __forceinline__ float rt(float v) { return widen((uint32_t)narrow(v) << 16); }
+  static __device__ __forceinline__ f4 rt4(f4 v) { return f4{rt(v[0]), rt(v[1]), rt(v[2]), rt(v[3])}; }
+};
+
 // One run of k-slots of a GEMM: which source column of W feeds slot (step s, group g).
 template <int KIND, int BASE, int WIDTH>
 struct Seg {

@@ -151,6 +151,7 @@ static_assert(node_bwd_lds_floats() * 4 <= 160 * 1024, "node backward LDS plan e
 
 // g_up0 may alias g_dh (the head backward leaves d h_out there): a tile's rows are read
 // by the same lanes that overwrite them at the end of the tile.
+template <typename ST>
 __global__ __launch_bounds__(BW_TPB, 2) void node_bwd_kernel(NodeBArgs a) {
   typedef Image<0, 0> IM;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -183,13 +184,12 @@ __global__ __launch_bounds__(BW_TPB, 2) void node_bwd_kernel(NodeBArgs a) {
     f4 gs[1] = {zero};
     float gv[3][1] = {{0.f}, {0.f}, {0.f}};
     if (active) {
-      const float* hr = a.h + n * ROW;
-      const float* dr = a.dh + n * ROW;
+      const int64_t hr = n * ROW;
       node_dropout(a.mask0, a.rng, 0, n, g, m0s, m0v);      // the factors the forward applied (given, or regenerated)
       node_dropout(a.mask1, a.rng, 1, n, g, m1s, m1v);
-      x0[0] = *reinterpret_cast<const f4*>(hr + 4 * g) + *reinterpret_cast<const f4*>(dr + 4 * g) * m0s;
+      x0[0] = Io<ST>::ld4(a.h, hr + 4 * g) + Io<ST>::ld4(a.dh, hr + 4 * g) * m0s;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) xv0[p][0] = hr[NS + 3 * g + p] + dr[NS + 3 * g + p] * m0v;
+      for (int p = 0; p < 3; ++p) xv0[p][0] = Io<ST>::ld(a.h, hr + NS + 3 * g + p) + Io<ST>::ld(a.dh, hr + NS + 3 * g + p) * m0v;
       // upstream gradient of this stage's output (sum of up to three buffers)
       const float* ups[3] = {a.g_up0, a.g_up1, a.g_up2};
 #pragma unroll
@@ -298,6 +298,7 @@ struct HeadBArgs {
 };
 constexpr int head_bwd_lds_floats() { return BW_TPB + Image<0, 0>::HD_SIZE + Image<0, 0>::TH_SIZE + BW_WPB * (HEAD_GB + TSCR_FLOATS); }
 
+template <typename ST>
 __global__ __launch_bounds__(BW_TPB, 2) void head_bwd_kernel(HeadBArgs a) {
   typedef Image<0, 0> IM;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -324,10 +325,10 @@ __global__ __launch_bounds__(BW_TPB, 2) void head_bwd_kernel(HeadBArgs a) {
     float ov1[3][1] = {{0.f}, {0.f}, {0.f}};
     f4 d_o[4] = {zero, zero, zero, zero};
     if (active) {
-      const float* hr = a.h_out + n * ROW;
-      o1[0] = *reinterpret_cast<const f4*>(hr + 4 * g);
+      const int64_t hr = n * ROW;
+      o1[0] = Io<ST>::ld4(a.h_out, hr + 4 * g);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) ov1[p][0] = hr[NS + 3 * g + p];
+      for (int p = 0; p < 3; ++p) ov1[p][0] = Io<ST>::ld(a.h_out, hr + NS + 3 * g + p);
       const float* gr_ = a.g_out + n * OUT;
 #pragma unroll
       for (int t = 0; t < 4; ++t) d_o[t] = *reinterpret_cast<const f4*>(gr_ + 16 * t + 4 * g);
@@ -400,7 +401,7 @@ struct ConvBArgs {
   int64_t N; int npw; int mean; const float* g_dh; float* g_src; float* g_dst; float* g_e; float* slab;
 };
 
-template <int NTE>
+template <int NTE, typename ST>
 __global__ __launch_bounds__(CB_TPB, CB_WPB / 4) void conv_bwd_kernel(ConvBArgs a) {
   typedef Image<0, NTE> IM;
   typedef ConvBImg<NTE> BI;
@@ -452,21 +453,20 @@ __global__ __launch_bounds__(CB_TPB, CB_WPB / 4) void conv_bwd_kernel(ConvBArgs 
       if (active) {
         src = a.esrc[p];
         dst = a.edst[p];
-        const float* er = a.e_emb + (int64_t)p * EROW;
-        es0 = *reinterpret_cast<const f4*>(er + 4 * g);
-        es1 = *reinterpret_cast<const f4*>(er + 16 + 4 * g);
+        const int64_t er = (int64_t)p * EROW;
+        es0 = Io<ST>::ld4(a.e_emb, er + 4 * g);
+        es1 = Io<ST>::ld4(a.e_emb, er + 16 + 4 * g);
         if (g == 0) {
 #pragma unroll
-          for (int d = 0; d < 3; ++d) ev[d] = er[ES + d];
+          for (int d = 0; d < 3; ++d) ev[d] = Io<ST>::ld(a.e_emb, er + ES + d);
         }
-        const float* hj = a.h + (int64_t)src * ROW;
-        const float* hi = a.h + (int64_t)dst * ROW;
+        const int64_t hj = (int64_t)src * ROW, hi = (int64_t)dst * ROW;
         const float* gd = a.g_dh + (int64_t)dst * ROW;       // d(aggregated message) of the target
-        sj = *reinterpret_cast<const f4*>(hj + 4 * g);
-        si = *reinterpret_cast<const f4*>(hi + 4 * g);
+        sj = Io<ST>::ld4(a.h, hj + 4 * g);
+        si = Io<ST>::ld4(a.h, hi + 4 * g);
         d_ms = *reinterpret_cast<const f4*>(gd + 4 * g);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { vj[d] = hj[NS + 3 * g + d]; vi[d] = hi[NS + 3 * g + d]; d_mv[d] = gd[NS + 3 * g + d]; }
+        for (int d = 0; d < 3; ++d) { vj[d] = Io<ST>::ld(a.h, hj + NS + 3 * g + d); vi[d] = Io<ST>::ld(a.h, hi + NS + 3 * g + d); d_mv[d] = gd[NS + 3 * g + d]; }
         if (a.mean) {
           const int deg = a.rowptr[dst + 1] - a.rowptr[dst];
           const float sc = 1.0f / (float)(deg > 1 ? deg : 1);
@@ -622,7 +622,7 @@ struct EdgeBArgs {
 template <int NTE>
 constexpr int edge_bwd_lds_floats() { return BW_TPB + Image<0, NTE>::CV_M0 + Image<0, NTE>::TC_M0 + BW_WPB * (EdgeBlk<NTE>::SIZE + TSCR_FLOATS); }
 
-template <int NTE>
+template <int NTE, typename ST>
 __global__ __launch_bounds__(BW_TPB, 2) void edge_bwd_kernel(EdgeBArgs a) {
   typedef Image<0, NTE> IM;
   typedef EdgeBlk<NTE> B;
@@ -652,12 +652,12 @@ __global__ __launch_bounds__(BW_TPB, 2) void edge_bwd_kernel(EdgeBArgs a) {
     float d_ev[3][1] = {{0.f}, {0.f}, {0.f}};
     if (active) {
       const int32_t eid = a.eperm[p];
-      const float* er = a.e_s + (int64_t)eid * EDGE_IN_S;
-      es0 = *reinterpret_cast<const f4*>(er + 4 * g);
-      es1 = *reinterpret_cast<const f4*>(er + 16 + 4 * g);
+      const int64_t er = (int64_t)eid * EDGE_IN_S;
+      es0 = Io<ST>::ld4(a.e_s, er + 4 * g);
+      es1 = Io<ST>::ld4(a.e_s, er + 16 + 4 * g);
       if (g == 0) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) ev[d] = a.e_v[(int64_t)eid * 3 + d];
+        for (int d = 0; d < 3; ++d) ev[d] = Io<ST>::ld(a.e_v, (int64_t)eid * 3 + d);
       }
       if (NTE > 0) {
         et[0] = (int)a.etypes[eid];
@@ -707,7 +707,7 @@ struct EmbBArgs {
 template <int NTN>
 constexpr int embed_bwd_lds_floats() { return BW_TPB + Image<NTN, 0>::EMB_SIZE + Image<NTN, 0>::TE_SIZE + BW_WPB * (EmbBlk<NTN>::SIZE + TSCR_FLOATS); }
 
-template <int NTN>
+template <int NTN, typename ST>
 __global__ __launch_bounds__(BW_TPB, 2) void embed_bwd_kernel(EmbBArgs a) {
   typedef Image<NTN, 0> IM;
   typedef QNode<NTN> Q;
@@ -735,10 +735,10 @@ __global__ __launch_bounds__(BW_TPB, 2) void embed_bwd_kernel(EmbBArgs a) {
 #pragma unroll
     for (int s = 0; s < Q::SSTEPS; ++s) {
       const int c = 4 * s + g;
-      bs[0][s] = (active && c < NODE_IN_S) ? a.x_s[n * NODE_IN_S + c] : 0.f;
+      bs[0][s] = (active && c < NODE_IN_S) ? Io<ST>::ld(a.x_s, n * NODE_IN_S + c) : 0.f;
     }
 #pragma unroll
-    for (int p = 0; p < 3; ++p) bv[0][p][0] = (active && g < NODE_IN_V) ? a.x_v[n * 3 * NODE_IN_V + 3 * g + p] : 0.f;
+    for (int p = 0; p < 3; ++p) bv[0][p][0] = (active && g < NODE_IN_V) ? Io<ST>::ld(a.x_v, n * 3 * NODE_IN_V + 3 * g + p) : 0.f;
     if (NTN > 0 && active) {
       type[0] = (int)a.ntypes[n];
       type[0] = type[0] < 0 ? 0 : (type[0] >= NTN ? NTN - 1 : type[0]);
@@ -874,96 +874,113 @@ int reduce_slab(const float* slab, int rows, int stride, int col0, int len, floa
   return 0;
 }
 
+// one launch of a backward kernel in the requested activation storage type
+#define BWD_LAUNCH(KERNEL, G, TPB_, LDS_, ARGS)                                                                               \
+  do {                                                                                                                        \
+    if (bf16) {                                                                                                               \
+      if (hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL(bf16s)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_))) return (int)err; \
+      hipLaunchKernelGGL((KERNEL(bf16s)), dim3(G), dim3(TPB_), (LDS_), st, ARGS);                                             \
+    } else {                                                                                                                  \
+      if (hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL(float)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_))) return (int)err; \
+      hipLaunchKernelGGL((KERNEL(float)), dim3(G), dim3(TPB_), (LDS_), st, ARGS);                                             \
+    }                                                                                                                         \
+  } while (0)
+
 int node_update_bwd(const float* img_node, const float* imgT_node, const float* h, const float* dh,
                     const float* mask0, const float* mask1, gvp::RngArgs rng, const float* g_up0, const float* g_up1,
                     const float* g_up2, int64_t N, float* g_dh, float* g_h, float* zero_rows, float* slab, int* grid,
-                    hipStream_t st) {
+                    int bf16, hipStream_t st) {
   NodeBArgs a{img_node, imgT_node, h, dh, mask0, mask1, rng, g_up0, g_up1, g_up2, N, g_dh, g_h, zero_rows, slab};
   const int G = grid_for((N + TILE - 1) / TILE);
   *grid = G;
   const size_t lds = (size_t)node_bwd_lds_floats() * sizeof(float);
-  if (hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(node_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return (int)err;
-  hipLaunchKernelGGL(node_bwd_kernel, dim3(G), dim3(BW_TPB), lds, st, a);
+#define K_(ST) node_bwd_kernel<ST>
+  BWD_LAUNCH(K_, G, BW_TPB, lds, a);
+#undef K_
   return 0;
 }
 
 int head_bwd(const float* img_head, const float* imgT_head, const float* h_out, const float* g_out, int64_t N,
-             float* g_h_out, float* slab, int* grid, hipStream_t st) {
+             float* g_h_out, float* slab, int* grid, int bf16, hipStream_t st) {
   HeadBArgs a{img_head, imgT_head, h_out, g_out, N, g_h_out, slab};
   const int G = grid_for((N + TILE - 1) / TILE);
   *grid = G;
   const size_t lds = (size_t)head_bwd_lds_floats() * sizeof(float);
-  if (hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(head_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return (int)err;
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(G), dim3(BW_TPB), lds, st, a);
+#define K_(ST) head_bwd_kernel<ST>
+  BWD_LAUNCH(K_, G, BW_TPB, lds, a);
+#undef K_
   return 0;
 }
 
 template <int NTE>
-int conv_bwd_impl(ConvBArgs& a, int* grid, hipStream_t st) {
+int conv_bwd_impl(ConvBArgs& a, int* grid, int bf16, hipStream_t st) {
   const int64_t ngroups = (a.N + a.npw - 1) / a.npw;
   const int64_t wgs = (ngroups + CB_WPB - 1) / CB_WPB;
   const int G = (int)(wgs < 1 ? 1 : (wgs > CB_MAX_GRID ? CB_MAX_GRID : wgs));
   *grid = G;
   const size_t lds = (size_t)conv_bwd_lds_floats<NTE>() * sizeof(float);
-  if (hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bwd_kernel<NTE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return (int)err;
-  hipLaunchKernelGGL(conv_bwd_kernel<NTE>, dim3(G), dim3(CB_TPB), lds, st, a);
+#define K_(ST) conv_bwd_kernel<NTE, ST>
+  BWD_LAUNCH(K_, G, CB_TPB, lds, a);
+#undef K_
   return 0;
 }
 
 int conv_bwd(int nt_edge, const float* img, const float* imgT, const float* h, const float* e_emb,
              const int32_t* rowptr, const int32_t* esrc, const int32_t* edst, int64_t N, int64_t E, int mean,
-             const float* g_dh, float* g_src, float* g_dst, float* g_e, float* slab, int* grid, hipStream_t st) {
+             const float* g_dh, float* g_src, float* g_dst, float* g_e, float* slab, int* grid, int bf16, hipStream_t st) {
   // targets per wave: two 16-edge tiles' worth (the forward's 32-edge passes), as in quad::conv
   int64_t deg = N > 0 ? (E + N - 1) / N : 1;
   if (deg < 1) deg = 1;
   int npw = (int)((2 * TILE - 2) / deg);
   npw = npw < 1 ? 1 : (npw > WAVE ? WAVE : npw);
   ConvBArgs a{img, imgT, h, e_emb, rowptr, esrc, edst, N, npw, mean, g_dh, g_src, g_dst, g_e, slab};
-  if (nt_edge == 0) return conv_bwd_impl<0>(a, grid, st);
-  if (nt_edge == 1) return conv_bwd_impl<1>(a, grid, st);
+  if (nt_edge == 0) return conv_bwd_impl<0>(a, grid, bf16, st);
+  if (nt_edge == 1) return conv_bwd_impl<1>(a, grid, bf16, st);
   return CGVP_ERR_UNSUPPORTED_DIMS;
 }
 
 template <int NTE>
-int edge_bwd_impl(EdgeBArgs& a, int* grid, hipStream_t st) {
+int edge_bwd_impl(EdgeBArgs& a, int* grid, int bf16, hipStream_t st) {
   // 66 KB of LDS and ~115 VGPRs per workgroup: TWO workgroups share a CU (4 waves per SIMD), so up to 2 x 240 slab rows
   const int64_t tiles = (a.E + TILE - 1) / TILE;
   const int G = (int)(tiles < 1 ? 1 : (tiles > 2 * BW_MAX_GRID ? 2 * BW_MAX_GRID : tiles));
   *grid = G;
   const size_t lds = (size_t)edge_bwd_lds_floats<NTE>() * sizeof(float);
-  if (hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_bwd_kernel<NTE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return (int)err;
-  hipLaunchKernelGGL(edge_bwd_kernel<NTE>, dim3(G), dim3(BW_TPB), lds, st, a);
+#define K_(ST) edge_bwd_kernel<NTE, ST>
+  BWD_LAUNCH(K_, G, BW_TPB, lds, a);
+#undef K_
   return 0;
 }
 
 int edge_embed_bwd(int nt_edge, const float* img, const float* imgT, const float* e_s, const float* e_v,
                    const int64_t* etypes, const int32_t* eperm, int64_t E, const float* const* g_e, int n_g,
-                   float* slab, int* grid, hipStream_t st) {
+                   float* slab, int* grid, int bf16, hipStream_t st) {
   if (n_g < 1 || n_g > EB_MAX_LAYERS) return CGVP_ERR_BAD_ARG;
   EdgeBArgs a{img, imgT, e_s, e_v, etypes, eperm, E, {}, n_g, slab};
   for (int l = 0; l < n_g; ++l) a.g_e[l] = g_e[l];
-  if (nt_edge == 0) return edge_bwd_impl<0>(a, grid, st);
-  if (nt_edge == 1) return edge_bwd_impl<1>(a, grid, st);
+  if (nt_edge == 0) return edge_bwd_impl<0>(a, grid, bf16, st);
+  if (nt_edge == 1) return edge_bwd_impl<1>(a, grid, bf16, st);
   return CGVP_ERR_UNSUPPORTED_DIMS;
 }
 
 template <int NTN>
-int embed_bwd_impl(EmbBArgs& a, int* grid, hipStream_t st) {
+int embed_bwd_impl(EmbBArgs& a, int* grid, int bf16, hipStream_t st) {
   const int G = grid_for((a.N + TILE - 1) / TILE);
   *grid = G;
   const size_t lds = (size_t)embed_bwd_lds_floats<NTN>() * sizeof(float);
-  if (hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel<NTN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return (int)err;
-  hipLaunchKernelGGL(embed_bwd_kernel<NTN>, dim3(G), dim3(BW_TPB), lds, st, a);
+#define K_(ST) embed_bwd_kernel<NTN, ST>
+  BWD_LAUNCH(K_, G, BW_TPB, lds, a);
+#undef K_
   return 0;
 }
 
 int node_embed_bwd(int nt_node, const float* img, const float* imgT, const float* x_s, const float* x_v,
                    const int64_t* ntypes, int64_t N, const float* g_up0, const float* g_up1, const float* g_up2,
-                   float* g_x_s, float* g_x_v, float* slab, int* grid, hipStream_t st) {
+                   float* g_x_s, float* g_x_v, float* slab, int* grid, int bf16, hipStream_t st) {
   EmbBArgs a{img, imgT, x_s, x_v, ntypes, N, g_up0, g_up1, g_up2, g_x_s, g_x_v, slab};
-  if (nt_node == 0) return embed_bwd_impl<0>(a, grid, st);
-  if (nt_node == 20) return embed_bwd_impl<20>(a, grid, st);
-  if (nt_node == 21) return embed_bwd_impl<21>(a, grid, st);
+  if (nt_node == 0) return embed_bwd_impl<0>(a, grid, bf16, st);
+  if (nt_node == 20) return embed_bwd_impl<20>(a, grid, bf16, st);
+  if (nt_node == 21) return embed_bwd_impl<21>(a, grid, bf16, st);
   return CGVP_ERR_UNSUPPORTED_DIMS;
 }
 

@@ -120,7 +120,7 @@ struct EmbedQArgs {
   unsigned long long* rng_state; unsigned long long* rng_out;
 };
 
-template <int NTN>
+template <int NTN, typename ST>
 __global__ __launch_bounds__(TPB) void embed_quad_kernel(EmbedQArgs a) {
   typedef Image<NTN, 0> IM;
   typedef QNode<NTN> Q;
@@ -142,10 +142,10 @@ __global__ __launch_bounds__(TPB) void embed_quad_kernel(EmbedQArgs a) {
 #pragma unroll
   for (int s = 0; s < Q::SSTEPS; ++s) {
     const int c = 4 * s + g;
-    bs[0][s] = (active && c < NODE_IN_S) ? a.x_s[n * NODE_IN_S + c] : 0.f;
+    bs[0][s] = (active && c < NODE_IN_S) ? Io<ST>::ld(a.x_s, n * NODE_IN_S + c) : 0.f;
   }
 #pragma unroll
-  for (int p = 0; p < 3; ++p) bv[0][p][0] = (active && g < NODE_IN_V) ? a.x_v[n * 3 * NODE_IN_V + 3 * g + p] : 0.f;
+  for (int p = 0; p < 3; ++p) bv[0][p][0] = (active && g < NODE_IN_V) ? Io<ST>::ld(a.x_v, n * 3 * NODE_IN_V + 3 * g + p) : 0.f;
   if (NTN > 0 && active) {
     type[0] = (int)a.ntypes[n];
     type[0] = type[0] < 0 ? 0 : (type[0] >= NTN ? NTN - 1 : type[0]);
@@ -156,10 +156,9 @@ __global__ __launch_bounds__(TPB) void embed_quad_kernel(EmbedQArgs a) {
   Q::template forward<1>(lds + IM::EMB_GVP, lane, type, bs, bv, s, v, c);
   ln_quad<NS, NV>(lds + IM::EMB_LN, lane, s[0], v[0]);
   if (active) {
-    float* row = a.h + n * ROW;
-    *reinterpret_cast<f4*>(row + 4 * g) = s[0][0];
+    Io<ST>::st4(a.h, n * ROW + 4 * g, s[0][0]);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) row[NS + 3 * g + p] = v[0][p][0];
+    for (int p = 0; p < 3; ++p) Io<ST>::st(a.h, n * ROW + NS + 3 * g + p, v[0][p][0]);
   }
 }
 
@@ -193,7 +192,7 @@ __device__ __forceinline__ void node_dropout(const float* mask, const gvp::RngAr
 // Rest of GVPConvLayer.forward for one tile of 16 residues, from s/v = h + mask0 * dh (lane (i, g)
 // holds scalars 4g..4g+3 and vector channel g): LN0, feed-forward GVPs, residual, LN1 -> h_out
 // (optional with the head), then gvp_norm_before_scalar + gvp_to_scalar -> out.
-template <bool HEAD>
+template <bool HEAD, typename ST>
 __device__ __forceinline__ void node_tile(const float* nd, const float* hd, int lane, bool active, int64_t n,
                                           f4 (&s)[1], float (&v)[3][1], f4 m1s, float m1v, float* h_out,
                                           float* out) {
@@ -230,10 +229,9 @@ __device__ __forceinline__ void node_tile(const float* nd, const float* hd, int 
   }
   ln_quad<NS, NV>(nd + IM::ND_LN1, lane, s, v);
   if (active && (!HEAD || h_out)) {          // with the head h_out is optional (training saves it for the backward)
-    float* row = h_out + n * ROW;
-    *reinterpret_cast<f4*>(row + 4 * g) = s[0];
+    Io<ST>::st4(h_out, n * ROW + 4 * g, s[0]);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) row[NS + 3 * g + p] = v[p][0];
+    for (int p = 0; p < 3; ++p) Io<ST>::st(h_out, n * ROW + NS + 3 * g + p, v[p][0]);
   }
   if (!HEAD) return;
   ln_quad<NS, NV>(hd + IM::HD_LN, lane, s, v);
@@ -246,24 +244,24 @@ __device__ __forceinline__ void node_tile(const float* nd, const float* hd, int 
   QHead::Cache c[1];
   QHead::forward<1>(hd + IM::HD_GVP, lane, zt, bs, bv, o, dummy, c);
   if (active) {
-    float* row = out + n * OUT;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) *reinterpret_cast<f4*>(row + 16 * t + 4 * g) = o[0][t];
+    for (int t = 0; t < 4; ++t) Io<ST>::st4(out, n * OUT + 16 * t + 4 * g, o[0][t]);
   }
 }
 
-// s/v = h[n] + mask0 * dh_row for lane (i, g); dh_row points at the node's [28] aggregated message
+// s/v = h[n] + mask0 * dh_row for lane (i, g); `dr` + `dr_off` is the node's [28] aggregated message: an fp32 row of
+// the wave's LDS accumulator (DT = float, fused layer kernel) or a row of the dh buffer in HBM (DT = ST)
+template <typename ST, typename DT>
 __device__ __forceinline__ void node_inputs(const NodeQArgs& a, int lane, bool active, int64_t n, const float* dr,
-                                            f4 (&s)[1], float (&v)[3][1], f4& m1s, float& m1v) {
+                                            int64_t dr_off, f4 (&s)[1], float (&v)[3][1], f4& m1s, float& m1v) {
   const int g = lane >> 4;
   s[0] = f4{0.f, 0.f, 0.f, 0.f};
   v[0][0] = v[1][0] = v[2][0] = 0.f;
   m1s = f4{1.f, 1.f, 1.f, 1.f};
   m1v = 1.f;
   if (!active) return;
-  const float* hr = a.h + n * ROW;
-  f4 ds = *reinterpret_cast<const f4*>(dr + 4 * g);
-  float dv[3] = {dr[NS + 3 * g], dr[NS + 3 * g + 1], dr[NS + 3 * g + 2]};
+  f4 ds = Io<DT>::ld4(dr, dr_off + 4 * g);
+  float dv[3] = {Io<DT>::ld(dr, dr_off + NS + 3 * g), Io<DT>::ld(dr, dr_off + NS + 3 * g + 1), Io<DT>::ld(dr, dr_off + NS + 3 * g + 2)};
   {
     f4 m0s = {1.f, 1.f, 1.f, 1.f};
     float m0v = 1.f;
@@ -273,12 +271,12 @@ __device__ __forceinline__ void node_inputs(const NodeQArgs& a, int lane, bool a
 #pragma unroll
     for (int p = 0; p < 3; ++p) dv[p] *= m0v;
   }
-  s[0] = *reinterpret_cast<const f4*>(hr + 4 * g) + ds;
+  s[0] = Io<ST>::ld4(a.h, n * ROW + 4 * g) + ds;
 #pragma unroll
-  for (int p = 0; p < 3; ++p) v[p][0] = hr[NS + 3 * g + p] + dv[p];
+  for (int p = 0; p < 3; ++p) v[p][0] = Io<ST>::ld(a.h, n * ROW + NS + 3 * g + p) + dv[p];
 }
 
-template <bool HEAD>
+template <bool HEAD, typename ST>
 __global__ __launch_bounds__(TPB) void node_quad_kernel(NodeQArgs a) {
   typedef Image<0, 0> IM;
   __shared__ __attribute__((aligned(16))) float lds[IM::ND_SIZE + (HEAD ? IM::HD_SIZE : 0)];
@@ -288,11 +286,11 @@ __global__ __launch_bounds__(TPB) void node_quad_kernel(NodeQArgs a) {
   const bool active = n < a.N;
   f4 s[1], m1s;
   float v[3][1], m1v;
-  node_inputs(a, lane, active, n, a.dh + n * ROW, s, v, m1s, m1v);     // row loads fly while the image is staged
+  node_inputs<ST, ST>(a, lane, active, n, a.dh, n * ROW, s, v, m1s, m1v);     // row loads fly while the image is staged
   stage_slice<IM::ND_SIZE>(lds, a.img_node, threadIdx.x);
   if (HEAD) stage_slice<IM::HD_SIZE>(lds + IM::ND_SIZE, a.img_head, threadIdx.x);
   __syncthreads();
-  node_tile<HEAD>(lds, lds + IM::ND_SIZE, lane, active, n, s, v, m1s, m1v, a.h_out, a.out);
+  node_tile<HEAD, ST>(lds, lds + IM::ND_SIZE, lane, active, n, s, v, m1s, m1v, a.h_out, a.out);
 }
 
 // ------------------------------------------------------------------ conv
@@ -305,7 +303,7 @@ struct ConvQArgs {
   // EDGE EMBEDDING STORE (sorted-edge order, EROW floats per edge = [e_s 32 | e_v 3 | pad]): gvp_edge + LayerNorm
   // (protein_gnn.py:376) does not depend on the layer, so the first conv layer may write it (e_out) and later layers
   // and the backward kernels read it (e_in) instead of re-deriving it from the raw features
-  const float* e_in; float* e_out;
+  const float* e_in; float* e_out; int64_t E;      // e_out holds E + 1 rows: row E is a spare that masked-off lanes write
 };
 constexpr int EROW = 36;
 // EMODE of the conv kernel: 0 = derive the edge embedding from the raw features (and keep it in registers),
@@ -324,7 +322,7 @@ struct ConvIn {
 
 // Gather the inputs of the pass starting at sorted-edge position `base`:
 // CSR tables -> raw edge features (original edge order) + source / target rows.
-template <int NTE, int EMODE>
+template <int NTE, int EMODE, typename ST>
 __device__ __forceinline__ void conv_gather(const ConvQArgs& a, int32_t base, int32_t e1, int lane, ConvIn& in) {
   const int i = lane & 15, g = lane >> 4;
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -345,41 +343,40 @@ __device__ __forceinline__ void conv_gather(const ConvQArgs& a, int32_t base, in
     for (int d = 0; d < 3; ++d) in.ev[j][d] = in.vj[j][d] = in.vi[j][d] = 0.f;
     if (in.active[j]) {
       if (EMODE == 2) {                                // stored embedding, sequential in sorted-edge order
-        const float* er = a.e_in + (int64_t)(base + j * TILE + i) * EROW;
-        in.es0[j] = *reinterpret_cast<const f4*>(er + 4 * g);
-        in.es1[j] = *reinterpret_cast<const f4*>(er + 16 + 4 * g);
+        const int64_t er = (int64_t)(base + j * TILE + i) * EROW;
+        in.es0[j] = Io<ST>::ld4(a.e_in, er + 4 * g);
+        in.es1[j] = Io<ST>::ld4(a.e_in, er + 16 + 4 * g);
         if (g == 0) {
 #pragma unroll
-          for (int d = 0; d < 3; ++d) in.ev[j][d] = er[ES + d];
+          for (int d = 0; d < 3; ++d) in.ev[j][d] = Io<ST>::ld(a.e_in, er + ES + d);
         }
       } else {
-        const float* er = a.e_s + (int64_t)eid[j] * EDGE_IN_S;
-        in.es0[j] = *reinterpret_cast<const f4*>(er + 4 * g);
-        in.es1[j] = *reinterpret_cast<const f4*>(er + 16 + 4 * g);
+        const int64_t er = (int64_t)eid[j] * EDGE_IN_S;
+        in.es0[j] = Io<ST>::ld4(a.e_s, er + 4 * g);
+        in.es1[j] = Io<ST>::ld4(a.e_s, er + 16 + 4 * g);
         if (g == 0) {
 #pragma unroll
-          for (int d = 0; d < 3; ++d) in.ev[j][d] = a.e_v[(int64_t)eid[j] * 3 + d];
+          for (int d = 0; d < 3; ++d) in.ev[j][d] = Io<ST>::ld(a.e_v, (int64_t)eid[j] * 3 + d);
         }
         if (NTE > 0) {
           in.et[j] = (int)a.etypes[eid[j]];
           in.et[j] = in.et[j] < 0 ? 0 : (in.et[j] >= NTE ? NTE - 1 : in.et[j]);
         }
       }
-      const float* hj = a.h + (int64_t)src[j] * ROW;
-      const float* hi = a.h + (int64_t)in.dst[j] * ROW;
-      in.sj[j] = *reinterpret_cast<const f4*>(hj + 4 * g);
-      in.si[j] = *reinterpret_cast<const f4*>(hi + 4 * g);
+      const int64_t hj = (int64_t)src[j] * ROW, hi = (int64_t)in.dst[j] * ROW;
+      in.sj[j] = Io<ST>::ld4(a.h, hj + 4 * g);
+      in.si[j] = Io<ST>::ld4(a.h, hi + 4 * g);
 #pragma unroll
-      for (int d = 0; d < 3; ++d) { in.vj[j][d] = hj[NS + 3 * g + d]; in.vi[j][d] = hi[NS + 3 * g + d]; }
+      for (int d = 0; d < 3; ++d) { in.vj[j][d] = Io<ST>::ld(a.h, hj + NS + 3 * g + d); in.vi[j][d] = Io<ST>::ld(a.h, hi + NS + 3 * g + d); }
     }
   }
 }
 
 // Message of CTN tiles: raw edge features -> gvp_edge + LayerNorm (in registers)
 // -> cat with source / target node rows -> 3 message GVPs.
-template <int NTE, int EMODE>
-__device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, int lane, float* e_out, int32_t base,
-                                           f4 (&m_s)[CTN], float (&m_v)[CTN][3]) {
+template <int NTE, int EMODE, typename ST>
+__device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, int lane, float* e_out, int64_t e_spare,
+                                           int32_t base, f4 (&m_s)[CTN], float (&m_v)[CTN][3]) {
   typedef Image<0, NTE> IM;
   const f4 (&es0)[CTN] = in.es0; const f4 (&es1)[CTN] = in.es1; const f4 (&sj)[CTN] = in.sj; const f4 (&si)[CTN] = in.si;
   const float (&ev)[CTN][3] = in.ev; const float (&vj)[CTN][3] = in.vj; const float (&vi)[CTN][3] = in.vi;
@@ -409,15 +406,27 @@ __device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, i
 #pragma unroll
     for (int j = 0; j < CTN; ++j) ln_quad<ES, EV>(img + IM::CV_ELN, lane, e_s[j], e_v[j]);
     if (EMODE == 1) {
+      // continue with the values the store will hold (bf16 storage): later layers and the backward read exactly these
+#pragma unroll
+      for (int j = 0; j < CTN; ++j) {
+        e_s[j][0] = Io<ST>::rt4(e_s[j][0]); e_s[j][1] = Io<ST>::rt4(e_s[j][1]);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) e_v[j][d][0] = Io<ST>::rt(e_v[j][d][0]);
+      }
       const int i = lane & 15, g = lane >> 4;
 #pragma unroll
-      for (int j = 0; j < CTN; ++j)
-        if (in.active[j]) {
-          float* er = e_out + (int64_t)(base + j * TILE + i) * EROW;
-          *reinterpret_cast<f4*>(er + 4 * g) = e_s[j][0];
-          *reinterpret_cast<f4*>(er + 16 + 4 * g) = e_s[j][1];
-          if (g == 0) *reinterpret_cast<f4*>(er + ES) = f4{e_v[j][0][0], e_v[j][1][0], e_v[j][2][0], 0.f};   // + zero pad
-        }
+      for (int j = 0; j < CTN; ++j) {
+        // branch-free: lanes past the wave's last edge write the store's spare row (row `e_spare` = E).  With the
+        // stores under `if (active)` hipcc duplicated the whole message body of this kernel (412 instead of 206 MFMAs).
+        // (every write to the spare row is a zero, so the row stays deterministic)
+        const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        const bool act = in.active[j], actv = act && g == 0;
+        const int64_t p = base + j * TILE + i;
+        const int64_t er = (act ? p : e_spare) * EROW, erv = (actv ? p : e_spare) * EROW;
+        Io<ST>::st4(e_out, er + 4 * g, act ? e_s[j][0] : zero4);
+        Io<ST>::st4(e_out, er + 16 + 4 * g, act ? e_s[j][1] : zero4);
+        Io<ST>::st4(e_out, erv + ES, actv ? f4{e_v[j][0][0], e_v[j][1][0], e_v[j][2][0], 0.f} : zero4);   // + zero pad
+      }
     }
   }
   STAMP(5);
@@ -477,7 +486,7 @@ __device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, i
 // segment total into the wave's private LDS accumulator.  Ownership makes the
 // result independent of scheduling: no atomics on HBM, bitwise reproducible.
 // FUSE: 0 = conv only; 1 = + node update; 2 = + node update with the output head
-template <int NTE, int FUSE, int EMODE>
+template <int NTE, int FUSE, int EMODE, typename ST>
 __global__ __launch_bounds__(TPB) void conv_quad_kernel(ConvQArgs a) {
   typedef Image<0, NTE> IM;
   typedef Image<0, 0> IMN;
@@ -495,7 +504,9 @@ __global__ __launch_bounds__(TPB) void conv_quad_kernel(ConvQArgs a) {
   // The first pass's gathers (3 dependent hops) are issued BEFORE the image is
   // staged so that their latency hides behind the staging traffic and barrier.
   ConvIn in;
-  conv_gather<NTE, EMODE>(a, e0, e1, lane, in);
+  conv_gather<NTE, EMODE, ST>(a, e0, e1, lane, in);
+  if (EMODE == 1 && blockIdx.x == 0 && threadIdx.x < EROW / 4)        // the store's spare row is always all zeros
+    Io<ST>::st4(a.e_out, a.E * EROW + 4 * threadIdx.x, f4{0.f, 0.f, 0.f, 0.f});
   stage_slice<IM::CV_SIZE>(img, a.img, threadIdx.x);
   if (FUSE > 0) stage_slice<IMN::ND_SIZE>(nd_img, a.node.img_node, threadIdx.x);
   if (FUSE == 2) stage_slice<IMN::HD_SIZE>(nd_img + IMN::ND_SIZE, a.node.img_head, threadIdx.x);
@@ -506,13 +517,13 @@ __global__ __launch_bounds__(TPB) void conv_quad_kernel(ConvQArgs a) {
 
   const int i = lane & 15, g = lane >> 4;
   for (int32_t base = e0; base < e1; base += CTN * TILE) {
-    if (base != e0) conv_gather<NTE, EMODE>(a, base, e1, lane, in);
+    if (base != e0) conv_gather<NTE, EMODE, ST>(a, base, e1, lane, in);
     const int32_t (&dst)[CTN] = in.dst;
     const bool (&active)[CTN] = in.active;
     f4 m_s[CTN];
     float m_v[CTN][3];
     STAMP(3);
-    conv_tiles<NTE, EMODE>(img, in, lane, a.e_out, base, m_s, m_v);
+    conv_tiles<NTE, EMODE, ST>(img, in, lane, a.e_out, a.E, base, m_s, m_v);
     STAMP(6);
 #pragma unroll
     for (int j = 0; j < CTN; ++j) {
@@ -540,7 +551,6 @@ __global__ __launch_bounds__(TPB) void conv_quad_kernel(ConvQArgs a) {
   __syncthreads();
   STAMP(8);
   if (nn > 0) {
-    float* out = a.dh ? a.dh + n0 * ROW : nullptr;
     for (int k = lane; k < nn * ROW; k += WAVE) {
       float v = acc[k];
       if (a.mean) {
@@ -549,7 +559,10 @@ __global__ __launch_bounds__(TPB) void conv_quad_kernel(ConvQArgs a) {
         v = v / (float)(deg > 1 ? deg : 1);
         if (FUSE > 0) acc[k] = v;
       }
-      if (out) out[k] = v;            // kept for the backward pass; inference passes no dh buffer when fused
+      if (a.dh) {                                             // kept for the backward pass; inference passes no dh buffer when fused
+        Io<ST>::st(a.dh, n0 * ROW + k, v);
+        if (FUSE > 0) acc[k] = Io<ST>::rt(v);                 // the fused node update continues with what the backward will re-read
+      }
     }
   }
   STAMP(9);
@@ -564,8 +577,8 @@ __global__ __launch_bounds__(TPB) void conv_quad_kernel(ConvQArgs a) {
       const int64_t n = n0 + k;
       f4 s[1], m1s;
       float v[3][1], m1v;
-      node_inputs(a.node, lane, act, n, acc + (act ? k : 0) * ROW, s, v, m1s, m1v);
-      node_tile<FUSE == 2>(nd_img, nd_img + IMN::ND_SIZE, lane, act, n, s, v, m1s, m1v, a.node.h_out, a.node.out);
+      node_inputs<ST, float>(a.node, lane, act, n, acc, (int64_t)(act ? k : 0) * ROW, s, v, m1s, m1v);
+      node_tile<FUSE == 2, ST>(nd_img, nd_img + IMN::ND_SIZE, lane, act, n, s, v, m1s, m1v, a.node.h_out, a.node.out);
     }
   }
 }
@@ -620,31 +633,39 @@ int prepare(const EncLayout& L, int num_convs, const float* params, float* image
 }
 
 int node_embed(int nt_node, const float* img, const float* x_s, const float* x_v, const int64_t* ntypes,
-               int64_t N, float* h, unsigned long long* rng_state, unsigned long long* rng_out, hipStream_t st) {
+               int64_t N, float* h, unsigned long long* rng_state, unsigned long long* rng_out, int bf16, hipStream_t st) {
   EmbedQArgs a{img, x_s, x_v, ntypes, N, h, rng_state, rng_out};
   const dim3 grid((unsigned)((N + WPB * TILE - 1) / (WPB * TILE)));
+#define EMB_LAUNCH(NT) { if (bf16) hipLaunchKernelGGL((embed_quad_kernel<NT, bf16s>), grid, dim3(TPB), 0, st, a); \
+                         else hipLaunchKernelGGL((embed_quad_kernel<NT, float>), grid, dim3(TPB), 0, st, a); }
   switch (nt_node) {
-    case 0: hipLaunchKernelGGL(embed_quad_kernel<0>, grid, dim3(TPB), 0, st, a); break;
-    case 20: hipLaunchKernelGGL(embed_quad_kernel<20>, grid, dim3(TPB), 0, st, a); break;
-    case 21: hipLaunchKernelGGL(embed_quad_kernel<21>, grid, dim3(TPB), 0, st, a); break;
+    case 0: EMB_LAUNCH(0) break;
+    case 20: EMB_LAUNCH(20) break;
+    case 21: EMB_LAUNCH(21) break;
     default: return CGVP_ERR_UNSUPPORTED_DIMS;
   }
+#undef EMB_LAUNCH
   return 0;
 }
 
-template <int NTE, int FUSE, int EMODE>
+template <int NTE, int FUSE, int EMODE, typename ST>
 void conv_launch_e(const ConvQArgs& a, dim3 grid, hipStream_t st) {
   const size_t lds = (size_t)(Image<0, NTE>::CV_SIZE + (FUSE == 0 ? 0 : Image<0, 0>::ND_SIZE + (FUSE == 2 ? Image<0, 0>::HD_SIZE : 0)) +
                               WPB * WAVE * ROW) * sizeof(float);
   if (lds > 64 * 1024)      // a failure here resurfaces as the launch error launch_status() reports
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_quad_kernel<NTE, FUSE, EMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((conv_quad_kernel<NTE, FUSE, EMODE>), grid, dim3(TPB), lds, st, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_quad_kernel<NTE, FUSE, EMODE, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((conv_quad_kernel<NTE, FUSE, EMODE, ST>), grid, dim3(TPB), lds, st, a);
+}
+template <int NTE, int FUSE, typename ST>
+void conv_launch_s(const ConvQArgs& a, dim3 grid, hipStream_t st) {
+  if (a.e_in) conv_launch_e<NTE, FUSE, 2, ST>(a, grid, st);
+  else if (a.e_out) conv_launch_e<NTE, FUSE, 1, ST>(a, grid, st);
+  else conv_launch_e<NTE, FUSE, 0, ST>(a, grid, st);
 }
 template <int NTE, int FUSE>
-void conv_launch(const ConvQArgs& a, dim3 grid, hipStream_t st) {
-  if (a.e_in) conv_launch_e<NTE, FUSE, 2>(a, grid, st);
-  else if (a.e_out) conv_launch_e<NTE, FUSE, 1>(a, grid, st);
-  else conv_launch_e<NTE, FUSE, 0>(a, grid, st);
+void conv_launch(const ConvQArgs& a, dim3 grid, int bf16, hipStream_t st) {
+  if (bf16) conv_launch_s<NTE, FUSE, bf16s>(a, grid, st);
+  else conv_launch_s<NTE, FUSE, float>(a, grid, st);
 }
 
 // fuse: 0 = conv only (dh required); 1 / 2 = the layer's node update (2: with the output head) in the same launch
@@ -652,33 +673,38 @@ int conv(int nt_edge, const float* img, const float* h, const float* e_s, const 
          const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
          const int32_t* edst, int64_t N, int64_t E, int mean, float* dh, int fuse, const float* img_node,
          const float* img_head, float* h_out, float* out, const float* mask0, const float* mask1, gvp::RngArgs rng,
-         const float* e_in, float* e_out, hipStream_t st) {
+         const float* e_in, float* e_out, int bf16, hipStream_t st) {
   // target nodes per wave: one pass of CTN lockstep 16-edge tiles (~30 edges) per wave
   int64_t deg = N > 0 ? (E + N - 1) / N : 1;
   if (deg < 1) deg = 1;
   int npw = (int)((CTN * TILE - 2) / deg);
   npw = npw < 1 ? 1 : (npw > WAVE ? WAVE : npw);
   ConvQArgs a{img, h, e_s, e_v, etypes, rowptr, eperm, esrc, edst, N, npw, mean, dh,
-              NodeQArgs{img_node, img_head, h, nullptr, N, h_out, out, mask0, mask1, rng}, e_in, e_out};
+              NodeQArgs{img_node, img_head, h, nullptr, N, h_out, out, mask0, mask1, rng}, e_in, e_out, E};
   const int64_t groups = (N + npw - 1) / npw;
   const dim3 grid((unsigned)((groups + WPB - 1) / WPB));
   if (nt_edge != 0 && nt_edge != 1) return CGVP_ERR_UNSUPPORTED_DIMS;
   if (fuse < 0 || fuse > 2) return CGVP_ERR_BAD_ARG;
   if (nt_edge == 0) {
-    if (fuse == 0) conv_launch<0, 0>(a, grid, st); else if (fuse == 1) conv_launch<0, 1>(a, grid, st); else conv_launch<0, 2>(a, grid, st);
+    if (fuse == 0) conv_launch<0, 0>(a, grid, bf16, st); else if (fuse == 1) conv_launch<0, 1>(a, grid, bf16, st); else conv_launch<0, 2>(a, grid, bf16, st);
   } else {
-    if (fuse == 0) conv_launch<1, 0>(a, grid, st); else if (fuse == 1) conv_launch<1, 1>(a, grid, st); else conv_launch<1, 2>(a, grid, st);
+    if (fuse == 0) conv_launch<1, 0>(a, grid, bf16, st); else if (fuse == 1) conv_launch<1, 1>(a, grid, bf16, st); else conv_launch<1, 2>(a, grid, bf16, st);
   }
   return 0;
 }
 
 int node_update(const float* img_node, const float* img_head, const float* h, const float* dh, int64_t N,
                 int with_head, float* h_out, float* out, const float* mask0, const float* mask1, gvp::RngArgs rng,
-                hipStream_t st) {
+                int bf16, hipStream_t st) {
   NodeQArgs a{img_node, img_head, h, dh, N, h_out, out, mask0, mask1, rng};
   const dim3 grid((unsigned)((N + WPB * TILE - 1) / (WPB * TILE)));
-  if (with_head) hipLaunchKernelGGL(node_quad_kernel<true>, grid, dim3(TPB), 0, st, a);
-  else hipLaunchKernelGGL(node_quad_kernel<false>, grid, dim3(TPB), 0, st, a);
+  if (bf16) {
+    if (with_head) hipLaunchKernelGGL((node_quad_kernel<true, bf16s>), grid, dim3(TPB), 0, st, a);
+    else hipLaunchKernelGGL((node_quad_kernel<false, bf16s>), grid, dim3(TPB), 0, st, a);
+  } else {
+    if (with_head) hipLaunchKernelGGL((node_quad_kernel<true, float>), grid, dim3(TPB), 0, st, a);
+    else hipLaunchKernelGGL((node_quad_kernel<false, float>), grid, dim3(TPB), 0, st, a);
+  }
   return 0;
 }
 

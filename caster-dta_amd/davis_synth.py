@@ -232,7 +232,12 @@ def real_lengths(dataset, n, seed):
     import os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
                         "protein_lengths.json")
-    table = np.asarray(json.load(open(path))[dataset])
+    if dataset == "bindingdb":
+        # no BindingDB sequences ship with the reference; its length filter is 25..3000 (dataset/load_data.py:218-222)
+        # and the shipped example batch averages 558 residues (model_summary.txt): the KIBA table rescaled to that mean
+        table = np.clip(np.rint(np.asarray(json.load(open(path))["kiba"]) * (558.0 / 729.0)), 25, 3000).astype(int)
+    else:
+        table = np.asarray(json.load(open(path))[dataset])
     return [int(v) for v in np.random.default_rng(seed).choice(table, size=n, replace=True)]
 
 

@@ -15,11 +15,11 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CGVP_LIB_PATH: A/B builds of the same ABI (diagnostics); the default is the in-tree library
 LIB_PATH = os.environ.get("CGVP_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libcaster_gvp.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 # sha256 of include/caster_gvp.h with comments, blank space and the CGVP_ABI_VERSION line removed, as
 # `abi_header_digest()` computes it.  tests/test_abi.py fails when the header's declarations change
 # without CGVP_ABI_VERSION, ABI_VERSION and this digest being updated together.
-ABI_HEADER_SHA256 = "c41d39f5bcb062b31c7e63ca5121070fcc4a9744d07cbc2b16547144e6593d81"
+ABI_HEADER_SHA256 = "ca84f348040cd833dae7c562ebdbc85de8c88e21dd23bd4fdd367860e5e99f82"
 
 
 class HipLibraryError(RuntimeError):
@@ -29,7 +29,7 @@ class HipLibraryError(RuntimeError):
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "node_in_s", "node_in_v", "edge_in_s", "edge_in_v", "hidden_s", "hidden_v",
-        "edge_hidden_s", "edge_hidden_v", "out_s")]
+        "edge_hidden_s", "edge_hidden_v", "out_s", "storage")]
 
 
 class Layout(C.Structure):

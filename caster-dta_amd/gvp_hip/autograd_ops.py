@@ -32,13 +32,13 @@ import torch
 from torch import Tensor
 
 from . import _lib, ops
-from .ops import EROW, ROW, _f32, _i64, _ptr, _stream
+from .ops import EROW, ROW, _act, _f32, _i64, _ptr, _stream
 
 MROW = 20   # dropout mask row: 16 scalar-channel + 4 vector-channel factors
 # `cfg` argument of the LBA ops: the nine cgvp_dims fields, then these
 _CFG_FIELDS = ("node_in_s", "node_in_v", "edge_in_s", "edge_in_v", "hidden_s", "hidden_v", "edge_hidden_s",
                "edge_hidden_v", "out_s")
-CFG_NTN, CFG_NTE, CFG_NC, CFG_MEAN, CFG_LEN = 9, 10, 11, 12, 13
+CFG_NTN, CFG_NTE, CFG_NC, CFG_MEAN, CFG_LEN = 9, 10, 11, 12, 13     # the activation storage type is NOT in cfg: it follows x_s.dtype
 
 
 # Test hook: a callable (count, n, width, p, device) -> [count, n, width] fp32 tensor of EXPLICIT dropout factors
@@ -86,8 +86,9 @@ def make_cfg(dims, num_ntypes, num_etypes, num_convs, aggr_mean):
                                                            1 if aggr_mean else 0]
 
 
-def _dims_layout(cfg):
-    dims = ops.make_dims(**{f: cfg[i] for i, f in enumerate(_CFG_FIELDS)})
+def _dims_layout(cfg, sdt=torch.float32):
+    dims = ops.make_dims(storage=ops.BF16 if sdt == torch.bfloat16 else ops.F32,
+                         **{f: cfg[i] for i, f in enumerate(_CFG_FIELDS)})
     return dims, ops.lba_layout(dims, cfg[CFG_NTN], cfg[CFG_NTE], cfg[CFG_NC])
 
 
@@ -133,9 +134,10 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
     if ops.VARIANT != "mfma" and save_state:
         raise NotImplementedError("training / gradients need the MFMA kernels (CGVP_VARIANT=mfma)")
     L = _lib.lib()
-    dims, layout = _dims_layout(cfg)
+    sdt = ops.storage_dtype(x_s)                       # activation storage: bf16 when the features arrive in bf16
+    dims, layout = _dims_layout(cfg, sdt)
     nc, mean = cfg[CFG_NC], bool(cfg[CFG_MEAN])
-    x_s, x_v, e_s, e_v = _f32(x_s, "x_s"), _f32(x_v, "x_v"), _f32(e_s, "eattr_s"), _f32(e_v, "eattr_v")
+    x_s, x_v, e_s, e_v = _act(x_s, "x_s", sdt), _act(x_v, "x_v", sdt), _act(e_s, "eattr_s", sdt), _act(e_v, "eattr_v", sdt)
     N, E = int(x_s.shape[0]), int(e_s.shape[0])
     dev = x_s.device
     flat = flat_arena(params)
@@ -143,18 +145,20 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
         raise RuntimeError(f"parameter arena has {flat.numel()} floats, kernels expect {layout.total}")
     image = fragment_image(params, flat, layout, dims) if ops.VARIANT == "mfma" else None
     csr = ops.csr_for_forward(edge_index, N)
-    f32 = dict(dtype=torch.float32, device=dev)
+    f32, act = dict(dtype=torch.float32, device=dev), dict(dtype=sdt, device=dev)
     if not save_state:
         out = ops.lba_encoder_forward(flat, layout, dims, nc, x_s, x_v, ntypes, e_s, e_v, etypes, csr,
                                       aggr_mean=mean, image=image)
-        return (out, torch.empty(0, **f32), torch.empty(0, **f32), torch.empty(0, dtype=torch.int64, device=dev),
-                torch.empty(0, **f32))
+        return (out, torch.empty(0, **act), torch.empty(0, **f32), torch.empty(0, dtype=torch.int64, device=dev),
+                torch.empty(0, **act))
     if tuple(x_s.shape) != (N, dims.node_in_s) or tuple(x_v.shape) != (N, dims.node_in_v, 3) or \
             tuple(e_s.shape) != (E, dims.edge_in_s) or tuple(e_v.shape) != (E, dims.edge_in_v, 3):
         raise NotImplementedError("feature shapes do not match the compiled CASTER-DTA configuration")
     nt = _i64(ntypes, "ntypes") if layout.nt_node > 0 else None
     et = _i64(etypes, "etypes") if layout.nt_edge > 0 else None
-    state = torch.empty(2 * nc + 1, N, ROW, **f32)
+    state = torch.empty(2 * nc + 1, N + (N & 1), ROW, **act)      # even row count: every slice stays 16-B aligned in bf16 too
+    if N & 1:
+        state[:, N].zero_()                                       # the pad row is an op output: keep it deterministic
     hs, dhs, h_last = [state[l] for l in range(nc)], [state[nc + l] for l in range(nc)], state[2 * nc]
     masks, mk, seed = torch.empty(0, **f32), [(None, None)] * nc, torch.empty(0, dtype=torch.int64, device=dev)
     if dropout_p > 0 and PINNED_MASKS is not None:
@@ -164,8 +168,8 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
         seed = torch.empty(2, dtype=torch.int64, device=dev)      # filled by the node-embed kernel (below)
         _LAST_SEED["lba"] = seed
     rstate = rng_state("lba", dev) if seed.numel() else None
-    out = torch.empty(N, dims.out_s, **f32)
-    e_emb = torch.empty(max(E, 1), EROW, **f32)
+    out = torch.empty(N, dims.out_s, **act)
+    e_emb = torch.empty(E + 1, EROW, **act)
     with torch.cuda.device(dev):
         st = _stream()
         d, lay, P, I = C.byref(dims), C.byref(layout), _ptr(flat), _ptr(image)
@@ -199,15 +203,16 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
 @lba_encoder_op.register_fake
 def _(params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, cfg, dropout_p, save_state):
     N, nc = x_s.shape[0], cfg[CFG_NC]
-    out = x_s.new_empty((N, cfg[8]), dtype=torch.float32)
+    sdt = torch.bfloat16 if x_s.dtype == torch.bfloat16 else torch.float32
+    out = x_s.new_empty((N, cfg[8]), dtype=sdt)
     e32, e64 = x_s.new_empty((0,), dtype=torch.float32), x_s.new_empty((0,), dtype=torch.int64)
     if not save_state:
-        return out, e32, e32, e64, x_s.new_empty((0,), dtype=torch.float32)
+        return out, x_s.new_empty((0,), dtype=sdt), e32, e64, x_s.new_empty((0,), dtype=sdt)
     pinned = dropout_p > 0 and PINNED_MASKS is not None
     masks = x_s.new_empty((2 * nc, N, MROW), dtype=torch.float32) if pinned else e32
     seed = x_s.new_empty((2,), dtype=torch.int64) if dropout_p > 0 and not pinned else e64
-    e_emb = x_s.new_empty((torch.sym_max(e_s.shape[0], 1), EROW), dtype=torch.float32)
-    return out, x_s.new_empty((2 * nc + 1, N, ROW), dtype=torch.float32), masks, seed, e_emb
+    e_emb = x_s.new_empty((e_s.shape[0] + 1, EROW), dtype=sdt)
+    return out, x_s.new_empty((2 * nc + 1, (N + 1) // 2 * 2, ROW), dtype=sdt), masks, seed, e_emb
 
 
 @torch.library.custom_op("caster_gvp::lba_encoder_backward", mutates_args=(), device_types="cuda")
@@ -217,9 +222,11 @@ def lba_encoder_backward_op(g_out: Tensor, params: List[Tensor], x_s: Tensor, x_
                             need_x: bool) -> Tuple[Tensor, Tensor, Tensor]:
     """-> (grad arena [layout.total], g_x_s [N, 17], g_x_v [N, 3, 3]) (the latter two empty unless need_x)."""
     L = _lib.lib()
-    dims, layout = _dims_layout(cfg)
+    sdt = ops.storage_dtype(x_s)
+    dims, layout = _dims_layout(cfg, sdt)
     nc, mean = cfg[CFG_NC], bool(cfg[CFG_MEAN])
-    x_s, x_v, e_s, e_v = _f32(x_s, "x_s"), _f32(x_v, "x_v"), _f32(e_s, "eattr_s"), _f32(e_v, "eattr_v")
+    x_s, x_v, e_s, e_v = _act(x_s, "x_s", sdt), _act(x_v, "x_v", sdt), _act(e_s, "eattr_s", sdt), _act(e_v, "eattr_v", sdt)
+    state, e_emb = _act(state, "state", sdt), _act(e_emb, "e_emb", sdt)
     N, E = int(x_s.shape[0]), int(e_s.shape[0])
     dev = x_s.device
     nt = _i64(ntypes, "ntypes") if layout.nt_node > 0 else None
@@ -229,7 +236,7 @@ def lba_encoder_backward_op(g_out: Tensor, params: List[Tensor], x_s: Tensor, x_
     csr = ops.csr_for_backward(edge_index, N)
     hs, dhs, h_last = [state[l] for l in range(nc)], [state[nc + l] for l in range(nc)], state[2 * nc]
     mk = [(masks[2 * l], masks[2 * l + 1]) for l in range(nc)] if masks.numel() else [(None, None)] * nc
-    g_out = _f32(g_out, "grad_output")
+    g_out = _f32(g_out.float(), "grad_output")               # every gradient buffer is fp32, whatever the storage type
     f32 = dict(dtype=torch.float32, device=dev)
     gparams = torch.empty(layout.total, **f32)        # every element is STORED by the final reduce (disjoint segments)
     # every stage writes its per-workgroup partial weight-gradient blocks into its own region of
@@ -237,7 +244,7 @@ def lba_encoder_backward_op(g_out: Tensor, params: List[Tensor], x_s: Tensor, x_
     wsz = int(L.cgvp_bwd_workspace_floats(C.byref(dims), C.byref(layout)))
     nstage = 2 * nc + 2
     ws_all = torch.empty(nstage * wsz, **f32)
-    g_e = torch.empty(nc, max(E, 1), EROW, **f32)         # d(edge embedding) of every conv layer, summed by the edge stage
+    g_e = torch.empty(nc, E + 1, EROW, **f32)         # d(edge embedding) of every conv layer, summed by the edge stage
     segs = (_lib.Segment * (2 * nstage))()
     nseg, stage = 0, 0
     cnt = C.c_int32(0)
@@ -332,6 +339,8 @@ def _lba_backward(ctx, g_out, g_state, g_masks, g_seed, g_e_emb):
         g_out.contiguous(), params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, seed, e_emb, ctx.cfg,
         ctx.dropout_p, need_x)
     grads = [g.view(s) for g, s in zip(torch.split(gflat, [_numel(s) for s in ctx.shapes]), ctx.shapes)]
+    if need_x and x_s.dtype != torch.float32:                 # input gradients are produced in fp32
+        g_x_s, g_x_v = g_x_s.to(x_s.dtype), g_x_v.to(x_v.dtype)
     return (grads, g_x_s if need_x else None, g_x_v if need_x else None, None, None, None, None, None, None, None,
             None)
 

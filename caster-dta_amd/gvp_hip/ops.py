@@ -14,7 +14,8 @@ from . import _lib
 from ._lib import Dims, GineW, Layout, Rng
 
 CASTER_DIMS = dict(node_in_s=17, node_in_v=3, edge_in_s=32, edge_in_v=1, hidden_s=16, hidden_v=4,
-                   edge_hidden_s=32, edge_hidden_v=1, out_s=64)
+                   edge_hidden_s=32, edge_hidden_v=1, out_s=64, storage=0)
+F32, BF16 = 0, 1   # cgvp_dims.storage: element type of the activation buffers ("bf16 storage / fp32 accumulate")
 ROW = 28  # merged node row: 16 scalars + 4x3 vector channels
 EROW = 36  # stored edge embedding row (CGVP_EDGE_ROW): 32 scalars + 1x3 vector + pad, sorted-edge order
 
@@ -37,6 +38,27 @@ def _f32(t, name):
     if t.data_ptr() % 16:
         t = t.clone()
     return t
+
+
+def _act(t, name, dtype):
+    """An ACTIVATION buffer (features, node rows, edge-embedding store): contiguous, 16-B aligned, of the pass's
+    storage dtype (torch.float32 or torch.bfloat16 -- cast here if the caller mixed them)."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: caster-dta_amd runs on MI355X only (got a {t.device} tensor); "
+                           "there is no CPU path")
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"{name}: expected float32 or bfloat16, got {t.dtype}")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+def storage_dtype(*tensors):
+    """bf16 storage when the node features arrive in bf16, fp32 otherwise."""
+    return torch.bfloat16 if tensors[0].dtype == torch.bfloat16 else torch.float32
 
 
 def _i64(t, name):
@@ -252,8 +274,9 @@ def lba_encoder_forward(params, layout, dims, num_convs, x_s, x_v, ntypes, e_s, 
     as 1 + 2*num_convs launches: node embed, then (conv, node update) per layer
     with the output head fused into the last node update."""
     L = _lib.lib()
-    x_s, x_v = _f32(x_s, "x_s"), _f32(x_v, "x_v")
-    e_s, e_v = _f32(e_s, "eattr_s"), _f32(e_v, "eattr_v")
+    sdt = torch.bfloat16 if dims.storage == BF16 else torch.float32
+    x_s, x_v = _act(x_s, "x_s", sdt), _act(x_v, "x_v", sdt)
+    e_s, e_v = _act(e_s, "eattr_s", sdt), _act(e_v, "eattr_v", sdt)
     N, E = int(x_s.shape[0]), int(e_s.shape[0])
     if tuple(x_s.shape) != (N, dims.node_in_s) or tuple(x_v.shape) != (N, dims.node_in_v, 3):
         raise NotImplementedError(f"node features {tuple(x_s.shape)}/{tuple(x_v.shape)} do not match the "
@@ -268,12 +291,12 @@ def lba_encoder_forward(params, layout, dims, num_convs, x_s, x_v, ntypes, e_s, 
     nt = _i64(ntypes, "ntypes") if layout.nt_node > 0 else None
     et = _i64(etypes, "etypes") if layout.nt_edge > 0 else None
     dev = x_s.device
-    h = torch.empty(N, ROW, dtype=torch.float32, device=dev)
-    h2 = torch.empty(N, ROW, dtype=torch.float32, device=dev)
+    h = torch.empty(N, ROW, dtype=sdt, device=dev)
+    h2 = torch.empty(N, ROW, dtype=sdt, device=dev)
     # edge embedding store: layer 0 writes gvp_edge + LayerNorm of every edge (sorted order), later layers read it
-    e_emb = torch.empty(max(E, 1), EROW, dtype=torch.float32, device=dev) if (VARIANT == "mfma" and num_convs > 1) else None
-    dh = torch.empty(N, ROW, dtype=torch.float32, device=dev)
-    out = torch.empty(N, dims.out_s, dtype=torch.float32, device=dev)
+    e_emb = torch.empty(E + 1, EROW, dtype=sdt, device=dev) if (VARIANT == "mfma" and num_convs > 1) else None
+    dh = torch.empty(N, ROW, dtype=sdt, device=dev)
+    out = torch.empty(N, dims.out_s, dtype=sdt, device=dev)
     stages = {}
     if VARIANT == "mfma" and image is None:
         image = prepare_image(params, layout, dims)

@@ -245,6 +245,11 @@ class JointGNN(nn.Module):
         mbatch = molecule_graph_data.get("batch", None)
         residue = self.protein_gnn(**{k: v for k, v in protein_graph_data.items() if k != "ptr"})    # MI355X kernels
         atom = self.molecule_gnn(**{k: v for k, v in molecule_graph_data.items() if k != "ptr"})     # MI355X kernels
+        hdt = self.output_layer.weight.dtype
+        if residue.dtype != hdt and not torch.is_autocast_enabled():   # bf16-storage encoders feeding an fp32 head
+            residue = residue.to(hdt)
+        if atom.dtype != hdt and not torch.is_autocast_enabled():
+            atom = atom.to(hdt)
         residue = self._stack(residue, self.residue_lins, self.residue_norms)
         atom = self._stack(atom, self.atom_lins, self.atom_norms)
         attn = None

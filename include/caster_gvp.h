@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 18
+#define CGVP_ABI_VERSION 19
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
@@ -70,7 +70,17 @@ typedef struct {
   int32_t hidden_s, hidden_v;       /* 16, 4 */
   int32_t edge_hidden_s, edge_hidden_v; /* 32, 1 */
   int32_t out_s;                    /* 64 */
+  int32_t storage;                  /* CGVP_F32 (0) or CGVP_BF16 (1): element type of the ACTIVATION buffers, see below */
 } cgvp_dims;
+/* ACTIVATION STORAGE ("bf16 storage / fp32 accumulate", BASELINE config 5; MFMA kernels only).  With
+ * dims->storage == CGVP_BF16 every activation buffer of the protein entry points -- x_s, x_v, e_s, e_v, the node rows
+ * h / dh / h_out, the edge-embedding store e_in / e_out / e_emb and the residue embeddings out -- holds bfloat16
+ * (2-byte) elements with the same shapes and element strides, passed through the `float*` parameters below.  Loads
+ * widen to fp32; all arithmetic, LayerNorm statistics, MFMA accumulation, the parameter arena / fragment image and
+ * EVERY gradient buffer (g_*, grad_params, workspace) and dropout mask stay fp32; stores round to nearest even.
+ * This halves the activation bytes of SURVEY 8(d)'s model: (300 + 112 L) N + (148 + 86 L) E per pass. */
+#define CGVP_F32 0
+#define CGVP_BF16 1
 
 /* Destination-sorted CSR of a batched graph.  Replaces the gather/scatter
  * bookkeeping inside PyG MessagePassing.propagate (called at
@@ -140,6 +150,7 @@ int cgvp_node_embed_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
  * EDGE EMBEDDING STORE (MFMA kernels; both optional).  gvp_edge + LayerNorm does not depend on the conv layer.
  * With e_out != NULL the call also writes it, in SORTED-edge order (the CSR position p, not the original edge
  * id): CGVP_EDGE_ROW floats per edge = [e_s 32 | e_v 3 | pad].  With e_in != NULL the call reads that store
+ * (the buffer must hold num_edges + 1 rows: row num_edges is a spare that masked-off lanes write zeros to)
  * sequentially instead of gathering and re-embedding the raw features (e_s / e_v / etypes / eperm are then
  * unused and may be NULL).  The host code lets layer 0 write it and every later layer -- and every conv
  * backward -- read it: this is exactly SURVEY 8(d)'s byte model (embed writes 140 B/edge, each conv reads them). */

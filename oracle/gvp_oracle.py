@@ -127,6 +127,15 @@ def gvp_conv(P, pfx, x, edge_index, edge_attr, n_layers=3, aggr="mean",
     return out[:, :-3 * nv], out[:, -3 * nv:].reshape(n, nv, 3)      # :301 _split
 
 
+def _ste_round(t, dtype):
+    """Round to `dtype` and back (what storing an activation in that type does), with a straight-through gradient."""
+    if dtype is None:
+        return t
+    if isinstance(t, tuple):
+        return tuple(_ste_round(u, dtype) for u in t)
+    return t + (t.to(dtype).to(t.dtype) - t).detach()
+
+
 # --------------------------------------------------------------------------- a7
 def _apply_mask(t, mask):
     """gvp_layers.Dropout with a GIVEN mask row [s factors | v-channel factors]
@@ -138,12 +147,14 @@ def _apply_mask(t, mask):
 
 
 def gvp_conv_layer(P, pfx, x, edge_index, edge_attr, n_message=3, n_feedforward=2,
-                   aggr="mean", activations=("relu", "sigmoid"), vector_gate=False, masks=(None, None)):
+                   aggr="mean", activations=("relu", "sigmoid"), vector_gate=False, masks=(None, None),
+                   store_dtype=None):
     """gvp_layers.py:366-415 without the autoregressive / node_mask branches.
     Eval mode by default (dropout = identity, :192-193); `masks` supplies the two
     dropout masks explicitly to check the training kernels."""
     nv = x[1].shape[1]
     dh = gvp_conv(P, pfx + "conv.", x, edge_index, edge_attr, n_message, aggr, activations, vector_gate)
+    dh = _ste_round(dh, store_dtype)          # the aggregated messages are a stored stage hand-off (see protein_lba_forward)
     dh = _apply_mask(dh, masks[0])
     x = gvp_layernorm(P, pfx + "norm.0.", (x[0] + dh[0], x[1] + dh[1]), nv)     # :407
     h = x
@@ -162,8 +173,12 @@ def gvp_conv_layer(P, pfx, x, edge_index, edge_attr, n_message=3, n_feedforward=
 
 # --------------------------------------------------------------------------- a8/a9
 def protein_lba_forward(P, x, edge_index, ntypes, etypes, eattr, num_ntypes=20, num_etypes=1,
-                        num_convs=2, aggr="sum", pfx="", return_stages=False, masks=None):
+                        num_convs=2, aggr="sum", pfx="", return_stages=False, masks=None, store_dtype=None):
     """protein_gnn.py:361-388 (VectorProteinGNN_LBAModel.forward), eval mode.
+
+    `store_dtype` (e.g. torch.bfloat16) emulates an implementation that keeps the activations it hands from stage to
+    stage in that type: the node embedding, the edge embedding, every layer's aggregated messages and output and the
+    result are rounded to it (straight-through gradient) -- the checker of the bf16-storage kernels.
 
     One-hot node / edge types are concatenated IN FRONT of the scalar features
     (protein_gnn.py:139-152).  GVP activations are (ReLU, None) with
@@ -181,15 +196,17 @@ def protein_lba_forward(P, x, edge_index, ntypes, etypes, eattr, num_ntypes=20, 
     h = gvp(P, pfx + "gvp_node.0.", (x_s, x_v), x_v.shape[1], hv, None, None, True)
     h = gvp_layernorm(P, pfx + "gvp_node.1.", h, hv)                            # :375
     e = gvp(P, pfx + "gvp_edge.0.", (e_s, e_v), e_v.shape[1], ev, None, None, True)
-    e = gvp_layernorm(P, pfx + "gvp_edge.1.", e, ev)                            # :376
+    e = _ste_round(gvp_layernorm(P, pfx + "gvp_edge.1.", e, ev), store_dtype)   # :376
+    h = _ste_round(h, store_dtype)
     stages["node_embed"] = h
     stages["edge_embed"] = e
     for l in range(num_convs):                                                  # :379-380
-        h = gvp_conv_layer(P, f"{pfx}conv_list.{l}.", h, edge_index, e, 3, 2, aggr, ("relu", None), True,
-                           masks[l] if masks is not None else (None, None))
+        h = gvp_conv_layer(P, f"{pfx}conv_list.{l}.", h, edge_index, e, 3, 2,
+                           aggr, ("relu", None), True, masks[l] if masks is not None else (None, None), store_dtype)
+        h = _ste_round(h, store_dtype)
         stages[f"conv{l}"] = h
     h = gvp_layernorm(P, pfx + "gvp_norm_before_scalar.", h, hv)                # :385
-    out = gvp(P, pfx + "gvp_to_scalar.", h, hv, 0, "relu", None, True)          # :386
+    out = _ste_round(gvp(P, pfx + "gvp_to_scalar.", h, hv, 0, "relu", None, True), store_dtype)   # :386
     return (out, stages) if return_stages else out
 
 

@@ -1,0 +1,106 @@
+"""bf16 storage / fp32 accumulate (BASELINE config 5; cgvp_dims.storage = CGVP_BF16): features, node rows, the
+edge-embedding store and the residue embeddings live in HBM as bfloat16, every load widens to fp32 and all arithmetic,
+MFMA accumulation, LayerNorm statistics and gradient buffers stay fp32.
+
+Checker: the fp32 oracle on the SAME bf16-rounded inputs with `store_dtype=torch.bfloat16`, i.e. rounding the same
+stage hand-offs to bf16 (node embedding, re-read edge embedding, layer outputs, result; straight-through gradient).
+(The kernels continue with the ROUNDED value wherever they store an activation and keep using it -- the edge embedding
+in the layer that derives it, the aggregated messages in the fused layer kernel -- so their forward and backward see
+the same numbers, exactly like this emulation.)  Stated tolerance: what is left between the two is fp32 summation order
+plus the occasional 1-ulp bf16 flip at a rounding boundary (2^-8 relative on single elements): outputs within 1.5e-2 of
+the output scale, every gradient tensor within 6e-2 in the L2 norm.  Against the fp32-storage kernels on the same inputs the outputs stay within 3e-2; the bf16 path repeats
+bitwise."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import davis_synth as ds
+from conftest import GOLDEN, rel_err
+from oracle import gvp_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+FWD_TOL, GRAD_TOL, VS_F32 = 1.5e-2, 6e-2, 3e-2
+
+
+def _encoder(state=None, num_convs=2, seed=None):
+    from models.protein_gnn import SelectableProteinModelWrapper
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))["protein_gnn_kwargs"]
+    kw = dict(kw, num_convs=num_convs)
+    for k in ("in_channels", "edge_dim", "hidden_channels", "edge_hidden_channels"):
+        kw[k] = tuple(kw[k])
+    if seed is not None:
+        torch.manual_seed(seed)
+    m = SelectableProteinModelWrapper(**kw)
+    if state is not None:
+        m.load_state_dict({"gnn_model." + k: v for k, v in state.items()})
+    return m.to(DEV).eval()
+
+
+def _bf(d, dev=None):
+    """features rounded to bf16 (kept as bf16 on `dev`, or widened back to fp32 on the CPU for the oracle)"""
+    c = lambda t: t.to(torch.bfloat16).to(dev) if dev else t.to(torch.bfloat16).float()
+    return {k: (tuple(c(t) for t in v) if isinstance(v, tuple) else (v.to(dev) if dev else v)) for k, v in d.items()}
+
+
+@pytest.mark.parametrize("case", ["davis_2_2", "knn_unfused", "depth4_ragged"])
+def test_bf16_forward_backward_vs_oracle(protein_params, case):
+    if case == "davis_2_2":
+        gb, nc, state = ds.protein_batch(8, 3), 2, protein_params
+    elif case == "knn_unfused":
+        gb, nc, state = ds.protein_batch(2, 5, length=120, thresh=12, thresh_type="num"), 2, protein_params
+    else:
+        gb, nc, state = ds.protein_batch(4, 7, lengths=[1, 40, 77, 33], thresh=6.0), 4, None      # CASTER-DTA(4,4) depth
+    model = _encoder(state, nc, seed=11)
+    d = ds.to_torch(gb)
+    dd, dc = _bf(d, DEV), _bf(d)
+    xs, xv = dd["x"][0].clone().requires_grad_(), dd["x"][1].clone().requires_grad_()
+    out = model((xs, xv), dd["edge_index"], dd["ntypes"], dd["etypes"], eattr=dd["eattr"])
+    assert out.dtype == torch.bfloat16 and out.shape == (gb.num_nodes, 64)
+    P = {k: v.detach().cpu().clone().requires_grad_(v.numel() > 0) for k, v in model.gnn_model.state_dict().items()}
+    rxs, rxv = dc["x"][0].clone().requires_grad_(), dc["x"][1].clone().requires_grad_()
+    ref = O.protein_lba_forward(P, (rxs, rxv), dc["edge_index"], dc["ntypes"], dc["etypes"], dc["eattr"], num_convs=nc,
+                                store_dtype=torch.bfloat16)
+    assert rel_err(out.float(), ref) < FWD_TOL
+    r = torch.randn(ref.shape, generator=torch.Generator().manual_seed(3))
+    (out.float() * r.to(DEV)).sum().backward()
+    (ref * r).sum().backward()
+    scale = max(float(v.grad.abs().max()) for v in P.values() if v.grad is not None)
+    for name, p in model.gnn_model.named_parameters():
+        if p.numel():
+            want = P[name].grad
+            assert p.grad.dtype == torch.float32                      # weight gradients are fp32
+            assert float((p.grad.cpu() - want).norm()) <= GRAD_TOL * float(want.norm()) + 2e-3 * scale, name
+    assert xs.grad.dtype == torch.bfloat16
+    l2 = lambda a, b: float((a.cpu().float() - b).norm() / b.norm())
+    assert l2(xs.grad, rxs.grad) < GRAD_TOL and l2(xv.grad, rxv.grad) < GRAD_TOL
+    # same kernels in fp32 storage on the same (bf16-representable) inputs: agree to the same bound; bf16 run repeats bitwise
+    f32 = {k: (tuple(t.float() for t in v) if isinstance(v, tuple) else v) for k, v in dd.items()}
+    with torch.no_grad():
+        o32 = model(f32["x"], f32["edge_index"], f32["ntypes"], f32["etypes"], eattr=f32["eattr"])
+        o16 = model(dd["x"], dd["edge_index"], dd["ntypes"], dd["etypes"], eattr=dd["eattr"])
+        again = model(dd["x"], dd["edge_index"], dd["ntypes"], dd["etypes"], eattr=dd["eattr"])
+    assert o32.dtype == torch.float32 and rel_err(o16.float(), o32) < VS_F32
+    assert torch.equal(o16, again)
+
+
+def test_bf16_training_mode_and_joint_head(pretrained):
+    """bf16-storage encoders inside JointGNN (fp32 head): a training step with in-kernel dropout runs and every
+    parameter receives a finite gradient."""
+    from models.joint_gnn import JointGNN
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))
+    model = JointGNN(protein_gnn_kwargs=kw["protein_gnn_kwargs"], molecule_gnn_kwargs=kw["molecule_gnn_kwargs"],
+                     **kw["joint_gnn_kwargs"])
+    model.load_state_dict(pretrained, strict=True)
+    model = model.to(DEV).train()
+    p, m = ds.pair_batch(4, 5, lengths=[40, 55, 33, 70])
+    pd = _bf(ds.to_torch(p), DEV)
+    md = {k: v.to(DEV) for k, v in ds.to_torch(m).items()}
+    pred, _ = model(pd, md)
+    assert pred.dtype == torch.float32 and pred.shape == (4, 1)
+    pred.square().mean().backward()
+    bad = [n for n, q in model.named_parameters() if q.numel() and (q.grad is None or not torch.isfinite(q.grad).all())]
+    assert not bad, bad

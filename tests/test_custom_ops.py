@@ -57,12 +57,12 @@ def test_fake_kernels_propagate_shapes_without_a_gpu(protein_params, molecule_pa
         args = (params, f(N, 17), f(N, 3, 3), f(N, dt=torch.int64), f(E, 32), f(E, 1, 3), f(E, dt=torch.int64),
                 f(2, E, dt=torch.int64), CFG)
         out, state, masks, seed, e_emb = torch.ops.caster_gvp.lba_encoder(*args, 0.2, True)
-        assert out.shape == (N, 64) and state.shape == (5, N, 28) and masks.numel() == 0      # masks live in the kernels
-        assert seed.shape == (2,) and seed.dtype == torch.int64 and e_emb.shape == (E, 36)
+        assert out.shape == (N, 64) and state.shape == (5, N + (N & 1), 28) and masks.numel() == 0      # masks live in the kernels
+        assert seed.shape == (2,) and seed.dtype == torch.int64 and e_emb.shape == (E + 1, 36)
         out, state, masks, seed, e_emb = torch.ops.caster_gvp.lba_encoder(*args, 0.0, False)
         assert out.shape == (N, 64) and state.numel() == 0 and masks.numel() == 0 and seed.numel() == 0 and e_emb.numel() == 0
-        g, gxs, gxv = torch.ops.caster_gvp.lba_encoder_backward(f(N, 64), *args[:8], f(5, N, 28), f(0),
-                                                                f(2, dt=torch.int64), f(E, 36), CFG, 0.2, True)
+        g, gxs, gxv = torch.ops.caster_gvp.lba_encoder_backward(f(N, 64), *args[:8], f(5, N + (N & 1), 28), f(0),
+                                                                f(2, dt=torch.int64), f(E + 1, 36), CFG, 0.2, True)
         assert g.shape == (15117,) and gxs.shape == (N, 17) and gxv.shape == (N, 3, 3)
         keys = ("eps", "nn.lins.0.weight", "nn.lins.0.bias", "nn.lins.1.weight", "nn.lins.1.bias", "lin.weight", "lin.bias")
         mparams = [f(*molecule_params[f"conv_list.{l}.{k}"].shape) for l in range(2) for k in keys]
