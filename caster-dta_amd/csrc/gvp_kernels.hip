@@ -47,6 +47,13 @@ inline int launch_status() {
 }
 
 // ------------------------------------------------------------------ CSR build
+// Stable counting sort of the edges by target in four launches:
+//   count  : cnt[dst] += 1                                     (int atomics, one thread per edge)
+//   scan   : exclusive scan of cnt -> rowptr; cnt becomes the per-target cursor   (ONE block, LDS tiles with a carry)
+//   fill   : pos = cursor[dst]++ -> tmp[pos] = edge id, edst[pos] = dst          (arrival order inside a segment)
+//   rank   : every position ranks its edge id inside its segment (deg reads, all independent) and writes
+//            eperm / esrc at the ranked position: segments end up ordered by edge id = the reference's index_add
+//            order, run-to-run reproducible; the same launch zeroes the counters again for the next call.
 __global__ void csr_count_kernel(const int64_t* __restrict__ ei, int64_t N, int64_t E,
                                  int32_t* __restrict__ cnt) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -56,102 +63,100 @@ __global__ void csr_count_kernel(const int64_t* __restrict__ ei, int64_t N, int6
   atomicAdd(&cnt[d], 1);
 }
 
-// Exclusive scan of cnt[0..N) by ONE 1024-thread block; rowptr[N] = total;
-// cnt is rewritten with the scan so the fill kernel can use it as a cursor.
-// Tables up to SCAN_LDS entries are scanned in LDS with coalesced global
-// traffic; longer ones fall back to per-thread contiguous chunks.
+// Exclusive scan of cnt[0..N) by ONE 1024-thread block; rowptr[N] = total; cnt is rewritten with the scan so the
+// fill kernel can use it as a cursor.  The table goes through LDS in tiles of SCAN_LDS entries (coalesced global
+// traffic both ways) with a running carry, so long tables cost tiles x the short-table time, not a strided crawl.
 constexpr int SCAN_LDS = 36 * 1024;   // 144 KB of the 160 KB LDS
 __global__ __launch_bounds__(1024) void csr_scan_kernel(int32_t* __restrict__ cnt, int64_t N,
                                                         int32_t* __restrict__ rowptr) {
-  extern __shared__ int32_t sbuf[];             // [N if it fits][1024 partials]
+  extern __shared__ int32_t sbuf[];             // [tile][1024 partials + 32]
   const int t = threadIdx.x;
-  const bool in_lds = N <= SCAN_LDS;
-  int32_t* part = sbuf + (in_lds ? (int)N : 0);
-  const int64_t chunk = (N + 1023) / 1024;
-  const int64_t lo = t * chunk, hi = (lo + chunk < N) ? lo + chunk : N;
-  if (in_lds) {
+  const int tile_cap = (int)(N < SCAN_LDS ? (N + 3) / 4 * 4 : SCAN_LDS);
+  int32_t* part = sbuf + tile_cap;
+  int32_t carry = 0;
+  for (int64_t base = 0; base < N || base == 0; base += SCAN_LDS) {
+    const int64_t rem = N - base;
+    const int n = (int)(rem < SCAN_LDS ? (rem > 0 ? rem : 0) : SCAN_LDS);     // entries of this tile
     // all global loads in flight at once (9 x int4 per thread covers SCAN_LDS), then LDS
     constexpr int VPT = SCAN_LDS / 4096;
     int4 v[VPT];
-    const int64_t n4 = N >> 2;
+    const int n4 = n >> 2;
+    const int4* src4 = reinterpret_cast<const int4*>(cnt + base);     // base is a multiple of SCAN_LDS: 16-B aligned
 #pragma unroll
     for (int k = 0; k < VPT; ++k) {
-      const int64_t q = t + 1024 * k;
-      v[k] = q < n4 ? reinterpret_cast<const int4*>(cnt)[q] : make_int4(0, 0, 0, 0);
+      const int q = t + 1024 * k;
+      v[k] = q < n4 ? src4[q] : make_int4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int k = 0; k < VPT; ++k) {
-      const int64_t q = t + 1024 * k;
+      const int q = t + 1024 * k;
       if (q < n4) reinterpret_cast<int4*>(sbuf)[q] = v[k];
     }
-    if (t < (N & 3)) sbuf[(n4 << 2) + t] = cnt[(n4 << 2) + t];
+    if (t < (n & 3)) sbuf[(n4 << 2) + t] = cnt[base + (n4 << 2) + t];
     __syncthreads();
-  }
-  int32_t sum = 0;
-  if (in_lds) { for (int64_t i = lo; i < hi; ++i) sum += sbuf[i]; }      // two loops: keeps LDS / global
-  else { for (int64_t i = lo; i < hi; ++i) sum += cnt[i]; }              // addressing explicit (no flat)
-  // inclusive scan of the 1024 per-thread sums: shuffles inside each wave, the 16 wave totals through
-  // LDS (2 barriers instead of the 20 of a block-wide Hillis-Steele)
-  int32_t inc = sum;
+    const int chunk = (n + 1023) / 1024;
+    const int lo = t * chunk < n ? t * chunk : n, hi = lo + chunk < n ? lo + chunk : n;
+    int32_t sum = 0;
+    for (int i = lo; i < hi; ++i) sum += sbuf[i];
+    // inclusive scan of the 1024 per-thread sums: shuffles inside each wave, the 16 wave totals through
+    // LDS (2 barriers instead of the 20 of a block-wide Hillis-Steele)
+    int32_t inc = sum;
 #pragma unroll
-  for (int off = 1; off < WAVE; off <<= 1) {
-    const int32_t v = __shfl_up(inc, off);
-    if ((t & (WAVE - 1)) >= off) inc += v;
-  }
-  if ((t & (WAVE - 1)) == WAVE - 1) part[t >> 6] = inc;
-  __syncthreads();
-  if (t < 16) {
-    int32_t w = part[t];
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) {
-      const int32_t v = __shfl_up(w, off, 16);
-      if (t >= off) w += v;
+    for (int off = 1; off < WAVE; off <<= 1) {
+      const int32_t u = __shfl_up(inc, off);
+      if ((t & (WAVE - 1)) >= off) inc += u;
     }
-    part[16 + t] = w;            // inclusive totals of waves 0..t
-  }
-  __syncthreads();
-  const int32_t wave_base = (t >> 6) > 0 ? part[16 + (t >> 6) - 1] : 0;
-  const int32_t total = part[31];
-  int32_t run = wave_base + inc - sum;   // exclusive prefix of this thread's chunk
-  if (in_lds) {
-    for (int64_t i = lo; i < hi; ++i) { const int32_t c = sbuf[i]; sbuf[i] = run; run += c; }
+    if ((t & (WAVE - 1)) == WAVE - 1) part[t >> 6] = inc;
     __syncthreads();
-    for (int64_t i = t; i < N; i += 1024) { const int32_t v = sbuf[i]; rowptr[i] = v; cnt[i] = v; }
-  } else {
-    for (int64_t i = lo; i < hi; ++i) { const int32_t c = cnt[i]; rowptr[i] = run; cnt[i] = run; run += c; }
+    if (t < 16) {
+      int32_t w = part[t];
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {
+        const int32_t u = __shfl_up(w, off, 16);
+        if (t >= off) w += u;
+      }
+      part[16 + t] = w;            // inclusive totals of waves 0..t
+    }
+    __syncthreads();
+    const int32_t wave_base = (t >> 6) > 0 ? part[16 + (t >> 6) - 1] : 0;
+    const int32_t total = part[31];
+    int32_t run = carry + wave_base + inc - sum;   // exclusive prefix of this thread's chunk
+    for (int i = lo; i < hi; ++i) { const int32_t c = sbuf[i]; sbuf[i] = run; run += c; }
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) { const int32_t x = sbuf[i]; rowptr[base + i] = x; cnt[base + i] = x; }
+    carry += total;
+    __syncthreads();
+    if (N == 0) break;
   }
-  if (t == 1023) rowptr[N] = total;
+  if (t == 0) rowptr[N] = carry;
 }
 
 __global__ void csr_fill_kernel(const int64_t* __restrict__ ei, int64_t N, int64_t E,
-                                int32_t* __restrict__ cursor, int32_t* __restrict__ eperm) {
+                                int32_t* __restrict__ cursor, int32_t* __restrict__ tmp, int32_t* __restrict__ edst) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   int64_t s = ei[e], d = ei[E + e];
   if (s < 0 || s >= N || d < 0 || d >= N) return;
   int32_t pos = atomicAdd(&cursor[d], 1);
-  eperm[pos] = (int32_t)e;
+  tmp[pos] = (int32_t)e;
+  edst[pos] = (int32_t)d;
 }
 
-// Order every target's segment by original edge id (stable CSR => the fp32
-// summation order per node is the reference's index_add order) and emit the
-// sorted source / target tables.
-__global__ void csr_finish_kernel(const int64_t* __restrict__ ei, int64_t N, int64_t E,
-                                  const int32_t* __restrict__ rowptr, int32_t* __restrict__ eperm,
-                                  int32_t* __restrict__ esrc, int32_t* __restrict__ edst) {
-  int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  const int32_t lo = rowptr[n], hi = rowptr[n + 1];
-  for (int32_t i = lo + 1; i < hi; ++i) {
-    int32_t key = eperm[i];
-    int32_t j = i - 1;
-    while (j >= lo && eperm[j] > key) { eperm[j + 1] = eperm[j]; --j; }
-    eperm[j + 1] = key;
-  }
-  for (int32_t i = lo; i < hi; ++i) {
-    esrc[i] = (int32_t)ei[eperm[i]];
-    edst[i] = (int32_t)n;
-  }
+// Position p of target n's segment holds SOME edge of n (arrival order of the fill).  Its final place is its rank
+// among the segment's edge ids; deg independent reads per position instead of a serial per-node insertion sort.
+// Threads t < counters also restore the zeroed-counters contract of `work`.
+__global__ void csr_rank_kernel(const int64_t* __restrict__ ei, int64_t N, int64_t counters,
+                                const int32_t* __restrict__ rowptr, const int32_t* __restrict__ tmp,
+                                const int32_t* __restrict__ edst, int32_t* __restrict__ eperm,
+                                int32_t* __restrict__ esrc, int32_t* __restrict__ cnt) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < counters) cnt[t] = 0;
+  if (t >= rowptr[N]) return;
+  const int32_t n = edst[t], lo = rowptr[n], hi = rowptr[n + 1], key = tmp[t];
+  int32_t rank = 0;
+  for (int32_t j = lo; j < hi; ++j) rank += tmp[j] < key ? 1 : 0;
+  eperm[lo + rank] = key;
+  esrc[lo + rank] = (int32_t)ei[key];
 }
 
 // Batch CSR by CONCATENATION of per-graph CSRs (a dataset's few hundred unique
@@ -561,19 +566,28 @@ int cgvp_abi_version(void) { return CGVP_ABI_VERSION; }
 const char* cgvp_build_info(void) { return "libcaster_gvp gfx950 (HIP, wave64), built " __DATE__ " " __TIME__; }
 
 int cgvp_csr_from_coo(const int64_t* edge_index, int64_t N, int64_t E, int32_t* rowptr,
-                      int32_t* eperm, int32_t* esrc, int32_t* edst, int32_t* work, void* stream) {
-  if (N < 0 || E < 0 || !rowptr || !work || (E > 0 && (!edge_index || !eperm || !esrc || !edst)))
+                      int32_t* eperm, int32_t* esrc, int32_t* edst, int32_t* work, int32_t work_is_zero,
+                      int32_t* ids_scratch, void* stream) {
+  if (N < 0 || E < 0 || !rowptr || !work || (E > 0 && (!edge_index || !eperm || !esrc || !edst || !ids_scratch)))
     return CGVP_ERR_BAD_ARG;
   if (N >= (int64_t)1 << 31 || E >= (int64_t)1 << 31) return CGVP_ERR_BAD_ARG;
+  if ((uintptr_t)work & 15) return CGVP_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  // whole 256-B multiples: the runtime splits any other size into two fill launches (body + tail)
-  hipError_t err = hipMemsetAsync(work, 0, (size_t)((N + 1 + 63) / 64 * 64) * sizeof(int32_t), s);
-  if (err != hipSuccess) return (int)err;
+  const int64_t counters = (N + 1 + 63) / 64 * 64;
+  if (!work_is_zero) {
+    // whole 256-B multiples: the runtime splits any other size into two fill launches (body + tail)
+    hipError_t err = hipMemsetAsync(work, 0, (size_t)counters * sizeof(int32_t), s);
+    if (err != hipSuccess) return (int)err;
+  }
+  int32_t* tmp = ids_scratch;
   const int B = 256;
   if (E > 0) hipLaunchKernelGGL(csr_count_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, work);
-  hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), (size_t)((N <= SCAN_LDS ? N : 0) + 1024) * sizeof(int32_t), s, work, N, rowptr);
-  if (E > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, work, eperm);
-  if (N > 0 && E > 0) hipLaunchKernelGGL(csr_finish_kernel, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, rowptr, eperm, esrc, edst);
+  const int64_t tile = N < SCAN_LDS ? (N + 3) / 4 * 4 : SCAN_LDS;
+  hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), (size_t)(tile + 1024 + 32) * sizeof(int32_t), s, work, N, rowptr);
+  if (E > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, work, tmp, edst);
+  const int64_t span = E > counters ? E : counters;
+  hipLaunchKernelGGL(csr_rank_kernel, dim3((unsigned)((span + B - 1) / B)), dim3(B), 0, s, edge_index, N, counters, rowptr, tmp,
+                     edst, eperm, esrc, work);
   return launch_status();
 }
 

@@ -123,15 +123,31 @@ def build_csr(edge_index, num_nodes):
     dev = ei.device
     i32 = dict(dtype=torch.int32, device=dev)
     rowptr = torch.empty(num_nodes + 1, **i32)
-    work = torch.empty((num_nodes + 1 + 63) // 64 * 64, **i32)       # whole 256-B units, see the header
     eperm = torch.empty(max(E, 1), **i32)
     esrc = torch.empty(max(E, 1), **i32)
     edst = torch.empty(max(E, 1), **i32)
+    ids = torch.empty(max(E, 1), **i32)
     with torch.cuda.device(dev):
+        work = _zeroed_counters(dev, (num_nodes + 1 + 63) // 64 * 64)
         rc = _lib.lib().cgvp_csr_from_coo(_ptr(ei), num_nodes, E, _ptr(rowptr), _ptr(eperm), _ptr(esrc),
-                                          _ptr(edst), _ptr(work), _stream())
+                                          _ptr(edst), _ptr(work), 1, _ptr(ids), _stream())
     _lib.check(rc, "cgvp_csr_from_coo")
     return Csr(rowptr, eperm, esrc, edst, num_nodes, E)
+
+
+_COUNTERS = {}      # (device index, stream handle) -> int32 counters, zero between calls (cgvp_csr_from_coo keeps them so)
+
+
+def _zeroed_counters(dev, n):
+    """The CSR build's per-target counters: one persistent buffer per (device, stream), zero-filled ONCE when it is
+    created or grown -- every build leaves the counters it used zeroed again, so a step needs no fill launch.  Keyed by
+    stream because builds on different streams (protein / drug) run concurrently."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _COUNTERS.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.zeros(max(n * 2, 4096), dtype=torch.int32, device=dev)
+        _COUNTERS[key] = buf
+    return buf
 
 
 class CsrStore:

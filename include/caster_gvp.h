@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 19
+#define CGVP_ABI_VERSION 20
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
@@ -89,12 +89,15 @@ typedef struct {
  *   rowptr[N+1]  first sorted-edge position of every target node
  *   eperm[E]     original edge id of every sorted position (stable in edge id)
  *   esrc[E], edst[E]  source / target node of every sorted position
- *   work         scratch of N+1 ints rounded UP to a multiple of 64 (zero-filled
- *                here in whole 256-B units: one fill launch instead of two)
- * Launches 5 small kernels on `stream`. */
+ *   work         per-target counters: N+1 ints rounded UP to a multiple of 64, 16-B aligned.  They must be zero when
+ *                the kernels start: pass work_is_zero = 0 and the call zero-fills them first (one more launch), or
+ *                keep a buffer that was zero-filled once and pass work_is_zero = 1 -- every call leaves the
+ *                counters it used zeroed again.
+ *   ids_scratch  E ints (edge ids in arrival order, consumed by the ranking launch)
+ * Four launches on `stream` (count, scan, fill, rank), stable: a target's edges stay in edge-id order. */
 int cgvp_csr_from_coo(const int64_t* edge_index, int64_t num_nodes, int64_t num_edges,
                       int32_t* rowptr, int32_t* eperm, int32_t* esrc, int32_t* edst,
-                      int32_t* work, void* stream);
+                      int32_t* work, int32_t work_is_zero, int32_t* ids_scratch, void* stream);
 
 /* The same tables for a batch assembled from graphs whose CSR is already known (the
  * reference's datasets reuse a few hundred unique protein / drug graphs across tens of
