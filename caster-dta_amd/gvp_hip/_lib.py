@@ -15,11 +15,11 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CGVP_LIB_PATH: A/B builds of the same ABI (diagnostics); the default is the in-tree library
 LIB_PATH = os.environ.get("CGVP_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libcaster_gvp.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 # sha256 of include/caster_gvp.h with comments, blank space and the CGVP_ABI_VERSION line removed, as
 # `abi_header_digest()` computes it.  tests/test_abi.py fails when the header's declarations change
 # without CGVP_ABI_VERSION, ABI_VERSION and this digest being updated together.
-ABI_HEADER_SHA256 = "b7e7e023d9598cad2c9be19be960ed75e550d117145cbf91efd26a0317407913"
+ABI_HEADER_SHA256 = "6078ccbc5d4f8e94ec55f7e5f552f3432c18a63115d0983e01cd6e4c507482cf"
 
 
 class HipLibraryError(RuntimeError):
@@ -95,6 +95,7 @@ _SIGNATURES = {
     "cgvp_bwd_reduce": (C.c_int, [_P, _I32, _P, _I32, _P]),
     "cgvp_gine_conv_fwd": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32,
                                      _I32, C.POINTER(GineW), C.c_float, _P, C.POINTER(Rng), _I32, _P, _P]),
+    "cgvp_edge_featurise": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P]),
     "cgvp_attn_fwd": (C.c_int, [C.POINTER(AttnProblem), _I32, _I64, _I32, C.c_float, _P]),
     "cgvp_attn_bwd": (C.c_int, [C.POINTER(AttnProblem), _I32, _I64, _I32, C.c_float, _P]),
     "cgvp_attn_weights": (C.c_int, [C.POINTER(AttnProblem), _I32, _I64, _I32, C.c_float, _P]),

@@ -360,7 +360,7 @@ def lba_encoder(model, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, train_dro
            model.edge_hidden_channels[1], model.out_channels[0], model.num_ntypes, model.num_etypes,
            model.num_convs, 1 if model.aggr == "mean" else 0]
     out, _, _, _, _ = torch.ops.caster_gvp.lba_encoder(
-        model._arena.params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, cfg,
+        model.op_params(), x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, cfg,
         float(model.dropout_rate) if train_dropout else 0.0, save_state)
     return out
 

@@ -271,6 +271,23 @@ def csr_for_backward(edge_index, num_nodes):
     return cached_csr(edge_index, num_nodes)      # e.g. under torch.compile: a different tensor object
 
 
+def edge_features(ca_xyz, seq_index, edge_index):
+    """Protein edge features from C-alpha coordinates [N, 3] (fp32, Angstrom) and per-chain sequence indices [N]
+    (utils/create_protein_features.py:225-273 on the device): -> (e_s [E, 32], e_v [E, 1, 3]) in the
+    order of `edge_index` -- the `eattr` tuple the protein encoder takes."""
+    ca = _f32(ca_xyz, "ca_xyz")
+    seq, ei = _i64(seq_index, "seq_index"), _i64(edge_index, "edge_index")
+    if ca.dim() != 2 or ca.shape[1] != 3 or seq.shape[0] != ca.shape[0] or ei.dim() != 2 or ei.shape[0] != 2:
+        raise ValueError("expected ca_xyz [N, 3], seq_index [N], edge_index [2, E]")
+    N, E = int(ca.shape[0]), int(ei.shape[1])
+    e_s = torch.empty(E, 32, dtype=torch.float32, device=ca.device)
+    e_v = torch.empty(E, 1, 3, dtype=torch.float32, device=ca.device)
+    with torch.cuda.device(ca.device):
+        _lib.check(_lib.lib().cgvp_edge_featurise(_ptr(ca), _ptr(seq), _ptr(ei), N, E, _ptr(e_s), _ptr(e_v), _stream()),
+                   "cgvp_edge_featurise")
+    return e_s, e_v
+
+
 def prepare_image(params, layout, dims):
     """Fragment image of the arena for the MFMA kernels (one small launch)."""
     L = _lib.lib()

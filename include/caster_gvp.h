@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 20
+#define CGVP_ABI_VERSION 21
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
@@ -359,6 +359,18 @@ int cgvp_gine_conv_bwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
                        int32_t chid, int32_t cout, const cgvp_gine_w* w, float act_slope,
                        const float* mask, const cgvp_rng* rng, const float* g_out, float* g_x,
                        float* grad_layer, float* workspace, int32_t max_workgroups, void* stream);
+
+/* ------------------------------------------------------------ EDGE FEATURISATION (opt-in)
+ * The protein edge features of utils/create_protein_features.py:225-273 (+ calc_pos_encoding :368-386) computed on the
+ * device from C-alpha coordinates and sequence indices, for the edges i -> j of edge_index ([2][E], row 0 = i):
+ *   e_s[e][ 0:16] = exp(-((|CA_i - CA_j| - mu_k) / 1.25)^2), mu_k = linspace(0, 20, 16)
+ *   e_s[e][16:24] = cos((seq_j - seq_i) f_k), e_s[e][24:32] = sin(...), f_k = exp(-2 k ln(10000) / 8), k = 0..7
+ *   e_v[e]        = (CA_i - CA_j) / |CA_i - CA_j|, zero for coincident positions (self loops)
+ * ca_xyz [N][3] fp32 (Angstrom), seq_index [N] int64 (position of the residue in its own chain), outputs fp32 in
+ * ORIGINAL edge order: exactly the eattr tensors the encoder entry points take.  A dataset can then keep 12 B per
+ * residue + the edge list instead of 140 B per edge. */
+int cgvp_edge_featurise(const float* ca_xyz, const int64_t* seq_index, const int64_t* edge_index,
+                        int64_t num_nodes, int64_t num_edges, float* e_s, float* e_v, void* stream);
 
 /* ------------------------------------------------------------ CROSS-ATTENTION CORE
  * The part of nn.MultiheadAttention between its input and output projections, for the residue <-> atom cross

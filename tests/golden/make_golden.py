@@ -17,7 +17,8 @@ replaced by minimal stand-ins registered in ``sys.modules`` *before* the import:
   reduced over ``edge_index[1]`` with ``aggr`` in {'add','sum','mean'}.  This is
   third-party behaviour restated, not reference code: parity is UNPINNED at
   exactly this boundary (see oracle/gvp_oracle.py docstring).
-* ``torch_scatter.scatter_add``: only used on the autoregressive branch, never hit.
+* ``torch_scatter.scatter_add``: only used on the autoregressive branch (the CPD decoder of gvp_stacks.npz):
+  a three-line restatement of its documented 1-D semantics.
 * ``ipdb``: debugger import, unused.
 
 All GVP / LayerNorm / GVPConv.message / GVPConvLayer / LBA-model arithmetic in the
@@ -91,7 +92,13 @@ def install_standins():
     pyg.nn.MessagePassing = MessagePassing
     pyg.utils.degree = None
     ts = types.ModuleType("torch_scatter")
-    ts.scatter_add = None
+
+    def scatter_add(src, index, dim=-1, out=None, dim_size=None):
+        """torch_scatter.scatter_add for 1-D `src` / `index` (the only use: the in-degree count of the
+        autoregressive branch, gvp_layers.py:395) -- documented semantics restated, third-party code."""
+        n = int(dim_size) if dim_size is not None else int(index.max()) + 1
+        return torch.zeros(n, dtype=src.dtype).index_add_(0, index, src)
+    ts.scatter_add = scatter_add
     sys.modules.update({"torch_geometric": pyg, "torch_geometric.nn": pyg.nn,
                         "torch_geometric.utils": pyg.utils, "torch_scatter": ts,
                         "ipdb": types.ModuleType("ipdb")})
@@ -133,6 +140,48 @@ def lba_fixture(model, m64, gb, r_seed):
     return arrays, (d, xs, xv, es, ev, out, out64)
 
 
+def gvp_stacks(Wrapper):
+    """The reference's other GVP stacks with seeded default initialisation, eval mode: PocketMiner-style, CPD-style
+    (autoregressive decoder) and the LBA model with nn.Embedding type encoders; inputs, state dicts, outputs and (for
+    the embedding LBA model) reference-autograd gradients."""
+    base = dict(in_channels=(17, 3), edge_dim=(32, 1), num_ntypes=20, num_etypes=1, num_convs=2, hidden_channels=(16, 4),
+                dropout_rate=0.1)
+    cases = {
+        "pocketminer": dict(base, base_conv="pocketminer", ntype_emb_dim=None, etype_emb_dim=None, out_channels=8,
+                            edge_hidden_channels=(32, 1), initial_node_project_channels=(20, 4),
+                            initial_edge_project_channels=(24, 2)),
+        "cpdmodel": dict(base, base_conv="cpdmodel", ntype_emb_dim=None, etype_emb_dim=None, out_channels=8,
+                         edge_hidden_channels=(32, 1)),
+        "lba_embedding": dict(base, base_conv="lbamodel", ntype_emb_dim=8, etype_emb_dim=4, out_channels=64,
+                              edge_hidden_channels=(32, 1), aggr="sum"),
+    }
+    rng = np.random.default_rng(31)
+    gb = ds.collate([ds.protein_graph(L, rng, 4.0, "dist") for L in (28, 41, 17)])
+    d = ds.to_torch(gb)
+    arrays = dict(x_s=gb.x_s, x_v=gb.x_v, edge_index=gb.edge_index, e_s=gb.e_s, e_v=gb.e_v, ntypes=gb.ntypes,
+                  etypes=gb.etypes, batch=gb.batch)
+    for name, kw in cases.items():
+        torch.manual_seed(100 + len(name))
+        model = Wrapper(**kw).eval()
+        with torch.no_grad():                      # default init leaves LayerNorm at identity: perturb it
+            for k, p in model.named_parameters():
+                if "scalar_norm" in k:
+                    p.add_(0.1 * torch.randn_like(p))
+        out = model(d["x"], d["edge_index"], d["ntypes"], d["etypes"], eattr=d["eattr"], batch=d["batch"])
+        arrays[f"{name}_out"] = np_(out)
+        for k, p in model.state_dict().items():
+            arrays[f"{name}_w_{k}"] = np_(p)
+        if name == "lba_embedding":
+            r = torch.from_numpy(np.random.default_rng(9).normal(size=tuple(out.shape)).astype(np.float32))
+            (out * r).sum().backward()
+            arrays[f"{name}_r"] = np_(r)
+            for k, p in model.named_parameters():
+                if p.numel():
+                    arrays[f"{name}_g_{k}"] = np_(p.grad)
+        print(f"gvp_stacks {name}: out", tuple(out.shape), "params", sum(p.numel() for p in model.parameters()))
+    np.savez_compressed(os.path.join(OUT, "gvp_stacks.npz"), **arrays)
+
+
 def main():
     global OUT
     ap = argparse.ArgumentParser()
@@ -140,7 +189,7 @@ def main():
     ap.add_argument("--only", default=None, help="comma-separated subset of {state,lba_small,lba_sparse,gvp_units}")
     args = ap.parse_args()
     OUT = args.out_dir
-    want = set(args.only.split(",")) if args.only else {"state", "lba_small", "lba_sparse", "gvp_units"}
+    want = set(args.only.split(",")) if args.only else {"state", "lba_small", "lba_sparse", "gvp_units", "gvp_stacks"}
     os.makedirs(OUT, exist_ok=True)
     install_standins()
     assert not any(os.path.abspath(p or ".").startswith(os.path.join(REPO, "caster-dta_amd")) for p in sys.path), \
@@ -193,6 +242,8 @@ def main():
         np.savez_compressed(os.path.join(OUT, "lba_sparse.npz"), **sp_arrays)
         print("lba_sparse: N", gs.num_nodes, "E", gs.num_edges, "out", tuple(so.shape),
               "fp32 vs fp64 max-abs/max", float((so.double() - so64).abs().max() / so64.abs().max()))
+    if "gvp_stacks" in want:
+        gvp_stacks(SelectableProteinModelWrapper)
     if "gvp_units" not in want:
         return
 

@@ -53,8 +53,8 @@ def test_wrapper_passthrough_and_errors(joint, kwargs):
         SelectableProteinModelWrapper(**dict(pk, in_channels=17, edge_dim=(32, 1)))
     with pytest.raises(ValueError):
         SelectableProteinModelWrapper(**dict(pk, in_channels=17, edge_dim=32))
-    with pytest.raises(NotImplementedError):
-        SelectableProteinModelWrapper(**dict(pk, base_conv="pocketminer"))
+    with pytest.raises(NotImplementedError):            # the non-GVP protein encoders stay out of scope
+        SelectableProteinModelWrapper(**dict(pk, in_channels=17, edge_dim=32, base_conv="gatv2"))
     with pytest.raises(NotImplementedError):
         SelectableMoleculeModelWrapper(**dict(kwargs["molecule_gnn_kwargs"], base_conv="gatv2"))
     with pytest.raises(ValueError):
