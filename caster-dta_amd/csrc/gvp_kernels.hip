@@ -167,6 +167,7 @@ struct CsrCollateArgs {
   const int64_t* st_node_off; const int64_t* st_edge_off;      // [G+1] prefix sums over the store's graphs
   const int64_t* sel; const int64_t* b_node_off; const int64_t* b_edge_off;   // [B], [B+1], [B+1]
   int64_t B; int32_t* rowptr; int32_t* eperm; int32_t* esrc; int32_t* edst;
+  int table_mode;      // 1: eperm = position in the STORE's dst-sorted feature tables (features stay resident, read in place)
 };
 __global__ __launch_bounds__(256) void csr_collate_kernel(CsrCollateArgs a) {
   const int64_t b = blockIdx.x;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256) void csr_collate_kernel(CsrCollateArgs a) {
   for (int64_t k = threadIdx.x; k < n; k += 256) a.rowptr[bn + k] = (int32_t)(be + rp[k]);
   if (b == a.B - 1 && threadIdx.x == 0) a.rowptr[bn + n] = (int32_t)(be + e);
   for (int64_t k = threadIdx.x; k < e; k += 256) {
-    a.eperm[be + k] = (int32_t)(be + a.st_eperm[se + k]);
+    a.eperm[be + k] = a.table_mode ? (int32_t)(se + k) : (int32_t)(be + a.st_eperm[se + k]);
     a.esrc[be + k] = (int32_t)(bn + a.st_esrc[se + k]);
     a.edst[be + k] = (int32_t)(bn + a.st_edst[se + k]);
   }
@@ -594,12 +595,12 @@ int cgvp_csr_from_coo(const int64_t* edge_index, int64_t N, int64_t E, int32_t* 
 int cgvp_csr_collate(const int32_t* st_rowptr, const int32_t* st_eperm, const int32_t* st_esrc,
                      const int32_t* st_edst, const int64_t* st_node_off, const int64_t* st_edge_off,
                      const int64_t* sel, const int64_t* b_node_off, const int64_t* b_edge_off, int64_t B,
-                     int32_t* rowptr, int32_t* eperm, int32_t* esrc, int32_t* edst, void* stream) {
+                     int32_t table_mode, int32_t* rowptr, int32_t* eperm, int32_t* esrc, int32_t* edst, void* stream) {
   if (B < 0 || !rowptr) return CGVP_ERR_BAD_ARG;
   if (B == 0) return 0;
   if (!st_rowptr || !st_node_off || !st_edge_off || !sel || !b_node_off || !b_edge_off) return CGVP_ERR_BAD_ARG;
   CsrCollateArgs a{st_rowptr, st_eperm, st_esrc, st_edst, st_node_off, st_edge_off, sel, b_node_off, b_edge_off, B,
-                   rowptr, eperm, esrc, edst};
+                   rowptr, eperm, esrc, edst, table_mode ? 1 : 0};
   hipLaunchKernelGGL(csr_collate_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }

@@ -138,7 +138,7 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
     dims, layout = _dims_layout(cfg, sdt)
     nc, mean = cfg[CFG_NC], bool(cfg[CFG_MEAN])
     x_s, x_v, e_s, e_v = _act(x_s, "x_s", sdt), _act(x_v, "x_v", sdt), _act(e_s, "eattr_s", sdt), _act(e_v, "eattr_v", sdt)
-    N, E = int(x_s.shape[0]), int(e_s.shape[0])
+    N, E = int(x_s.shape[0]), int(edge_index.shape[1])      # e_s / e_v may be a resident feature table (CsrStore table mode)
     dev = x_s.device
     flat = flat_arena(params)
     if flat.numel() != layout.total:
@@ -151,8 +151,9 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
                                       aggr_mean=mean, image=image)
         return (out, torch.empty(0, **act), torch.empty(0, **f32), torch.empty(0, dtype=torch.int64, device=dev),
                 torch.empty(0, **act))
+    rows = csr.table_rows if csr.table_rows is not None else E
     if tuple(x_s.shape) != (N, dims.node_in_s) or tuple(x_v.shape) != (N, dims.node_in_v, 3) or \
-            tuple(e_s.shape) != (E, dims.edge_in_s) or tuple(e_v.shape) != (E, dims.edge_in_v, 3):
+            tuple(e_s.shape) != (rows, dims.edge_in_s) or tuple(e_v.shape) != (rows, dims.edge_in_v, 3) or csr.num_edges != E:
         raise NotImplementedError("feature shapes do not match the compiled CASTER-DTA configuration")
     nt = _i64(ntypes, "ntypes") if layout.nt_node > 0 else None
     et = _i64(etypes, "etypes") if layout.nt_edge > 0 else None
@@ -211,7 +212,7 @@ def _(params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, cfg, dropout_p, sa
     pinned = dropout_p > 0 and PINNED_MASKS is not None
     masks = x_s.new_empty((2 * nc, N, MROW), dtype=torch.float32) if pinned else e32
     seed = x_s.new_empty((2,), dtype=torch.int64) if dropout_p > 0 and not pinned else e64
-    e_emb = x_s.new_empty((e_s.shape[0] + 1, EROW), dtype=sdt)
+    e_emb = x_s.new_empty((edge_index.shape[1] + 1, EROW), dtype=sdt)
     return out, x_s.new_empty((2 * nc + 1, (N + 1) // 2 * 2, ROW), dtype=sdt), masks, seed, e_emb
 
 
@@ -227,7 +228,7 @@ def lba_encoder_backward_op(g_out: Tensor, params: List[Tensor], x_s: Tensor, x_
     nc, mean = cfg[CFG_NC], bool(cfg[CFG_MEAN])
     x_s, x_v, e_s, e_v = _act(x_s, "x_s", sdt), _act(x_v, "x_v", sdt), _act(e_s, "eattr_s", sdt), _act(e_v, "eattr_v", sdt)
     state, e_emb = _act(state, "state", sdt), _act(e_emb, "e_emb", sdt)
-    N, E = int(x_s.shape[0]), int(e_s.shape[0])
+    N, E = int(x_s.shape[0]), int(edge_index.shape[1])
     dev = x_s.device
     nt = _i64(ntypes, "ntypes") if layout.nt_node > 0 else None
     et = _i64(etypes, "etypes") if layout.nt_edge > 0 else None

@@ -113,6 +113,7 @@ class Csr:
     edst: torch.Tensor
     num_nodes: int
     num_edges: int
+    table_rows: int = None      # set by CsrStore.collate(table=True): eperm indexes a resident feature table of this many rows
 
 
 def build_csr(edge_index, num_nodes):
@@ -153,12 +154,19 @@ def _zeroed_counters(dev, n):
 class CsrStore:
     """Per-graph CSR tables of a dataset's UNIQUE graphs, sorted once, and batches assembled from them by
     concatenation (the reference stores unique protein / drug graphs and lets pairs index
-    into them, dataset/dual_dataset.py:123-125).  `collate(ids, attach_to=edge_index)` builds the batch
+    into them, dataset/dual_dataset.py:123-125).  `collate(plan, attach_to=edge_index)` builds the batch
     tables in one small launch and memoises them on the batch's edge_index tensor, where the encoders'
-    `cached_csr` finds them -- the models need no other change."""
+    `cached_csr` finds them -- the models need no other change.
 
-    def __init__(self, edge_indices, num_nodes):
-        """edge_indices: list of [2, E_g] int64 CUDA tensors with LOCAL node ids; num_nodes: list of ints."""
+    With `edge_attr` (and `edge_types`) the store also keeps every unique graph's raw edge features ON THE DEVICE,
+    rows already in dst-sorted order ("feature-table wire format"): `collate(..., table=True)` then emits an `eperm`
+    that points INTO those tables, and the batch is run with `store.edge_table()` as eattr / etypes -- no per-batch
+    edge-feature tensor is collated, shipped or gathered; each graph's rows are read sequentially in place."""
+
+    def __init__(self, edge_indices, num_nodes, edge_attr=None, edge_types=None):
+        """edge_indices: list of [2, E_g] int64 CUDA tensors with LOCAL node ids; num_nodes: list of ints;
+        edge_attr: optional list of (e_s [E_g, 32], e_v [E_g, 1, 3]) in the graphs' original edge order;
+        edge_types: optional list of int64 [E_g]."""
         csrs = [build_csr(ei, n) for ei, n in zip(edge_indices, num_nodes)]
         dev = edge_indices[0].device
         self.device = dev
@@ -170,6 +178,21 @@ class CsrStore:
         self.edst = torch.cat([c.edst[:c.num_edges] for c in csrs] + [torch.zeros(1, dtype=torch.int32, device=dev)])
         self.node_off = torch.tensor([0] + list(torch.tensor(self.nodes).cumsum(0)), dtype=torch.int64, device=dev)
         self.edge_off = torch.tensor([0] + list(torch.tensor(self.edges).cumsum(0)), dtype=torch.int64, device=dev)
+        self.e_s = self.e_v = self.etypes = None
+        if edge_attr is not None:
+            perm = [c.eperm[:c.num_edges].long() for c in csrs]
+            self.e_s = torch.cat([a[0].to(dev).index_select(0, p) for a, p in zip(edge_attr, perm)]).contiguous()
+            self.e_v = torch.cat([a[1].to(dev).index_select(0, p) for a, p in zip(edge_attr, perm)]).contiguous()
+            if edge_types is not None:
+                self.etypes = torch.cat([t.to(dev).index_select(0, p) for t, p in zip(edge_types, perm)]).contiguous()
+            else:
+                self.etypes = torch.zeros(self.e_s.shape[0], dtype=torch.int64, device=dev)
+
+    def edge_table(self):
+        """(eattr tuple, etypes) to hand to the encoder with batches collated with table=True."""
+        if self.e_s is None:
+            raise ValueError("this store was built without edge features")
+        return (self.e_s, self.e_v), self.etypes
 
     def plan(self, ids):
         """Device-side description of a batch (graph ids in batch order): reusable across steps."""
@@ -181,22 +204,40 @@ class CsrStore:
                     edge_off=torch.cat([torch.zeros(1, dtype=torch.int64), e]).to(dev),
                     N=int(n[-1]), E=int(e[-1]), B=len(ids))
 
-    def collate(self, plan, attach_to=None):
+    def collate(self, plan, attach_to=None, table=False):
         dev = self.device
         i32 = dict(dtype=torch.int32, device=dev)
         N, E = plan["N"], plan["E"]
+        if table and self.e_s is None:
+            raise ValueError("table=True needs a store built with edge_attr")
         rowptr = torch.empty(N + 1, **i32)
         eperm, esrc, edst = (torch.empty(max(E, 1), **i32) for _ in range(3))
         with torch.cuda.device(dev):
             rc = _lib.lib().cgvp_csr_collate(_ptr(self.rowptr), _ptr(self.eperm), _ptr(self.esrc), _ptr(self.edst),
                                              _ptr(self.node_off), _ptr(self.edge_off), _ptr(plan["sel"]),
-                                             _ptr(plan["node_off"]), _ptr(plan["edge_off"]), plan["B"], _ptr(rowptr),
-                                             _ptr(eperm), _ptr(esrc), _ptr(edst), _stream())
+                                             _ptr(plan["node_off"]), _ptr(plan["edge_off"]), plan["B"],
+                                             1 if table else 0, _ptr(rowptr), _ptr(eperm), _ptr(esrc), _ptr(edst),
+                                             _stream())
         _lib.check(rc, "cgvp_csr_collate")
         csr = Csr(rowptr, eperm, esrc, edst, N, E)
+        csr.table_rows = int(self.e_s.shape[0]) if table else None
         if attach_to is not None:
             attach_to._cgvp_csr = (attach_to._version, csr)
         return csr
+
+
+def shard_pairs_by_edges(edge_counts, world_size):
+    """Edge-balanced assignment of a batch's pairs to ranks (the reference's own sampler balances
+    batches by edge count, dataset/dual_dataset.py:476-516): longest-processing-time greedy over the per-pair protein
+    edge counts.  Returns `world_size` lists of pair positions; every rank gets at least one pair when there are
+    enough, and the heaviest rank carries at most (mean + the largest single pair)."""
+    order = sorted(range(len(edge_counts)), key=lambda i: -int(edge_counts[i]))
+    loads, parts = [0] * world_size, [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (loads[k], len(parts[k])))
+        parts[r].append(i)
+        loads[r] += int(edge_counts[i])
+    return [sorted(p) for p in parts]
 
 
 CSR_CACHE_ENABLED = True
@@ -310,14 +351,15 @@ def lba_encoder_forward(params, layout, dims, num_convs, x_s, x_v, ntypes, e_s, 
     sdt = torch.bfloat16 if dims.storage == BF16 else torch.float32
     x_s, x_v = _act(x_s, "x_s", sdt), _act(x_v, "x_v", sdt)
     e_s, e_v = _act(e_s, "eattr_s", sdt), _act(e_v, "eattr_v", sdt)
-    N, E = int(x_s.shape[0]), int(e_s.shape[0])
+    N, E = int(x_s.shape[0]), csr.num_edges          # E = sorted edges of the batch; the feature tensors may be a resident table
     if tuple(x_s.shape) != (N, dims.node_in_s) or tuple(x_v.shape) != (N, dims.node_in_v, 3):
         raise NotImplementedError(f"node features {tuple(x_s.shape)}/{tuple(x_v.shape)} do not match the "
                                   "compiled CASTER-DTA configuration")
-    if tuple(e_s.shape) != (E, dims.edge_in_s) or tuple(e_v.shape) != (E, dims.edge_in_v, 3):
+    rows = csr.table_rows if csr.table_rows is not None else E
+    if tuple(e_s.shape) != (rows, dims.edge_in_s) or tuple(e_v.shape) != (rows, dims.edge_in_v, 3):
         raise NotImplementedError(f"edge features {tuple(e_s.shape)}/{tuple(e_v.shape)} do not match the "
-                                  "compiled CASTER-DTA configuration")
-    if csr.num_nodes != N or csr.num_edges != E:
+                                  f"compiled CASTER-DTA configuration ({rows} rows expected)")
+    if csr.num_nodes != N:
         raise ValueError("CSR tables were built for a different graph")
     if num_convs < 1:
         raise NotImplementedError("num_convs must be >= 1 (the output head is fused into the last layer)")

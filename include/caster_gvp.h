@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 21
+#define CGVP_ABI_VERSION 22
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
@@ -107,11 +107,16 @@ int cgvp_csr_from_coo(const int64_t* edge_index, int64_t num_nodes, int64_t num_
  * its edges at st_edge_off[g]); batch slot b takes graph sel[b] and places it at node
  * offset b_node_off[b], edge offset b_edge_off[b] (all offset arrays are device int64
  * prefix sums).  Equivalent to cgvp_csr_from_coo on the concatenated edge_index
- * (PyG Batch.from_data_list order), in ONE small launch instead of a memset and four. */
+ * (PyG Batch.from_data_list order), in ONE small launch.
+ * table_mode != 0 (feature-table wire format, dataset/dual_dataset.py:526-547 made unnecessary on the device): the
+ * store ALSO keeps every unique graph's raw edge features with the edges already in dst-sorted order, back to back
+ * ([sum of E_g][32], [sum of E_g][1][3], [sum of E_g] types); eperm then holds positions in THOSE tables, and the
+ * encoder entry points are simply given the store's tables as e_s / e_v / etypes: a batch's edge features are never
+ * copied or re-gathered, each graph's rows are read sequentially in place. */
 int cgvp_csr_collate(const int32_t* st_rowptr, const int32_t* st_eperm, const int32_t* st_esrc,
                      const int32_t* st_edst, const int64_t* st_node_off, const int64_t* st_edge_off,
                      const int64_t* sel, const int64_t* b_node_off, const int64_t* b_edge_off,
-                     int64_t batch_graphs, int32_t* rowptr, int32_t* eperm, int32_t* esrc,
+                     int64_t batch_graphs, int32_t table_mode, int32_t* rowptr, int32_t* eperm, int32_t* esrc,
                      int32_t* edst, void* stream);
 
 /* Fill `out` with the arena layout for the given one-hot widths and depth.

@@ -210,3 +210,47 @@ def test_csr_collate_equals_from_coo():
         n = plan["N"] + 1 if name == "rowptr" else plan["E"]
         assert torch.equal(a[:n].cpu(), b[:n].cpu()), name
     assert ops.cached_csr(batch_ei, plan["N"]) is got      # the encoders pick the attached tables up
+
+
+def test_feature_table_wire_format(protein_params):
+    """unique graphs' edge features stay resident on the device in dst-sorted order; a batch is a list of
+    graph ids.  Running the encoder on (store tables, eperm into the tables) == running it on the batch collated the
+    reference's way (concatenated features + COO sort), forward and every gradient."""
+    import json, os
+    from conftest import GOLDEN
+    from models.protein_gnn import SelectableProteinModelWrapper
+    if ops.VARIANT != "mfma":
+        pytest.skip("training path: MFMA kernels")
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))["protein_gnn_kwargs"]
+    for k in ("in_channels", "edge_dim", "hidden_channels", "edge_hidden_channels"):
+        kw[k] = tuple(kw[k])
+    model = SelectableProteinModelWrapper(**kw)
+    model.load_state_dict({"gnn_model." + k: v for k, v in protein_params.items()})
+    model = model.to(DEV).eval()
+    rng = np.random.default_rng(12)
+    graphs = [ds.protein_graph(L, rng, 4.0, "dist") for L in (40, 77, 33, 120)]
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    store = ops.CsrStore([T(g["edge_index"]) for g in graphs], [g["x_s"].shape[0] for g in graphs],
+                         edge_attr=[(T(g["e_s"]), T(g["e_v"])) for g in graphs], edge_types=[T(g["etypes"]) for g in graphs])
+    order = [2, 0, 3, 3, 1]                                   # a batch may repeat a graph and reorder them
+    gb = ds.collate([graphs[i] for i in order])
+    d = {k: (tuple(t.to(DEV) for t in v) if isinstance(v, tuple) else v.to(DEV)) for k, v in ds.to_torch(gb).items()}
+    params = [p for p in model.parameters() if p.numel()]
+    r = torch.randn(gb.num_nodes, 64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    ref = model(d["x"], d["edge_index"], d["ntypes"], d["etypes"], eattr=d["eattr"])
+    g_ref = torch.autograd.grad(ref, params, r)
+    plan = store.plan(order)
+    ei = d["edge_index"].clone()                              # a fresh tensor object: carries only the attached tables
+    csr = store.collate(plan, attach_to=ei, table=True)
+    assert csr.table_rows == sum(g["e_s"].shape[0] for g in graphs) and plan["E"] == gb.num_edges
+    eattr, etypes = store.edge_table()
+    old = ops.CSR_CACHE_ENABLED
+    ops.CSR_CACHE_ENABLED = True
+    try:
+        out = model(d["x"], ei, d["ntypes"], etypes, eattr=eattr)
+        g_out = torch.autograd.grad(out, params, r)
+    finally:
+        ops.CSR_CACHE_ENABLED = old
+    assert torch.equal(out, ref)                              # same kernels, same per-edge arithmetic, same order
+    for a, b in zip(g_out, g_ref):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9
