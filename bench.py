@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--drug-stream", default="side", choices=["side", "main"],
                     help="diagnostic: 'main' runs the drug encoder on the protein stream (no overlap)")
+    ap.add_argument("--gine-bwd-wgs", type=int, default=0,
+                    help="diagnostic: workgroup cap of the GINE backward (0 = library default of 16)")
     ap.add_argument("--only", default=None, choices=["protein", "drug"],
                     help="diagnostic: time one encoder alone (the reported metric needs both; never the default)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
@@ -136,7 +138,8 @@ def main():
     collectives = dist is not None
 
     import davis_synth as ds
-    from gvp_hip import ops
+    from gvp_hip import ops, autograd_ops
+    autograd_ops.GINE_BWD_WORKGROUPS = args.gine_bwd_wgs
     import __graft_entry__ as entry
 
     wl = WORKLOADS[args.workload]
@@ -203,18 +206,28 @@ def main():
             atoms = model.molecule_gnn(**mdata)
             return torch.autograd.grad([atoms], drug_params, [g_atm]) if train else atoms
         side.wait_stream(main_s)
+        # the protein chain is the critical path: it is issued first and stays on the launch stream (a HIP graph keeps
+        # the first-captured branch on the launch queue; the other branch pays the cross-queue joins)
+        if collate:
+            collate[0][0].collate(collate[0][1], attach_to=pdata["edge_index"])
+        residues = model.protein_gnn(**pdata)
         with torch.cuda.stream(side if args.drug_stream == "side" else main_s):   # drug graphs are tiny: run them beside the protein kernels
             if collate:
                 collate[1][0].collate(collate[1][1], attach_to=mdata["edge_index"])
             atoms = model.molecule_gnn(**mdata)
-        if collate:
-            collate[0][0].collate(collate[0][1], attach_to=pdata["edge_index"])
-        residues = model.protein_gnn(**pdata)
-        main_s.wait_stream(side)
         if not train:
+            main_s.wait_stream(side)
             return residues, atoms
-        # backward of both encoders: every weight gradient (22,507 parameters) is produced
-        return torch.autograd.grad([residues, atoms], enc_params, [g_res, g_atm])
+        # backward of both encoders: every weight gradient (22,507 parameters) is produced.  Two engine calls, so that
+        # the protein backward is again the first-issued branch and the drug backward stays on its side stream
+        gp = torch.autograd.grad([residues], prot_params, [g_res])
+        if args.drug_stream == "side":
+            with torch.cuda.stream(side):
+                gd = torch.autograd.grad([atoms], drug_params, [g_atm])
+        else:
+            gd = torch.autograd.grad([atoms], drug_params, [g_atm])
+        main_s.wait_stream(side)
+        return gp + gd
 
     def joint_step():
         if collate:
@@ -258,7 +271,7 @@ def main():
         # --scope joint is launched eagerly: capturing the torch head (library GEMMs called from the autograd thread)
         # into a HIP graph faulted on replay on this ROCm build (round 2, gpurun_out/r2_joint2.err); the encoders
         # scope -- only this library's kernels -- replays from a graph
-        if not args.no_graph and args.scope == "encoders" and args.only != "drug" and args.drug_stream == "side":
+        if not args.no_graph and args.scope == "encoders" and args.drug_stream == "side":
             s = torch.cuda.Stream(device=dev)
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
@@ -266,7 +279,7 @@ def main():
                     step()
             torch.cuda.current_stream().wait_stream(s)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=s):         # the stream the warm-up ran on: its per-stream CSR counters exist
                 out = step()
 
         def run():

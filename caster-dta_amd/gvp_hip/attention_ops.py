@@ -114,11 +114,16 @@ def _attn_setup(ctx, inputs, output):
     q_r, k_a, v_a, q_a, k_r, v_r, rptr, aptr, heads = inputs
     o_r, o_a, lse_r, lse_a = output
     ctx.heads = heads
+    ctx.set_materialize_grads(False)          # the log-sum-exp outputs never carry a gradient: no zero fills for them
     ctx.save_for_backward(q_r, k_a, v_a, q_a, k_r, v_r, o_r, o_a, lse_r, lse_a, rptr, aptr)
 
 
 def _attn_backward(ctx, g_o_r, g_o_a, g_lse_r, g_lse_a):
     q_r, k_a, v_a, q_a, k_r, v_r, o_r, o_a, lse_r, lse_a, rptr, aptr = ctx.saved_tensors
+    if g_o_r is None and g_o_a is None:
+        return (None,) * 9
+    g_o_r = torch.zeros_like(o_r) if g_o_r is None else g_o_r
+    g_o_a = torch.zeros_like(o_a) if g_o_a is None else g_o_a
     grads = torch.ops.caster_gvp.cross_attention_backward(g_o_r.contiguous(), g_o_a.contiguous(), q_r, k_a, v_a, q_a,
                                                           k_r, v_r, o_r, o_a, lse_r, lse_a, rptr, aptr, ctx.heads)
     # the two directions share no operand: a residue-side tensor gets its gradient from exactly one of them

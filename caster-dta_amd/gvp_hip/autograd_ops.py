@@ -144,16 +144,14 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
     if flat.numel() != layout.total:
         raise RuntimeError(f"parameter arena has {flat.numel()} floats, kernels expect {layout.total}")
     image = fragment_image(params, flat, layout, dims) if ops.VARIANT == "mfma" else None
-    csr = ops.csr_for_forward(edge_index, N)
     f32, act = dict(dtype=torch.float32, device=dev), dict(dtype=sdt, device=dev)
     if not save_state:
+        csr = ops.csr_for_forward(edge_index, N)
         out = ops.lba_encoder_forward(flat, layout, dims, nc, x_s, x_v, ntypes, e_s, e_v, etypes, csr,
                                       aggr_mean=mean, image=image)
         return (out, torch.empty(0, **act), torch.empty(0, **f32), torch.empty(0, dtype=torch.int64, device=dev),
                 torch.empty(0, **act))
-    rows = csr.table_rows if csr.table_rows is not None else E
-    if tuple(x_s.shape) != (N, dims.node_in_s) or tuple(x_v.shape) != (N, dims.node_in_v, 3) or \
-            tuple(e_s.shape) != (rows, dims.edge_in_s) or tuple(e_v.shape) != (rows, dims.edge_in_v, 3) or csr.num_edges != E:
+    if tuple(x_s.shape) != (N, dims.node_in_s) or tuple(x_v.shape) != (N, dims.node_in_v, 3):
         raise NotImplementedError("feature shapes do not match the compiled CASTER-DTA configuration")
     nt = _i64(ntypes, "ntypes") if layout.nt_node > 0 else None
     et = _i64(etypes, "etypes") if layout.nt_edge > 0 else None
@@ -172,11 +170,18 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
     out = torch.empty(N, dims.out_s, **act)
     e_emb = torch.empty(E + 1, EROW, **act)
     with torch.cuda.device(dev):
-        st = _stream()
         d, lay, P, I = C.byref(dims), C.byref(layout), _ptr(flat), _ptr(image)
+        # (forking the node embedding -- which does not need the tables -- onto a second stream beside the CSR build, and
+        # d(node embedding) beside d(edge embedding) in the backward, was measured in round 2: the two cross-queue joins
+        # cost more than the ~14 us of overlap they buy, 0.286 vs 0.252 ms per protein step; one stream it is)
+        st = _stream()
         _lib.check(L.cgvp_node_embed_fwd(d, lay, P, I, _ptr(x_s), _ptr(x_v), _ptr(nt), N, _ptr(hs[0]),
                                          _ptr(rstate), _ptr(seed if rstate is not None else None), st),
                    "cgvp_node_embed_fwd")
+        csr = ops.csr_for_forward(edge_index, N)
+        rows = csr.table_rows if csr.table_rows is not None else E
+        if tuple(e_s.shape) != (rows, dims.edge_in_s) or tuple(e_v.shape) != (rows, dims.edge_in_v, 3) or csr.num_edges != E:
+            raise NotImplementedError("feature shapes do not match the compiled CASTER-DTA configuration")
         for l in range(nc):
             last = l == nc - 1
             rng = ops.make_rng(seed, dropout_p, 2 * l)
@@ -323,6 +328,7 @@ def _lba_setup(ctx, inputs, output):
         raise RuntimeError("caster_gvp::lba_encoder was run with save_state=False; gradients need save_state=True")
     ctx.cfg, ctx.dropout_p = cfg, dropout_p
     ctx.shapes = [tuple(p.shape) for p in params]
+    ctx.set_materialize_grads(False)      # state / e_emb are outputs only to be saved: no zero-filled "gradients" for them
     ctx.save_for_backward(x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, seed, e_emb, *params)
 
 
@@ -334,6 +340,8 @@ def _numel(shape):
 
 
 def _lba_backward(ctx, g_out, g_state, g_masks, g_seed, g_e_emb):
+    if g_out is None:
+        return (None,) * 11
     x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, state, masks, seed, e_emb, *params = ctx.saved_tensors
     need_x = bool(ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
     gflat, g_x_s, g_x_v = torch.ops.caster_gvp.lba_encoder_backward(
@@ -474,10 +482,13 @@ def _gine_setup(ctx, inputs, output):
         raise RuntimeError("caster_gvp::gine_encoder was run with save_state=False; gradients need save_state=True")
     ctx.meta = (widths, num_ntypes, num_etypes, slope, dropout_p, len(params), len(hidden))
     ctx.shapes = [tuple(p.shape) for p in params]
+    ctx.set_materialize_grads(False)
     ctx.save_for_backward(x, ntypes, eattr, etypes, edge_index, seed, *params, *hidden, *masks)
 
 
 def _gine_backward(ctx, g_out, g_hidden, g_masks, g_seed):
+    if g_out is None:
+        return (None,) * 12
     widths, num_ntypes, num_etypes, slope, dropout_p, n_params, n_hidden = ctx.meta
     x, ntypes, eattr, etypes, edge_index, seed, *rest = ctx.saved_tensors
     params, hidden, masks = rest[:n_params], rest[n_params:n_params + n_hidden], rest[n_params + n_hidden:]

@@ -392,3 +392,4 @@ def test_backward_without_edges(protein_params, molecule_params):
         else:
             assert rel_err(p.grad, g) < 2e-4, name
     assert rel_err(gx.grad, xr.grad) < 2e-4
+
