@@ -497,7 +497,10 @@ struct GineFArgs {
   const float* eps; const float* we; const float* be; const float* w0; const float* b0;
   const float* w1; const float* b1; float slope; const float* mask; gvp::RngArgs rng; float* out;
 };
-constexpr int GF_WPB = 4, GF_TPB = WAVE * GF_WPB;
+#ifndef CGVP_GINE_FWD_WAVES
+#define CGVP_GINE_FWD_WAVES 4
+#endif
+constexpr int GF_WPB = CGVP_GINE_FWD_WAVES, GF_TPB = WAVE * GF_WPB;
 
 template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
 __global__ __launch_bounds__(GF_TPB) void gine_quad_fwd_kernel(GineFArgs a) {

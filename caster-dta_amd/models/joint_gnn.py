@@ -113,7 +113,7 @@ class JointGNN(nn.Module):
             out_lin_depth, pairwise_embedding_dim, scale_factor=out_lin_factor, include_norms=out_lin_norm_type)
         self.output_layer = nn.Linear(head_dim, 1)
         self._pair_group = None
-        self._pair_parallel = False
+        self._pair_parallel, self._pair_always = False, False
         self._pair_counts = None
         # nn.MultiheadAttention's head-averaged weights (second return value): "auto" = computed in eval mode (what
         # inference/evaluation.py:43-66 consumes), skipped in training (train_model.py:564 discards them);
@@ -121,7 +121,7 @@ class JointGNN(nn.Module):
         self.attention_weights = "auto"
 
     # ------------------------------------------------------------ multi-GPU
-    def enable_pair_parallel(self, group=None, pair_counts=None):
+    def enable_pair_parallel(self, group=None, pair_counts=None, always_communicate=False):
         """Shard pairs over the ranks of `group`: ONE all-gather of the per-pair embeddings before the head.
 
         `pair_counts`: pairs held by every rank, as the sampler knows them (list of world_size ints).  None =
@@ -135,11 +135,13 @@ class JointGNN(nn.Module):
           * parameters before it (both encoders, residue / atom lins, cross attention, protein / molecule lins)
             get the contribution of the LOCAL pairs only.  Call `reduce_pair_parallel_grads()` after
             `loss.backward()` and before `optimizer.step()`: one flat all-reduce(SUM) over RCCL.
-        Do not wrap the model in DistributedDataParallel as well (it would average what must be summed)."""
+        Do not wrap the model in DistributedDataParallel as well (it would average what must be summed).
+        `always_communicate`: issue the collectives in a one-rank group too (they are skipped there by default);
+        for rehearsing the N > 1 code path on a single GPU."""
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
-        self._pair_group, self._pair_parallel = group, True
+        self._pair_group, self._pair_parallel, self._pair_always = group, True, bool(always_communicate)
         self.set_pair_counts(pair_counts)
         return self
 
@@ -154,7 +156,7 @@ class JointGNN(nn.Module):
     def _gather_pairs(self, pair):
         import torch.distributed as dist
         world = dist.get_world_size(self._pair_group)
-        if world == 1:
+        if world == 1 and not self._pair_always:
             return pair
         rank = dist.get_rank(self._pair_group)
         counts = self._pair_counts or [int(pair.shape[0])] * world
@@ -173,7 +175,7 @@ class JointGNN(nn.Module):
         """All-reduce(SUM) of the pre-gather parameter gradients as ONE flat bucket (a few hundred KB: latency
         bound; one collective instead of ~90)."""
         import torch.distributed as dist
-        if not self._pair_parallel or dist.get_world_size(self._pair_group) == 1:
+        if not self._pair_parallel or (dist.get_world_size(self._pair_group) == 1 and not self._pair_always):
             return
         ps = [p for p in self.pre_gather_parameters() if p.requires_grad]
         for p in ps:

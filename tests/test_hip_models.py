@@ -109,3 +109,48 @@ def test_hip_graph_capture_replays(joint):
             assert torch.equal(out, eager)
     finally:
         ops.CSR_CACHE_ENABLED = old
+
+
+def test_pair_parallel_world1_on_the_hip_encoders(pretrained):
+    """`enable_pair_parallel()` on the real encoders with RCCL at world_size 1 (`always_communicate=True`: the
+    all-gather and the flat gradient all-reduce are issued although one rank needs neither): same prediction and same
+    gradients as the plain model.  The multi-rank arithmetic is covered by tests/test_pair_parallel_cpu.py (gloo)."""
+    import socket
+    import torch.distributed as dist
+    from models.joint_gnn import JointGNN
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))
+
+    def build():
+        m = JointGNN(protein_gnn_kwargs=kw["protein_gnn_kwargs"], molecule_gnn_kwargs=kw["molecule_gnn_kwargs"],
+                     **kw["joint_gnn_kwargs"])
+        m.load_state_dict(pretrained, strict=True)
+        return m.to(DEV).eval()
+
+    p, m = ds.pair_batch(6, 5, lengths=[40, 75, 33, 120, 64, 51])
+    pd, md = _to(ds.to_torch(p)), _to(ds.to_torch(m))
+    plain = build()
+    y0, _ = plain(pd, md)
+    y0.square().sum().backward()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    try:
+        par = build().enable_pair_parallel(pair_counts=[6], always_communicate=True)
+        y1, _ = par(pd, md)
+        y1.square().sum().backward()
+        par.reduce_pair_parallel_grads()
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert rel_err(y1, y0) < 1e-6
+    g0, g1 = dict(plain.named_parameters()), dict(par.named_parameters())
+    scale = max(float(v.grad.abs().max()) for v in g0.values() if v.grad is not None)
+    n = 0
+    for k, v in g0.items():
+        if v.grad is None:
+            continue
+        assert float((g1[k].grad - v.grad).abs().max()) <= 1e-5 * float(v.grad.abs().max()) + 2e-6 * scale, k
+        n += 1
+    assert n > 100
