@@ -31,8 +31,17 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
     if (g_stamp_buf && (threadIdx.x & 63) == 0)                                              \
       g_stamp_buf[((size_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * 16 + (slot)] = t_;        \
   } while (0)
+// wall-clock stamp (s_memrealtime: 100 MHz, one counter for the whole device -- s_memtime counters are per XCD)
+#define STAMP_REAL(slot)                                                                     \
+  do {                                                                                       \
+    unsigned long long t_;                                                                   \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+    if (g_stamp_buf && (threadIdx.x & 63) == 0)                                              \
+      g_stamp_buf[((size_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * 16 + (slot)] = t_;        \
+  } while (0)
 #else
 #define STAMP(slot) do {} while (0)
+#define STAMP_REAL(slot) do {} while (0)
 #endif
 
 constexpr int WAVE = 64;
@@ -487,7 +496,7 @@ __device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, i
 // result independent of scheduling: no atomics on HBM, bitwise reproducible.
 // FUSE: 0 = conv only; 1 = + node update; 2 = + node update with the output head
 template <int NTE, int FUSE, int EMODE, typename ST>
-__global__ __launch_bounds__(TPB) void conv_quad_kernel(ConvQArgs a) {
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_quad_kernel(ConvQArgs a) {
   typedef Image<0, NTE> IM;
   typedef Image<0, 0> IMN;
   constexpr int ACC = WAVE * ROW;
@@ -498,6 +507,7 @@ __global__ __launch_bounds__(TPB) void conv_quad_kernel(ConvQArgs a) {
   float* nd_img = lds + IM::CV_SIZE;
   float* acc = nd_img + ND_FLOATS + w * ACC;
   STAMP(0);
+  STAMP_REAL(14);
   const int64_t n0 = ((int64_t)blockIdx.x * WPB + w) * a.npw;
   const int nn = n0 < a.N ? (int)((a.N - n0 < a.npw) ? (a.N - n0) : a.npw) : 0;
   const int32_t e0 = nn > 0 ? a.rowptr[n0] : 0, e1 = nn > 0 ? a.rowptr[n0 + nn] : 0;
@@ -581,6 +591,8 @@ __global__ __launch_bounds__(TPB) void conv_quad_kernel(ConvQArgs a) {
       node_tile<FUSE == 2, ST>(nd_img, nd_img + IMN::ND_SIZE, lane, act, n, s, v, m1s, m1v, a.node.h_out, a.node.out);
     }
   }
+  STAMP(10);
+  STAMP_REAL(15);
 }
 
 template <int NTN, int NTE>

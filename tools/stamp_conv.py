@@ -30,6 +30,11 @@ for s in sorted(names):
     dt = b[:, s] - b[:, prev]
     print(f"{names[s]:22s} median {np.median(dt):8.0f} cyc   p90 {np.percentile(dt, 90):8.0f}")
     prev = s
-tot = b[:, 9] - b[:, 0]
+print(f"{'fused node update (+head)':22s} median {np.median(b[:, 10] - b[:, 9]):8.0f} cyc   p90 {np.percentile(b[:, 10] - b[:, 9], 90):8.0f}   (last conv launch of the pass)")
+tot = b[:, 10] - b[:, 0]
 print(f"{'wave total':22s} median {np.median(tot):8.0f} cyc   p90 {np.percentile(tot, 90):8.0f}")
-print("kernel span (first start -> last end):", (b[:, 9].max() - b[:, 0].min()), "cyc @100MHz-units? (s_memtime = shader cycles)")
+r0, r1 = b[:, 14].astype(np.float64), b[:, 15].astype(np.float64)
+print(f"wall clock (s_memrealtime, 100 MHz): first wave start -> last wave end {(r1.max() - r0.min()) / 100:.2f} us; "
+      f"wave start skew median {np.median(r0 - r0.min()) / 100:.2f} us, p90 {np.percentile(r0 - r0.min(), 90) / 100:.2f}, max {(r0 - r0.min()).max() / 100:.2f}; "
+      f"wave duration median {np.median(r1 - r0) / 100:.2f} us")
+print("kernel span (first stamp -> last stamp):", (b[:, 10].max() - b[:, 0].min()), "cyc;  first-stamp skew median", np.median(b[:, 0] - b[:, 0].min()), "max", (b[:, 0] - b[:, 0].min()).max())

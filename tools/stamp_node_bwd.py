@@ -16,7 +16,8 @@ pb = ds.protein_batch(64, 0)
 d = {k: (tuple(t.to(dev) for t in v) if isinstance(v, tuple) else v.to(dev)) for k, v in ds.to_torch(pb).items()}
 h = ctypes.CDLL(_lib.LIB_PATH)
 enc = model.protein_gnn.gnn_model
-params = enc._arena_buffer(); dims, layout = enc._hip_config(); image = enc._fragment_image(params, layout, dims)
+from gvp_hip import autograd_ops
+params = enc._arena_buffer(); dims, layout = enc._hip_config(); image = autograd_ops.fragment_image(enc.op_params(), params, layout, dims)
 N = pb.num_nodes
 L = _lib.lib()
 f32 = dict(dtype=torch.float32, device=dev)
@@ -29,7 +30,7 @@ for head in (0, 1):
     buf = torch.zeros(4096 * 16, dtype=torch.int64, device=dev)
     h.cgvp_debug_set_stamp_buffer_bwd(ctypes.c_void_p(buf.data_ptr()))
     for _ in range(3):
-        rc = L.cgvp_node_update_bwd(C.byref(dims), C.byref(layout), P(image), 1 if head else 0, P(hh), P(dh), P(None), P(None),
+        rc = L.cgvp_node_update_bwd(C.byref(dims), C.byref(layout), P(image), 1 if head else 0, P(hh), P(dh), P(None), P(None), None,
                                     P(hh if head else None), P(gout if head else None), P(None if head else g), P(None), P(None), N, head, P(gdh), P(None), P(None),
                                     P(gp), P(ws), P(None), P(None), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0, rc
@@ -51,7 +52,7 @@ for head in (0, 1):
     ev0.record()
     for _ in range(20):
         nsegs.value = 0
-        L.cgvp_node_update_bwd(C.byref(dims), C.byref(layout), P(image), 1 if head else 0, P(hh), P(dh), P(None), P(None),
+        L.cgvp_node_update_bwd(C.byref(dims), C.byref(layout), P(image), 1 if head else 0, P(hh), P(dh), P(None), P(None), None,
                                P(hh if head else None), P(gout if head else None), P(None if head else g), P(None), P(None), N, head, P(gdh), P(None), P(None),
                                P(gp), P(ws), segs, C.byref(nsegs), C.c_void_p(torch.cuda.current_stream().cuda_stream))
     ev1.record(); torch.cuda.synchronize()
