@@ -45,8 +45,12 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32: 64 FLOP/clk/SIMD = the 
 # Counted in the gfx950 ISA of the kernels (v_mfma in one tile body): conv backward 230 since the edge embedding moved to
 # its own once-per-step kernel (319 in round 1); forward 103 in the layer that derives the edge embedding, 71 in layers
 # that read the store.  Useful MACs per edge of the conv backward: 3 x the message GVPs' 2,543.
-MFMA_PER_TILE = {"conv_fwd": 103, "conv_bwd": 230}
+# --dtype bf16 (tools/count_mfma.py): every GEMM with more than one k-step runs on v_mfma_f32_16x16x16_bf16 (8,192 FLOP,
+# 4 passes = 16 cycles), one-step GEMMs stay on the fp32 instruction (32 cycles): (fp32 count, bf16 count) per tile.
+MFMA_PER_TILE = {"f32": {"conv_fwd": (103, 0), "conv_bwd": (230, 0)}, "bf16": {"conv_fwd": (18, 26), "conv_bwd": (30, 54)}}
 MAC_PER_EDGE = {"conv_fwd": 3669, "conv_bwd": 3 * 2543}
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (the K=32 forms; the K=16 form used here is half of it)
+MATRIX_PIPE_CYCLES_PER_US = 1024 * 2400.0       # 1,024 SIMDs at 2.4 GHz
 
 
 def parse():
@@ -334,14 +338,17 @@ def main():
                 hbm = dict(achieved=round(nbytes / avg / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                            frac=round(nbytes / avg / 1e9 / PEAK_HBM_GBS, 4), floor_us=round(nbytes / PEAK_HBM_GBS / 1e3, 2))
                 tiles = (E + 15) // 16                # 16 sorted edges per wave tile
-                issued = MFMA_PER_TILE[name] * tiles * 2048.0
+                n32, n16 = MFMA_PER_TILE[args.dtype][name]
+                issued = (n32 * 2048.0 + n16 * 8192.0) * tiles
                 useful = 2.0 * MAC_PER_EDGE[name] * E
+                peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
                 mfma = dict(achieved=round(useful / avg / 1e12, 2), issued=round(issued / avg / 1e12, 2),
-                            peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                            frac=round(useful / avg / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                            frac_issued=round(issued / avg / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                            floor_us=round(issued / PEAK_F32_MFMA_TFLOPS / 1e6, 2),
-                            mfma_per_16_edges=MFMA_PER_TILE[name], useful_mac_per_edge=MAC_PER_EDGE[name])
+                            peak=peak, unit="TFLOP/s",
+                            frac=round(useful / avg / 1e12 / peak, 4),
+                            frac_issued=round(issued / avg / 1e12 / peak, 4),
+                            # time the matrix pipes need for the instructions issued (32 cycles per fp32, 16 per bf16 MFMA)
+                            floor_us=round(tiles * (n32 * 32.0 + n16 * 16.0) / MATRIX_PIPE_CYCLES_PER_US, 2),
+                            mfma_per_16_edges=n32 + n16, mfma_f32_bf16=[n32, n16], useful_mac_per_edge=MAC_PER_EDGE[name])
                 # the bound is whichever floor is higher for THIS kernel at THIS size
                 bound = "mfma" if mfma["floor_us"] > hbm["floor_us"] else "hbm"
                 top = mfma if bound == "mfma" else hbm
@@ -378,7 +385,7 @@ def main():
             "config": {"workload": args.workload, "pairs_per_gpu": wl["pairs"], "residues_per_gpu": pb.num_nodes,
                        "protein_edges_per_gpu": pb.num_edges, "atoms_per_gpu": mb.num_nodes,
                        "drug_edges_per_gpu": mb.num_edges, "encoder": f"CASTER-DTA({convs},{convs})", "pass": args.mode,
-                       "activation_storage": "bf16 (protein encoder; fp32 accumulate, fp32 gradients)" if args.dtype == "bf16" else "fp32",
+                       "activation_storage": "bf16 (protein encoder: bf16 activations in HBM and bf16 matrix-core operands, fp32 accumulate, fp32 weights and gradient buffers)" if args.dtype == "bf16" else "fp32",
                        "scope": args.scope, "train_mode": bool(dropout_on), "dropout_p": 0.2 if dropout_on else 0.0,
                        "csr_build_in_step": ("collate" if args.collate_csr else not args.cache_csr),
                        "hip_graph": graph is not None, "kernels": ops.VARIANT, "parallelism": par},

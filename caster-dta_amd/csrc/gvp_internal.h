@@ -20,7 +20,7 @@ constexpr int kBwdMaxGrid = CGVP_BWD_MAX_GRID;    // persistent workgroups of th
 
 namespace quad {
 int offsets(int nt_node, int nt_edge, int num_convs, QuadOffsets* o);
-int prepare(const gvp::EncLayout& L, int num_convs, const float* params, float* image, hipStream_t st);
+int prepare(const gvp::EncLayout& L, int num_convs, int packed_bf16, const float* params, float* image, hipStream_t st);
 int node_embed(int nt_node, const float* img, const float* x_s, const float* x_v, const int64_t* ntypes,
                int64_t N, float* h, unsigned long long* rng_state, unsigned long long* rng_out, int bf16, hipStream_t st);
 int conv(int nt_edge, const float* img, const float* h, const float* e_s, const float* e_v,

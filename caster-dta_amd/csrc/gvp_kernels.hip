@@ -628,7 +628,8 @@ int cgvp_lba_prepare(const cgvp_dims* dims, const cgvp_layout* layout, const flo
                      void* stream) {
   if (int rc = check_dims(dims)) return rc;
   if (!layout || !params || !image) return CGVP_ERR_BAD_ARG;
-  if (int rc = quad::prepare(cvt(*layout), num_convs_of(*layout), params, image, (hipStream_t)stream)) return rc;
+  // bf16 storage: the fragments of every GEMM with K > 4 are packed as bf16 for v_mfma_f32_16x16x16_bf16 (gvp_quad.h)
+  if (int rc = quad::prepare(cvt(*layout), num_convs_of(*layout), is_bf16(dims) ? 1 : 0, params, image, (hipStream_t)stream)) return rc;
   return launch_status();
 }
 

@@ -47,6 +47,7 @@ constexpr int ceil4(int x) { return (x + 3) / 4; }
 struct bf16s {};
 template <typename ST> struct Io;
 template <> struct Io<float> {
+  static constexpr bool BF = false;          // matrix-core operand type of the channel GEMMs: fp32 (16x16x4) / bf16 (16x16x16)
   static __device__ __forceinline__ f4 ld4(const float* p, int64_t i) { return *reinterpret_cast<const f4*>(p + i); }
   static __device__ __forceinline__ float ld(const float* p, int64_t i) { return p[i]; }
   static __device__ __forceinline__ void st4(float* p, int64_t i, f4 v) { *reinterpret_cast<f4*>(p + i) = v; }
@@ -57,6 +58,7 @@ template <> struct Io<float> {
   static __device__ __forceinline__ f4 rt4(f4 v) { return v; }
 };
 template <> struct Io<bf16s> {
+  static constexpr bool BF = true;
   static __device__ __forceinline__ float widen(uint32_t hi16) { return __uint_as_float(hi16); }
   static __device__ __forceinline__ uint16_t narrow(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
   static __device__ __forceinline__ f4 ld4(const float* p, int64_t i) {        // 4 consecutive bf16 = one 8-byte load
@@ -159,12 +161,71 @@ __device__ __forceinline__ f4 mfma(float a, float b, f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ---- bf16 matrix-core path (activation storage bf16, template flag BF) ------------------------------------------
+// v_mfma_f32_16x16x16_bf16: lane (m | n = l & 15, g = l >> 4) supplies k = 4g .. 4g+3 as four bf16, D as above.  Four
+// consecutive k-STEPS of the fp32 scheme (step s, group g) become the four k's of one lane, so ONE instruction (4
+// passes) replaces four v_mfma_f32_16x16x4_f32 (8 passes each) and the chaining property is untouched: an accumulator
+// tile, rounded to bf16 two registers at a time (v_cvt_pk_bf16_f32), is still directly the next B operand.  The
+// weight fragments of such a GEMM are PACKED in the image: 8 bytes per lane per group of four steps, in the first
+// ceil(NSTEPS / 4) * 128 floats of the GEMM's (mt) region -- which fits the fp32 region for NSTEPS >= 2, so every
+// offset of the image layout is unchanged.  One-step GEMMs (K <= 4: wh / wv of the 4-channel GVPs) stay on the fp32
+// instruction with fp32 fragments.  Accumulation is fp32 either way.
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+template <class G> constexpr bool packs_bf16() { return G::NSTEPS >= 2; }
+__host__ __device__ inline uint32_t bf16_bits(float v) { return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)v); }   // RNE
+template <class G>
+__host__ __device__ float packed_element(const float* W, int idx) {
+  constexpr int NS_ = G::NSTEPS, REGION = NS_ * 64;
+  const int mt = idx / REGION, u = idx - mt * REGION, q = u >> 7;
+  if (q >= ceil4(NS_)) return 0.f;
+  const int lane = (u & 127) >> 1, s0 = 4 * q + 2 * (u & 1);
+  const float lo = s0 < NS_ ? G::element(W, (mt * NS_ + s0) * 64 + lane) : 0.f;
+  const float hi = s0 + 1 < NS_ ? G::element(W, (mt * NS_ + s0 + 1) * 64 + lane) : 0.f;
+  return __builtin_bit_cast(float, bf16_bits(lo) | (bf16_bits(hi) << 16));
+}
+template <class G>
+__host__ __device__ float gemm_element(const float* W, int idx, bool packed) {
+  return (packed && packs_bf16<G>()) ? packed_element<G>(W, idx) : G::element(W, idx);
+}
+// two floats -> one register of two bf16 (RNE).  Written as a 2-vector conversion so that it selects ONE
+// v_cvt_pk_bf16_f32 and the compiler keeps track of the VALU -> MFMA wait states (an inline-asm version of the same
+// instruction is invisible to the hazard recognizer and fed the matrix core stale registers).
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{lo, hi}, bf2));
+}
+__device__ __forceinline__ bf4 pack_bf4(float a, float b, float c, float d) {
+  return __builtin_bit_cast(bf4, uint2{cvt_pk_bf16(a, b), cvt_pk_bf16(c, d)});
+}
+__device__ __forceinline__ f4 mfma_bf(bf4 a, bf4 b, f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
 // acc[j] += sum over this GEMM's k-steps of A-fragment(mt, s) x b[j][s] for TN
 // tiles in lockstep: one LDS fragment read feeds TN independent MFMA chains.
 // With a single tile, long chains are split over two accumulators instead (a
 // dependent f32 MFMA chain issues every 40 cycles, independent ones every 32).
-template <class G, int TN>
+template <class G, int TN, bool BF = false>
 __device__ __forceinline__ void apply(const float* frag, int mt, const float (&b)[TN][G::NSTEPS], f4 (&acc)[TN], int lane) {
+  if constexpr (BF && packs_bf16<G>()) {
+    // (read as a vector of FLOATS: the staging code stores floats, and a load through an integer type may be moved
+    // across those stores by type-based alias analysis)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2* f = reinterpret_cast<const f2*>(frag + mt * G::NSTEPS * 64) + lane;
+#pragma unroll
+    for (int q = 0; q < ceil4(G::NSTEPS); ++q) {
+      const bf4 a = __builtin_bit_cast(bf4, f[q * 64]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float x1 = 4 * q + 1 < G::NSTEPS ? b[j][4 * q + 1 < G::NSTEPS ? 4 * q + 1 : 0] : 0.f;
+        const float x2 = 4 * q + 2 < G::NSTEPS ? b[j][4 * q + 2 < G::NSTEPS ? 4 * q + 2 : 0] : 0.f;
+        const float x3 = 4 * q + 3 < G::NSTEPS ? b[j][4 * q + 3 < G::NSTEPS ? 4 * q + 3 : 0] : 0.f;
+        acc[j] = mfma_bf(a, pack_bf4(b[j][4 * q], x1, x2, x3), acc[j]);
+      }
+    }
+    return;
+  }
   const float* f = frag + mt * G::NSTEPS * 64 + lane;
   if (TN == 1 && G::NSTEPS >= 8) {
     f4 acc2 = {0.f, 0.f, 0.f, 0.f};
@@ -275,8 +336,20 @@ __device__ __forceinline__ void transpose_slots(const float (&v)[NSTEPS], f4 (&o
 }
 
 // acc[mt][nt] = sum over the 16 items of the tile of A_T[mt] (x) B_T[nt]
-template <int MT, int NT_>
+template <int MT, int NT_, bool BF = false>
 __device__ __forceinline__ void outer_items(const f4 (&A)[MT], const f4 (&B)[NT_], f4 (&acc)[MT][NT_]) {
+  if constexpr (BF) {            // the 16 items of the tile are the 16 k's of ONE bf16 instruction per block
+    bf4 a[MT], b[NT_];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[mt] = pack_bf4(A[mt][0], A[mt][1], A[mt][2], A[mt][3]);
+#pragma unroll
+    for (int nt = 0; nt < NT_; ++nt) b[nt] = pack_bf4(B[nt][0], B[nt][1], B[nt][2], B[nt][3]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT_; ++nt) acc[mt][nt] = mfma_bf(a[mt], b[nt], acc[mt][nt]);
+    return;
+  }
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
@@ -324,6 +397,17 @@ __device__ __forceinline__ void add_where(float* const (&p)[N], const bool (&on)
 template <class Acc, class RowSegs, class ColSegs, int MT, int NT_>
 __device__ __forceinline__ void flush_slots(float* dst, bool first, int LD, const f4 (&acc)[MT][NT_], int lane) {
   const int n = lane & 15, gq_ = lane >> 4;
+#ifdef CGVP_EXPERIMENT_NOFLUSH       // timing experiment only (wrong results): keep the producers alive, drop the LDS read-add-writes
+  {
+    float t = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT_; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) t += acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2] + acc[mt][nt][3];
+    *Acc::trash() += t;
+    return;
+  }
+#endif
 #pragma unroll
   for (int nt = 0; nt < NT_; ++nt) {
     const int cs = 4 * nt + (n >> 2);
@@ -394,11 +478,11 @@ struct GvpQ {
   static constexpr int SIZE = V_BSV + 16;        // floats; multiple of 4
 
   // element `idx` of the image slice, from the GVP's arena block `P`
-  static __host__ __device__ float element(const float* P, int idx) {
-    if (idx < F_WS * 64) return GWh::element(P, idx);
-    if (idx < F_WV * 64) return GWs::element(P + A::ws(NT), idx - F_WS * 64);
-    if (VO > 0 && idx < F_WSV * 64) return GWv::element(P + A::wv(NT), idx - F_WV * 64);
-    if (VO > 0 && idx < V_BS) return GWsv::element(P + A::wsv(NT), idx - F_WSV * 64);
+  static __host__ __device__ float element(const float* P, int idx, bool packed = false) {
+    if (idx < F_WS * 64) return gemm_element<GWh>(P, idx, packed);
+    if (idx < F_WV * 64) return gemm_element<GWs>(P + A::ws(NT), idx - F_WS * 64, packed);
+    if (VO > 0 && idx < F_WSV * 64) return gemm_element<GWv>(P + A::wv(NT), idx - F_WV * 64, packed);
+    if (VO > 0 && idx < V_BS) return gemm_element<GWsv>(P + A::wsv(NT), idx - F_WSV * 64, packed);
     if (idx < V_WT) return P[A::bs(NT) + (idx - V_BS)];
     if (idx < V_BSV) { const int j = idx - V_WT; return P[A::ws(NT) + (j % SO) * K + (j / SO)]; }
     const int o = idx - V_BSV;
@@ -417,7 +501,7 @@ struct GvpQ {
     f4 vp[3];                    // wv.vh per plane before gating
     f4 sg;                       // sigmoid(gate) (P2 rows o)
   };
-  template <int TN>
+  template <int TN, bool BF = false>
   static __device__ __forceinline__ void forward(const float* img, int lane, const int (&type)[TN],
                                                  const float (&bs)[TN][SSTEPS], const float (&bv)[TN][3][VSTEPS],
                                                  f4 (&so)[TN][OT], float (&vo)[TN][3][VOR], Cache (&c)[TN]) {
@@ -433,7 +517,7 @@ struct GvpQ {
 #pragma unroll
         for (int s = 0; s < VSTEPS; ++s) b[j][s] = bv[j][p][s];
       }
-      apply<GWh, TN>(img + F_WH * 64, 0, b, acc, lane);
+      apply<GWh, TN, BF>(img + F_WH * 64, 0, b, acc, lane);
 #pragma unroll
       for (int j = 0; j < TN; ++j) c[j].vh[p] = acc[j];
     }
@@ -457,7 +541,7 @@ struct GvpQ {
         acc[j] = *reinterpret_cast<const f4*>(img + V_BS + 16 * t + 4 * g);
         if (NT > 0) acc[j] += *reinterpret_cast<const f4*>(img + V_WT + type[j] * SO + 16 * t + 4 * g);
       }
-      apply<GWs, TN>(img + F_WS * 64, t, bfull, acc, lane);
+      apply<GWs, TN, BF>(img + F_WS * 64, t, bfull, acc, lane);
 #pragma unroll
       for (int j = 0; j < TN; ++j) c[j].sp[t] = acc[j];
     }
@@ -473,7 +557,7 @@ struct GvpQ {
 #pragma unroll
         for (int r = 0; r < 4; ++r) gate[j][r] = img[V_BSV + ((4 * r + g) & 15)];
       }
-      apply<GWsv, TN>(img + F_WSV * 64, 0, bsp, gate, lane);
+      apply<GWsv, TN, BF>(img + F_WSV * 64, 0, bsp, gate, lane);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -488,7 +572,7 @@ struct GvpQ {
 #pragma unroll
           for (int r = 0; r < HR; ++r) bh[j][r] = c[j].vh[p][r];
         }
-        apply<GWv, TN>(img + F_WV * 64, 0, bh, acc, lane);
+        apply<GWv, TN, BF>(img + F_WV * 64, 0, bh, acc, lane);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           c[j].vp[p] = acc[j];
@@ -517,11 +601,11 @@ struct GvpQ {
   static constexpr int FT_WV = FT_WSV + (VO > 0 ? TWsv::NFRAG : 0);
   static constexpr int FT_WH = FT_WV + (VO > 0 ? TWv::NFRAG : 0);
   static constexpr int SIZE_T = (FT_WH + TWh::NFRAG) * 64;
-  static __host__ __device__ float element_t(const float* P, int idx) {
-    if (idx < FT_WSV * 64) return TWs::element(P + A::ws(NT), idx);
-    if (VO > 0 && idx < FT_WV * 64) return TWsv::element(P + A::wsv(NT), idx - FT_WSV * 64);
-    if (VO > 0 && idx < FT_WH * 64) return TWv::element(P + A::wv(NT), idx - FT_WV * 64);
-    return TWh::element(P, idx - FT_WH * 64);
+  static __host__ __device__ float element_t(const float* P, int idx, bool packed = false) {
+    if (idx < FT_WSV * 64) return gemm_element<TWs>(P + A::ws(NT), idx, packed);
+    if (VO > 0 && idx < FT_WV * 64) return gemm_element<TWsv>(P + A::wsv(NT), idx - FT_WSV * 64, packed);
+    if (VO > 0 && idx < FT_WH * 64) return gemm_element<TWv>(P + A::wv(NT), idx - FT_WV * 64, packed);
+    return gemm_element<TWh>(P, idx - FT_WH * 64, packed);
   }
 
   struct Grads {          // per-lane gradients the weight-gradient GEMMs consume
@@ -533,6 +617,7 @@ struct GvpQ {
 
   // Backward of `forward` for one tile.  d_so / d_vo: gradients of the outputs;
   // d_bs / d_bv: gradients of the k-slot inputs (same slots as bs / bv).
+  template <bool BF = false>
   static __device__ __forceinline__ void backward(const float* imgT, int lane, const Cache& c,
                                                   const f4 (&d_so)[OT], const float (&d_vo)[3][VOR],
                                                   float (&d_bs)[SSTEPS], float (&d_bv)[3][VSTEPS], Grads& gr) {
@@ -559,7 +644,7 @@ struct GvpQ {
 #pragma unroll
       for (int t = 0; t < OT; ++t) {
         f4 acc[1] = {gr.dsp[t]};
-        apply<TWsv, 1>(imgT + FT_WSV * 64, t, bg, acc, lane);
+        apply<TWsv, 1, BF>(imgT + FT_WSV * 64, t, bg, acc, lane);
         gr.dsp[t] = acc[0];
       }
 #pragma unroll
@@ -568,7 +653,7 @@ struct GvpQ {
 #pragma unroll
         for (int r = 0; r < TWv::NSTEPS; ++r) b[0][r] = gr.dvp[p][r];
         f4 acc[1] = {zero};
-        apply<TWv, 1>(imgT + FT_WV * 64, 0, b, acc, lane);
+        apply<TWv, 1, BF>(imgT + FT_WV * 64, 0, b, acc, lane);
         gr.dvh[p] = acc[0];
       }
     }
@@ -582,7 +667,7 @@ struct GvpQ {
 #pragma unroll
       for (int mt = 0; mt < TWs::MT; ++mt) {
         f4 acc[1] = {zero};
-        apply<TWs, 1>(imgT + FT_WS * 64, mt, bd, acc, lane);
+        apply<TWs, 1, BF>(imgT + FT_WS * 64, mt, bd, acc, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int slot = 4 * mt + r;
@@ -604,7 +689,7 @@ struct GvpQ {
 #pragma unroll
       for (int r = 0; r < TWh::NSTEPS; ++r) b[0][r] = gr.dvh[p][r];
       f4 acc[1] = {zero};
-      apply<TWh, 1>(imgT + FT_WH * 64, 0, b, acc, lane);
+      apply<TWh, 1, BF>(imgT + FT_WH * 64, 0, b, acc, lane);
 #pragma unroll
       for (int s2 = 0; s2 < VSTEPS; ++s2) d_bv[p][s2] = acc[0][s2];
     }
@@ -617,7 +702,7 @@ struct GvpQ {
   static constexpr int NTS = ceil4(NT);                 // k-steps of the one-hot type columns
   typedef Segs<Seg<P2, 0, (NT > 0 ? NT : 1)>, SSegs, Seg<P2, NT + SI, H>> WsCols;   // [types | scalars | norms]
   static constexpr bool PACK_V = VO > 0 && VOR + HR <= 4 && HR + VSTEPS <= 4;   // dWv and dWh fit one block
-  template <class Acc>
+  template <class Acc, bool BF = false>
   static __device__ __forceinline__ void weight_grads(float* gblk, bool first, int lane, int type, bool active,
                                                       const float (&bs)[SSTEPS], const float (&bv)[3][VSTEPS],
                                                       const Cache& c, const Grads& gr, float* tscr = nullptr) {
@@ -647,7 +732,7 @@ struct GvpQ {
       for (int x = 0; x < OT; ++x)
 #pragma unroll
         for (int y = 0; y < ceil4(NB); ++y) acc[x][y] = zero;
-      outer_items<OT, ceil4(NB)>(AT, BT, acc);
+      outer_items<OT, ceil4(NB), BF>(AT, BT, acc);
       flush_slots<Acc, Segs<Seg<P1, 0, SO>>, WsCols, OT, ceil4(NB)>(gblk + A::ws(NT), first, K, acc, lane);
     }
 #pragma unroll
@@ -677,7 +762,7 @@ struct GvpQ {
       transpose_slots<4 * OT>(b, BT, lane, tscr);
 #pragma unroll
       for (int y = 0; y < OT; ++y) acc[0][y] = zero;
-      outer_items<1, OT>(AT, BT, acc);
+      outer_items<1, OT, BF>(AT, BT, acc);
       flush_slots<Acc, Segs<Seg<P2, 0, (VO > 0 ? VO : 1)>>, Segs<Seg<P1, 0, SO>>, 1, OT>(gblk + A::wsv(NT), first, SO, acc, lane);
       {
         float tot[VOR];
@@ -704,7 +789,7 @@ struct GvpQ {
           f4 AV[1], BH[1];
           transpose_slots<VOR>(av, AV, lane, tscr);
           transpose_slots<HR>(bh, BH, lane, tscr);
-          outer_items<1, 1>(AV, BH, accv);
+          outer_items<1, 1, BF>(AV, BH, accv);
         }
         flush_slots<Acc, Segs<Seg<P2, 0, (VO > 0 ? VO : 1)>>, Segs<Seg<P2, 0, H>>, 1, 1>(gblk + A::wv(NT), first, H, accv, lane);
       }
@@ -728,7 +813,7 @@ struct GvpQ {
         f4 A2[1], B2[1];
         transpose_slots<VOR + HR>(a2, A2, lane, tscr);
         transpose_slots<HR + VSTEPS>(b2, B2, lane, tscr);
-        outer_items<1, 1>(A2, B2, acc2);
+        outer_items<1, 1, BF>(A2, B2, acc2);
       }
       flush_slots<Acc, Segs<Seg<P2, 0, (VO > 0 ? VO : 1)>, SegNone<HR>>, Segs<Seg<P2, 0, H>, SegNone<VSTEPS>>, 1, 1>(
           gblk + A::wv(NT), first, H, acc2, lane);
@@ -747,7 +832,7 @@ struct GvpQ {
         static_assert(VSTEPS <= 4 && HR <= 4, "vector operands fit one slot tile");
         transpose_slots<HR>(ah, AH, lane, tscr);
         transpose_slots<VSTEPS>(bin, BI, lane, tscr);
-        outer_items<1, 1>(AH, BI, acch);
+        outer_items<1, 1, BF>(AH, BI, acch);
       }
       flush_slots<Acc, Segs<Seg<P2, 0, H>>, VSegs, 1, 1>(gblk, first, VI, acch, lane);
     }

@@ -44,8 +44,24 @@ constexpr int TILE = 16;
     if (g_stamp_buf_bwd && (threadIdx.x & 63) == 0)                                          \
       g_stamp_buf_bwd[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (slot)] = t_;    \
   } while (0)
+// wall-clock start / end of every wave of a kernel (s_memrealtime: 100 MHz, one counter for the whole device), kept per
+// kernel kind behind the cycle stamps: buffer[4096 * 16 + (kind * 4096 + wave) * 2 + {0: start, 1: end}]
+struct WallStamp {
+  int kind;
+  __device__ __forceinline__ explicit WallStamp(int k) : kind(k) { put(0); }
+  __device__ __forceinline__ ~WallStamp() { put(1); }
+  __device__ __forceinline__ void put(int which) const {
+    unsigned long long t_;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+    const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (g_stamp_buf_bwd && (threadIdx.x & 63) == 0 && wave < 4096)
+      g_stamp_buf_bwd[4096 * 16 + ((size_t)kind * 4096 + wave) * 2 + which] = t_;
+  }
+};
+#define WALL_STAMP(kind) WallStamp wall_stamp_(kind)
 #else
 #define STAMP(slot) do {} while (0)
+#define WALL_STAMP(kind) do {} while (0)
 #endif
 // Every backward kernel runs ONE workgroup of 8 waves per CU (2 per SIMD) that owns the CU's
 // LDS: [trash word per thread | image slices | one private weight-gradient block per wave (AccPriv)].  Waves take
@@ -153,6 +169,7 @@ static_assert(node_bwd_lds_floats() * 4 <= 160 * 1024, "node backward LDS plan e
 // by the same lanes that overwrite them at the end of the tile.
 template <typename ST>
 __global__ __launch_bounds__(BW_TPB, 2) void node_bwd_kernel(NodeBArgs a) {
+  WALL_STAMP(0);
   typedef Image<0, 0> IM;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* f_node = lds + BW_TPB;                                     // lds[0..BW_TPB): AccPriv::trash()
@@ -213,14 +230,14 @@ __global__ __launch_bounds__(BW_TPB, 2) void node_bwd_kernel(NodeBArgs a) {
     for (int r = 0; r < 4; ++r) bs0[0][r] = y[0][r];
 #pragma unroll
     for (int p = 0; p < 3; ++p) bv0[0][p][0] = yv[p][0];
-    QFf0::forward<1>(f_node + IM::ND_FF0, lane, zt, bs0, bv0, hs, hv, c0);
+    QFf0::template forward<1, Io<ST>::BF>(f_node + IM::ND_FF0, lane, zt, bs0, bv0, hs, hv, c0);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) bs1[0][4 * t + r] = hs[0][t][r];
 #pragma unroll
     for (int p = 0; p < 3; ++p) { bv1[0][p][0] = hv[0][p][0]; bv1[0][p][1] = hv[0][p][1]; }
-    QFf1::forward<1>(f_node + IM::ND_FF1, lane, zt, bs1, bv1, s2, v2, c1);
+    QFf1::template forward<1, Io<ST>::BF>(f_node + IM::ND_FF1, lane, zt, bs1, bv1, s2, v2, c1);
     f4 z[1] = {y[0] + s2[0][0] * m1s};
     float zv[3][1];
 #pragma unroll
@@ -240,9 +257,9 @@ __global__ __launch_bounds__(BW_TPB, 2) void node_bwd_kernel(NodeBArgs a) {
       float d_vo[3][1] = {{gv[0][0] * m1v}, {gv[1][0] * m1v}, {gv[2][0] * m1v}};
       QFf1::Grads gr1;
       STAMP(4);
-      QFf1::backward(t_node + IM::TN_FF1, lane, c1[0], d_so, d_vo, d_hs, d_hv, gr1);
+      QFf1::template backward<Io<ST>::BF>(t_node + IM::TN_FF1, lane, c1[0], d_so, d_vo, d_hs, d_hv, gr1);
       STAMP(5);
-      QFf1::weight_grads<AccPriv>(gblk + NB_FF1, first, lane, 0, active, bs1[0], bv1[0], c1[0], gr1, tscr);
+      QFf1::template weight_grads<AccPriv, Io<ST>::BF>(gblk + NB_FF1, first, lane, 0, active, bs1[0], bv1[0], c1[0], gr1, tscr);
     }
     {
       f4 d_so[4];
@@ -251,9 +268,9 @@ __global__ __launch_bounds__(BW_TPB, 2) void node_bwd_kernel(NodeBArgs a) {
       float d_ys[4], d_yv[3][1];
       QFf0::Grads gr0;
       STAMP(6);
-      QFf0::backward(t_node + IM::TN_FF0, lane, c0[0], d_so, d_hv, d_ys, d_yv, gr0);
+      QFf0::template backward<Io<ST>::BF>(t_node + IM::TN_FF0, lane, c0[0], d_so, d_hv, d_ys, d_yv, gr0);
       STAMP(7);
-      QFf0::weight_grads<AccPriv>(gblk + NB_FF0, first, lane, 0, active, bs0[0], bv0[0], c0[0], gr0, tscr);
+      QFf0::template weight_grads<AccPriv, Io<ST>::BF>(gblk + NB_FF0, first, lane, 0, active, bs0[0], bv0[0], c0[0], gr0, tscr);
 #pragma unroll
       for (int r = 0; r < 4; ++r) gs[0][r] += d_ys[r];
 #pragma unroll
@@ -300,6 +317,7 @@ constexpr int head_bwd_lds_floats() { return BW_TPB + Image<0, 0>::HD_SIZE + Ima
 
 template <typename ST>
 __global__ __launch_bounds__(BW_TPB, 2) void head_bwd_kernel(HeadBArgs a) {
+  WALL_STAMP(1);
   typedef Image<0, 0> IM;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* f_head = lds + BW_TPB;
@@ -343,11 +361,11 @@ __global__ __launch_bounds__(BW_TPB, 2) void head_bwd_kernel(HeadBArgs a) {
     for (int p = 0; p < 3; ++p) bvh[0][p][0] = wvn[p][0];
     f4 o[1][4];
     QHead::Cache ch[1];
-    QHead::forward<1>(f_head + IM::HD_GVP, lane, zt, bsh, bvh, o, dummy, ch);
+    QHead::template forward<1, Io<ST>::BF>(f_head + IM::HD_GVP, lane, zt, bsh, bvh, o, dummy, ch);
     float d_vo[3][1] = {{0.f}, {0.f}, {0.f}}, d_bs[4], d_bv[3][1];
     QHead::Grads grh;
-    QHead::backward(t_head, lane, ch[0], d_o, d_vo, d_bs, d_bv, grh);
-    QHead::weight_grads<AccPriv>(gblk + HB_GVP, first, lane, 0, active, bsh[0], bvh[0], ch[0], grh, tscr);
+    QHead::template backward<Io<ST>::BF>(t_head, lane, ch[0], d_o, d_vo, d_bs, d_bv, grh);
+    QHead::template weight_grads<AccPriv, Io<ST>::BF>(gblk + HB_GVP, first, lane, 0, active, bsh[0], bvh[0], ch[0], grh, tscr);
     f4 dws[1] = {f4{d_bs[0], d_bs[1], d_bs[2], d_bs[3]}};
     float dwv[3][1] = {{d_bv[0][0]}, {d_bv[1][0]}, {d_bv[2][0]}};
     f4 dga[1], dbe[1];
@@ -403,6 +421,7 @@ struct ConvBArgs {
 
 template <int NTE, typename ST>
 __global__ __launch_bounds__(CB_TPB, CB_WPB / 4) void conv_bwd_kernel(ConvBArgs a) {
+  WALL_STAMP(2);
   typedef Image<0, NTE> IM;
   typedef ConvBImg<NTE> BI;
   typedef ConvBlk<NTE> B;
@@ -487,17 +506,17 @@ __global__ __launch_bounds__(CB_TPB, CB_WPB / 4) void conv_bwd_kernel(ConvBArgs 
       QMsg0::Cache c0[1];
       QMsg1::Cache c1[1];
       QMsg2::Cache c2[1];
-      QMsg0::forward<1>(img + IM::CV_M0, lane, zt, b0, bv0, s1, v1, c0);
+      QMsg0::template forward<1, Io<ST>::BF>(img + IM::CV_M0, lane, zt, b0, bv0, s1, v1, c0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) b1[0][r] = s1[0][0][r];
 #pragma unroll
       for (int d = 0; d < 3; ++d) bv1[0][d][0] = v1[0][d][0];
-      QMsg1::forward<1>(img + IM::CV_M1, lane, zt, b1, bv1, s2, v2, c1);
+      QMsg1::template forward<1, Io<ST>::BF>(img + IM::CV_M1, lane, zt, b1, bv1, s2, v2, c1);
 #pragma unroll
       for (int r = 0; r < 4; ++r) b2[0][r] = s2[0][0][r];
 #pragma unroll
       for (int d = 0; d < 3; ++d) bv2[0][d][0] = v2[0][d][0];
-      QMsg2::forward<1>(img + IM::CV_M2, lane, zt, b2, bv2, s3, v3, c2);
+      QMsg2::template forward<1, Io<ST>::BF>(img + IM::CV_M2, lane, zt, b2, bv2, s3, v3, c2);
 
       STAMP(3);
       // ---- backward through the three message GVPs
@@ -506,18 +525,18 @@ __global__ __launch_bounds__(CB_TPB, CB_WPB / 4) void conv_bwd_kernel(ConvBArgs 
         f4 d_so[1] = {d_ms};
         float d_vo[3][1] = {{d_mv[0]}, {d_mv[1]}, {d_mv[2]}};
         QMsg2::Grads gr;
-        QMsg2::backward(imgT + IM::TC_M2, lane, c2[0], d_so, d_vo, d_b, d_bv, gr);
+        QMsg2::template backward<Io<ST>::BF>(imgT + IM::TC_M2, lane, c2[0], d_so, d_vo, d_b, d_bv, gr);
         STAMP(10);
-        QMsg2::weight_grads<AccPriv>(gblk + B::M2, first, lane, 0, active, b2[0], bv2[0], c2[0], gr, CB_TSCR);
+        QMsg2::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::M2, first, lane, 0, active, b2[0], bv2[0], c2[0], gr, CB_TSCR);
       }
       {
         f4 d_so[1] = {f4{d_b[0], d_b[1], d_b[2], d_b[3]}};
         float d_vo[3][1] = {{d_bv[0][0]}, {d_bv[1][0]}, {d_bv[2][0]}};
         QMsg1::Grads gr;
         STAMP(11);
-        QMsg1::backward(imgT + IM::TC_M1, lane, c1[0], d_so, d_vo, d_b, d_bv, gr);
+        QMsg1::template backward<Io<ST>::BF>(imgT + IM::TC_M1, lane, c1[0], d_so, d_vo, d_b, d_bv, gr);
         STAMP(12);
-        QMsg1::weight_grads<AccPriv>(gblk + B::M1, first, lane, 0, active, b1[0], bv1[0], c1[0], gr, CB_TSCR);
+        QMsg1::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::M1, first, lane, 0, active, b1[0], bv1[0], c1[0], gr, CB_TSCR);
       }
       float d_b0[16], d_bv0[3][3];
       {
@@ -525,9 +544,9 @@ __global__ __launch_bounds__(CB_TPB, CB_WPB / 4) void conv_bwd_kernel(ConvBArgs 
         float d_vo[3][1] = {{d_bv[0][0]}, {d_bv[1][0]}, {d_bv[2][0]}};
         QMsg0::Grads gr;
         STAMP(13);
-        QMsg0::backward(imgT + IM::TC_M0, lane, c0[0], d_so, d_vo, d_b0, d_bv0, gr);
+        QMsg0::template backward<Io<ST>::BF>(imgT + IM::TC_M0, lane, c0[0], d_so, d_vo, d_b0, d_bv0, gr);
         STAMP(14);
-        QMsg0::weight_grads<AccPriv>(gblk + B::M0, first, lane, 0, active, b0[0], bv0[0], c0[0], gr, CB_TSCR);
+        QMsg0::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::M0, first, lane, 0, active, b0[0], bv0[0], c0[0], gr, CB_TSCR);
       }
       STAMP(4);
       // ---- d(edge embedding) of this layer -> g_e (plain stores, sorted-edge order)
@@ -624,6 +643,7 @@ constexpr int edge_bwd_lds_floats() { return BW_TPB + Image<0, NTE>::CV_M0 + Ima
 
 template <int NTE, typename ST>
 __global__ __launch_bounds__(BW_TPB, 2) void edge_bwd_kernel(EdgeBArgs a) {
+  WALL_STAMP(3);
   typedef Image<0, NTE> IM;
   typedef EdgeBlk<NTE> B;
   constexpr int PW = B::SIZE + TSCR_FLOATS;
@@ -681,14 +701,14 @@ __global__ __launch_bounds__(BW_TPB, 2) void edge_bwd_kernel(EdgeBArgs a) {
     f4 e_pre[1][2];
     float ev_pre[1][3][1];
     typename QEdge<NTE>::Cache ce[1];
-    QEdge<NTE>::template forward<1>(img + IM::CV_EDGE, lane, et, bse, bve, e_pre, ev_pre, ce);
+    QEdge<NTE>::template forward<1, Io<ST>::BF>(img + IM::CV_EDGE, lane, et, bse, bve, e_pre, ev_pre, ce);
     f4 dga[2], dbe[2];
     ln_quad_bwd<ES, EV>(img + IM::CV_ELN, lane, e_pre[0], ev_pre[0], d_es, d_ev, dga, dbe);
     ln_param_grads<AccPriv, ES>(gblk + B::LN, first, lane, active, dga, dbe);
     float d_in[8], d_inv[3][1];
     typename QEdge<NTE>::Grads gr;
-    QEdge<NTE>::backward(imgT + IM::TC_EDGE, lane, ce[0], d_es, d_ev, d_in, d_inv, gr);
-    QEdge<NTE>::template weight_grads<AccPriv>(gblk + B::GVP, first, lane, et[0], active, bse[0], bve[0], ce[0], gr, tscr);
+    QEdge<NTE>::template backward<Io<ST>::BF>(imgT + IM::TC_EDGE, lane, ce[0], d_es, d_ev, d_in, d_inv, gr);
+    QEdge<NTE>::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::GVP, first, lane, et[0], active, bse[0], bve[0], ce[0], gr, tscr);
   }
   write_slab_row<B::SIZE, PW>(a.slab, blocks);
 }
@@ -709,6 +729,7 @@ constexpr int embed_bwd_lds_floats() { return BW_TPB + Image<NTN, 0>::EMB_SIZE +
 
 template <int NTN, typename ST>
 __global__ __launch_bounds__(BW_TPB, 2) void embed_bwd_kernel(EmbBArgs a) {
+  WALL_STAMP(4);
   typedef Image<NTN, 0> IM;
   typedef QNode<NTN> Q;
   typedef EmbBlk<NTN> B;
@@ -746,7 +767,7 @@ __global__ __launch_bounds__(BW_TPB, 2) void embed_bwd_kernel(EmbBArgs a) {
     f4 s_pre[1][1];
     float v_pre[1][3][1];
     typename Q::Cache c[1];
-    Q::template forward<1>(img + IM::EMB_GVP, lane, type, bs, bv, s_pre, v_pre, c);
+    Q::template forward<1, Io<ST>::BF>(img + IM::EMB_GVP, lane, type, bs, bv, s_pre, v_pre, c);
     f4 gs[1] = {zero};
     float gv[3][1] = {{0.f}, {0.f}, {0.f}};
     if (active) {
@@ -765,8 +786,8 @@ __global__ __launch_bounds__(BW_TPB, 2) void embed_bwd_kernel(EmbBArgs a) {
     ln_param_grads<AccPriv, NS>(gblk + B::LN, first, lane, active, dga, dbe);
     float d_bs[Q::SSTEPS], d_bv[3][1];
     typename Q::Grads gr;
-    Q::backward(imgT, lane, c[0], gs, gv, d_bs, d_bv, gr);
-    Q::template weight_grads<AccPriv>(gblk + B::GVP, first, lane, type[0], active, bs[0], bv[0], c[0], gr, tscr);
+    Q::template backward<Io<ST>::BF>(imgT, lane, c[0], gs, gv, d_bs, d_bv, gr);
+    Q::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::GVP, first, lane, type[0], active, bs[0], bv[0], c[0], gr, tscr);
     if (active && a.g_x_s) {
 #pragma unroll
       for (int s = 0; s < Q::SSTEPS; ++s) {

@@ -73,49 +73,49 @@ __device__ __forceinline__ void stage_slice(float* lds, const float* __restrict_
 
 // ------------------------------------------------------------------ prepare
 template <int NTN, int NTE>
-__global__ void lba_prepare_kernel(const float* __restrict__ P, EncLayout L, int num_convs, float* __restrict__ img) {
+__global__ void lba_prepare_kernel(const float* __restrict__ P, EncLayout L, int num_convs, int packed, float* __restrict__ img) {
   typedef Image<NTN, NTE> IM;
   const int total = IM::total(num_convs);
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     float v;
     if (idx < IM::EMB_SIZE) {
-      v = idx < IM::EMB_LN ? QNode<NTN>::element(P + L.node_gvp, idx) : P[L.node_ln + (idx - IM::EMB_LN)];
+      v = idx < IM::EMB_LN ? QNode<NTN>::element(P + L.node_gvp, idx, packed != 0) : P[L.node_ln + (idx - IM::EMB_LN)];
     } else if (idx < IM::head(num_convs)) {
       const int j = idx - IM::EMB_SIZE;
       const int l = j / (IM::CV_SIZE + IM::ND_SIZE);
       int k = j - l * (IM::CV_SIZE + IM::ND_SIZE);
       const float* C = P + L.conv0 + l * L.conv_stride;
       if (k < IM::CV_SIZE) {
-        if (k < IM::CV_ELN) v = QEdge<NTE>::element(P + L.edge_gvp, k);
+        if (k < IM::CV_ELN) v = QEdge<NTE>::element(P + L.edge_gvp, k, packed != 0);
         else if (k < IM::CV_M0) v = P[L.edge_ln + (k - IM::CV_ELN)];
-        else if (k < IM::CV_M1) v = QMsg0::element(C + CONV_M0, k - IM::CV_M0);
-        else if (k < IM::CV_M2) v = QMsg1::element(C + conv_m1(), k - IM::CV_M1);
-        else v = QMsg2::element(C + conv_m2(), k - IM::CV_M2);
+        else if (k < IM::CV_M1) v = QMsg0::element(C + CONV_M0, k - IM::CV_M0, packed != 0);
+        else if (k < IM::CV_M2) v = QMsg1::element(C + conv_m1(), k - IM::CV_M1, packed != 0);
+        else v = QMsg2::element(C + conv_m2(), k - IM::CV_M2, packed != 0);
       } else {
         k -= IM::CV_SIZE;
         if (k < IM::ND_FF0) v = C[conv_ln0() + k];
-        else if (k < IM::ND_FF1) v = QFf0::element(C + conv_ff0(), k - IM::ND_FF0);
-        else if (k < IM::ND_LN1) v = QFf1::element(C + conv_ff1(), k - IM::ND_FF1);
+        else if (k < IM::ND_FF1) v = QFf0::element(C + conv_ff0(), k - IM::ND_FF0, packed != 0);
+        else if (k < IM::ND_LN1) v = QFf1::element(C + conv_ff1(), k - IM::ND_FF1, packed != 0);
         else v = C[conv_ln1() + (k - IM::ND_LN1)];
       }
     } else if (idx < IM::fwd_total(num_convs)) {
       const int k = idx - IM::head(num_convs);
-      v = k < IM::HD_GVP ? P[L.ln_out + k] : QHead::element(P + L.head, k - IM::HD_GVP);
+      v = k < IM::HD_GVP ? P[L.ln_out + k] : QHead::element(P + L.head, k - IM::HD_GVP, packed != 0);
     } else if (idx < IM::convT(num_convs, 0)) {
-      v = QNode<NTN>::element_t(P + L.node_gvp, idx - IM::embT(num_convs));
+      v = QNode<NTN>::element_t(P + L.node_gvp, idx - IM::embT(num_convs), packed != 0);
     } else if (idx < IM::headT(num_convs)) {
       const int j = idx - IM::convT(num_convs, 0);
       const int l = j / (IM::TC_SIZE + IM::TN_SIZE);
       int k = j - l * (IM::TC_SIZE + IM::TN_SIZE);
       const float* C = P + L.conv0 + l * L.conv_stride;
-      if (k < IM::TC_M0) v = QEdge<NTE>::element_t(P + L.edge_gvp, k);
-      else if (k < IM::TC_M1) v = QMsg0::element_t(C + CONV_M0, k - IM::TC_M0);
-      else if (k < IM::TC_M2) v = QMsg1::element_t(C + conv_m1(), k - IM::TC_M1);
-      else if (k < IM::TC_SIZE) v = QMsg2::element_t(C + conv_m2(), k - IM::TC_M2);
-      else if (k < IM::TC_SIZE + IM::TN_FF1) v = QFf0::element_t(C + conv_ff0(), k - IM::TC_SIZE);
-      else v = QFf1::element_t(C + conv_ff1(), k - IM::TC_SIZE - IM::TN_FF1);
+      if (k < IM::TC_M0) v = QEdge<NTE>::element_t(P + L.edge_gvp, k, packed != 0);
+      else if (k < IM::TC_M1) v = QMsg0::element_t(C + CONV_M0, k - IM::TC_M0, packed != 0);
+      else if (k < IM::TC_M2) v = QMsg1::element_t(C + conv_m1(), k - IM::TC_M1, packed != 0);
+      else if (k < IM::TC_SIZE) v = QMsg2::element_t(C + conv_m2(), k - IM::TC_M2, packed != 0);
+      else if (k < IM::TC_SIZE + IM::TN_FF1) v = QFf0::element_t(C + conv_ff0(), k - IM::TC_SIZE, packed != 0);
+      else v = QFf1::element_t(C + conv_ff1(), k - IM::TC_SIZE - IM::TN_FF1, packed != 0);
     } else {
-      v = QHead::element_t(P + L.head, idx - IM::headT(num_convs));
+      v = QHead::element_t(P + L.head, idx - IM::headT(num_convs), packed != 0);
     }
     img[idx] = v;
   }
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(TPB) void embed_quad_kernel(EmbedQArgs a) {
   f4 s[1][1];
   float v[1][3][1];
   typename Q::Cache c[1];
-  Q::template forward<1>(lds + IM::EMB_GVP, lane, type, bs, bv, s, v, c);
+  Q::template forward<1, Io<ST>::BF>(lds + IM::EMB_GVP, lane, type, bs, bv, s, v, c);
   ln_quad<NS, NV>(lds + IM::EMB_LN, lane, s[0], v[0]);
   if (active) {
     Io<ST>::st4(a.h, n * ROW + 4 * g, s[0][0]);
@@ -219,7 +219,7 @@ __device__ __forceinline__ void node_tile(const float* nd, const float* hd, int 
 #pragma unroll
       for (int p = 0; p < 3; ++p) bv[0][p][0] = v[p][0];
       QFf0::Cache c[1];
-      QFf0::forward<1>(nd + IM::ND_FF0, lane, zt, bs, bv, hs, hv, c);
+      QFf0::template forward<1, Io<ST>::BF>(nd + IM::ND_FF0, lane, zt, bs, bv, hs, hv, c);
     }
     {
       float bs[1][16], bv[1][3][2];
@@ -230,7 +230,7 @@ __device__ __forceinline__ void node_tile(const float* nd, const float* hd, int 
 #pragma unroll
       for (int p = 0; p < 3; ++p) { bv[0][p][0] = hv[0][p][0]; bv[0][p][1] = hv[0][p][1]; }
       QFf1::Cache c[1];
-      QFf1::forward<1>(nd + IM::ND_FF1, lane, zt, bs, bv, s2, v2, c);
+      QFf1::template forward<1, Io<ST>::BF>(nd + IM::ND_FF1, lane, zt, bs, bv, s2, v2, c);
     }
     s[0] += s2[0][0] * m1s;
 #pragma unroll
@@ -251,7 +251,7 @@ __device__ __forceinline__ void node_tile(const float* nd, const float* hd, int 
   for (int p = 0; p < 3; ++p) bv[0][p][0] = v[p][0];
   f4 o[1][4];
   QHead::Cache c[1];
-  QHead::forward<1>(hd + IM::HD_GVP, lane, zt, bs, bv, o, dummy, c);
+  QHead::template forward<1, Io<ST>::BF>(hd + IM::HD_GVP, lane, zt, bs, bv, o, dummy, c);
   if (active) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) Io<ST>::st4(out, n * OUT + 16 * t + 4 * g, o[0][t]);
@@ -411,7 +411,7 @@ __device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, i
       for (int d = 0; d < 3; ++d) bv[j][d][0] = ev[j][d];
     }
     typename QEdge<NTE>::Cache c[CTN];
-    QEdge<NTE>::template forward<CTN>(img + IM::CV_EDGE, lane, et, bs, bv, e_s, e_v, c);
+    QEdge<NTE>::template forward<CTN, Io<ST>::BF>(img + IM::CV_EDGE, lane, et, bs, bv, e_s, e_v, c);
 #pragma unroll
     for (int j = 0; j < CTN; ++j) ln_quad<ES, EV>(img + IM::CV_ELN, lane, e_s[j], e_v[j]);
     if (EMODE == 1) {
@@ -454,7 +454,7 @@ __device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, i
       for (int d = 0; d < 3; ++d) { bv[j][d][0] = vj[j][d]; bv[j][d][1] = vi[j][d]; bv[j][d][2] = e_v[j][d][0]; }
     }
     QMsg0::Cache c[CTN];
-    QMsg0::forward<CTN>(img + IM::CV_M0, lane, zero_t, bs, bv, s1, v1, c);
+    QMsg0::template forward<CTN, Io<ST>::BF>(img + IM::CV_M0, lane, zero_t, bs, bv, s1, v1, c);
   }
   {
     float bs[CTN][4], bv[CTN][3][1];
@@ -466,7 +466,7 @@ __device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, i
       for (int d = 0; d < 3; ++d) bv[j][d][0] = v1[j][d][0];
     }
     QMsg1::Cache c[CTN];
-    QMsg1::forward<CTN>(img + IM::CV_M1, lane, zero_t, bs, bv, s2, v2, c);
+    QMsg1::template forward<CTN, Io<ST>::BF>(img + IM::CV_M1, lane, zero_t, bs, bv, s2, v2, c);
   }
   {
     float bs[CTN][4], bv[CTN][3][1];
@@ -478,7 +478,7 @@ __device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, i
       for (int d = 0; d < 3; ++d) bv[j][d][0] = v2[j][d][0];
     }
     QMsg2::Cache c[CTN];
-    QMsg2::forward<CTN>(img + IM::CV_M2, lane, zero_t, bs, bv, s1, v1, c);
+    QMsg2::template forward<CTN, Io<ST>::BF>(img + IM::CV_M2, lane, zero_t, bs, bv, s1, v1, c);
   }
 #pragma unroll
   for (int j = 0; j < CTN; ++j) {
@@ -596,10 +596,10 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 template <int NTN, int NTE>
-int prepare_impl(const EncLayout& L, int num_convs, const float* params, float* image, hipStream_t st) {
+int prepare_impl(const EncLayout& L, int num_convs, int packed, const float* params, float* image, hipStream_t st) {
   const int total = Image<NTN, NTE>::total(num_convs);
   hipLaunchKernelGGL((lba_prepare_kernel<NTN, NTE>), dim3((total + 255) / 256), dim3(256), 0, st, params, L,
-                     num_convs, image);
+                     num_convs, packed, image);
   return 0;
 }
 
@@ -637,8 +637,8 @@ int offsets(int nt_node, int nt_edge, int num_convs, QuadOffsets* o) {
   return 0;
 }
 
-int prepare(const EncLayout& L, int num_convs, const float* params, float* image, hipStream_t st) {
-#define CALL(A, B) prepare_impl<A, B>(L, num_convs, params, image, st)
+int prepare(const EncLayout& L, int num_convs, int packed, const float* params, float* image, hipStream_t st) {
+#define CALL(A, B) prepare_impl<A, B>(L, num_convs, packed, params, image, st)
   DISPATCH_NT(L.nt_node, L.nt_edge, CALL)
 #undef CALL
   return 0;

@@ -110,7 +110,7 @@ _IMAGES = {}        # arena data_ptr -> (sum of parameter versions, fragment ima
 
 def fragment_image(params, flat, layout, dims):
     """Fragment image of the current weights (one ~5 us launch), cached on the parameters' version counters."""
-    key, ver = flat.data_ptr(), sum(p._version for p in params)
+    key, ver = (flat.data_ptr(), int(dims.storage)), sum(p._version for p in params)   # bf16 storage packs the fragments
     hit = _IMAGES.get(key)
     if hit is not None and hit[0] == ver and hit[1].device == flat.device:
         return hit[1]

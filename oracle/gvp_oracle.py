@@ -54,27 +54,81 @@ def _act(name):
             "leaky_relu": lambda t: F.leaky_relu(t, 0.01)}[name]
 
 
+# ----------------------------------------------------- test-only emulation of reduced-precision matrix-core operands
+_GEMM_DTYPE = None
+
+
+class emulate_gemm_dtype:
+    """`with emulate_gemm_dtype(torch.bfloat16):` -- every nn.Linear of a GVP is evaluated the way the bf16-storage
+    kernels evaluate it on v_mfma_f32_16x16x16_bf16: operands (input, weight; in the backward also the incoming
+    gradient) rounded to bf16, products accumulated in fp32, bias and bias gradient in fp32.  Linears with at most 4
+    input channels (one k-step: they stay on the fp32 instruction) are exact in the forward and in the data gradient;
+    their weight gradient still uses rounded operands (the item-reduction outer products all run on the bf16
+    instruction).  Checker of tests/test_bf16_storage.py only."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _GEMM_DTYPE
+        self.prev, _GEMM_DTYPE = _GEMM_DTYPE, self.dtype
+
+    def __exit__(self, *exc):
+        global _GEMM_DTYPE
+        _GEMM_DTYPE = self.prev
+        return False
+
+
+class _EmuLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b, dtype, exact_cols):
+        rd = lambda t: t.to(dtype).to(t.dtype)
+        narrow = W.shape[1] <= 4
+        xr, Wr = rd(x), rd(W)
+        if exact_cols:                  # one-hot type columns: the kernels add the fp32 weight column (no product to round)
+            Wr = torch.cat([W[:, :exact_cols], Wr[:, exact_cols:]], 1)
+        ctx.save_for_backward(W if narrow else Wr, xr)
+        ctx.dtype, ctx.narrow, ctx.has_bias = dtype, narrow, b is not None
+        return F.linear(x if narrow else xr, W if narrow else Wr, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        Wd, xr = ctx.saved_tensors
+        gr = gy.to(ctx.dtype).to(gy.dtype)
+        gx = (gy if ctx.narrow else gr) @ Wd
+        gW = gr.reshape(-1, gr.shape[-1]).t() @ xr.reshape(-1, xr.shape[-1])
+        gb = gy.reshape(-1, gy.shape[-1]).sum(0) if ctx.has_bias else None
+        return gx, gW, gb, None, None
+
+
+def _linear(x, W, b=None, exact_cols=0):
+    if _GEMM_DTYPE is None:
+        return F.linear(x, W, b)
+    return _EmuLinear.apply(x, W, b, _GEMM_DTYPE, exact_cols)
+
+
 # --------------------------------------------------------------------------- a3
-def gvp(P, pfx, x, vi, vo, scalar_act="relu", vector_act="sigmoid", vector_gate=False):
-    """gvp_layers.py:142-175.  ``x`` is (s, V) when vi > 0 else s."""
+def gvp(P, pfx, x, vi, vo, scalar_act="relu", vector_act="sigmoid", vector_gate=False, type_cols=0):
+    """gvp_layers.py:142-175.  ``x`` is (s, V) when vi > 0 else s.  (`type_cols`: leading one-hot columns of s; only
+    the reduced-precision emulation looks at it.)"""
     sa, va = _act(scalar_act), _act(vector_act)
     if vi:
         s, v = x
         v = torch.transpose(v, -1, -2)                       # :151
-        vh = F.linear(v, P[pfx + "wh.weight"])               # :152
+        vh = _linear(v, P[pfx + "wh.weight"])               # :152
         vn = norm_no_nan(vh, axis=-2)                        # :153
-        s = F.linear(torch.cat([s, vn], -1), P[pfx + "ws.weight"], P[pfx + "ws.bias"])  # :154
+        s = _linear(torch.cat([s, vn], -1), P[pfx + "ws.weight"], P[pfx + "ws.bias"], type_cols)  # :154
         if vo:
-            v = F.linear(vh, P[pfx + "wv.weight"])           # :156
+            v = _linear(vh, P[pfx + "wv.weight"])           # :156
             v = torch.transpose(v, -1, -2)                   # :157
             if vector_gate:                                  # :158-163 (gate sees pre-activation s)
                 gate_in = va(s) if va is not None else s
-                gate = F.linear(gate_in, P[pfx + "wsv.weight"], P[pfx + "wsv.bias"])
+                gate = _linear(gate_in, P[pfx + "wsv.weight"], P[pfx + "wsv.bias"])
                 v = v * torch.sigmoid(gate).unsqueeze(-1)
             elif va is not None:                             # :164-166
                 v = v * va(norm_no_nan(v, axis=-1, keepdims=True))
     else:
-        s = F.linear(x, P[pfx + "ws.weight"], P[pfx + "ws.bias"])   # :168
+        s = _linear(x, P[pfx + "ws.weight"], P[pfx + "ws.bias"])   # :168
         if vo:
             v = torch.zeros(s.shape[0], vo, 3, dtype=s.dtype)        # :170
     if sa is not None:
@@ -193,9 +247,9 @@ def protein_lba_forward(P, x, edge_index, ntypes, etypes, eattr, num_ntypes=20, 
     hv = P[pfx + "gvp_node.0.wv.weight"].shape[0]
     ev = P[pfx + "gvp_edge.0.wv.weight"].shape[0]
     stages = {}
-    h = gvp(P, pfx + "gvp_node.0.", (x_s, x_v), x_v.shape[1], hv, None, None, True)
+    h = gvp(P, pfx + "gvp_node.0.", (x_s, x_v), x_v.shape[1], hv, None, None, True, num_ntypes)
     h = gvp_layernorm(P, pfx + "gvp_node.1.", h, hv)                            # :375
-    e = gvp(P, pfx + "gvp_edge.0.", (e_s, e_v), e_v.shape[1], ev, None, None, True)
+    e = gvp(P, pfx + "gvp_edge.0.", (e_s, e_v), e_v.shape[1], ev, None, None, True, num_etypes)
     e = _ste_round(gvp_layernorm(P, pfx + "gvp_edge.1.", e, ev), store_dtype)   # :376
     h = _ste_round(h, store_dtype)
     stages["node_embed"] = h

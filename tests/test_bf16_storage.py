@@ -1,15 +1,20 @@
-"""bf16 storage / fp32 accumulate (BASELINE config 5; cgvp_dims.storage = CGVP_BF16): features, node rows, the
-edge-embedding store and the residue embeddings live in HBM as bfloat16, every load widens to fp32 and all arithmetic,
-MFMA accumulation, LayerNorm statistics and gradient buffers stay fp32.
+"""bf16 storage + bf16 matrix-core operands, fp32 accumulate (BASELINE config 5; cgvp_dims.storage = CGVP_BF16):
+features, node rows, the edge-embedding store and the residue embeddings live in HBM as bfloat16; every channel GEMM with
+more than 4 input channels runs on v_mfma_f32_16x16x16_bf16 (operands rounded to bf16 -- activations, weights and, in
+the backward, gradients -- products accumulated in fp32); LayerNorm statistics, norms, gates, biases, the one-hot type
+columns and every gradient BUFFER stay fp32.
 
-Checker: the fp32 oracle on the SAME bf16-rounded inputs with `store_dtype=torch.bfloat16`, i.e. rounding the same
-stage hand-offs to bf16 (node embedding, re-read edge embedding, layer outputs, result; straight-through gradient).
-(The kernels continue with the ROUNDED value wherever they store an activation and keep using it -- the edge embedding
-in the layer that derives it, the aggregated messages in the fused layer kernel -- so their forward and backward see
-the same numbers, exactly like this emulation.)  Stated tolerance: what is left between the two is fp32 summation order
-plus the occasional 1-ulp bf16 flip at a rounding boundary (2^-8 relative on single elements): outputs within 1.5e-2 of
-the output scale, every gradient tensor within 6e-2 in the L2 norm.  Against the fp32-storage kernels on the same inputs the outputs stay within 3e-2; the bf16 path repeats
-bitwise."""
+Checker: the fp32 oracle on the SAME bf16-rounded inputs, rounding the same tensors at the same points --
+`store_dtype=torch.bfloat16` (stage hand-offs: node embedding, edge embedding, aggregated messages, layer outputs,
+result; straight-through gradient) inside `emulate_gemm_dtype(torch.bfloat16)` (every GVP Linear: input, weight and
+incoming gradient rounded, <= 4-input-channel Linears exact, type columns exact).  What is left between the kernels and
+this emulation is fp32 summation order plus the occasional 1-ulp bf16 flip at a rounding boundary (2^-8 relative on
+single elements, and a ReLU whose input sits within that of zero): measured on MI355X 3.4e-3 of the output scale and
+<= 1e-2 in the L2 norm of every weight gradient (davis_2_2).  Stated tolerance: outputs 1e-2, every gradient tensor
+2e-2 in L2 (+ the absolute floor for analytically-zero gradients).  For scale: the SAME comparison against the
+unrounded fp32 oracle gives 4e-3 (outputs) and 6-30 % (gradients of a random upstream gradient: ReLU masks flip) --
+that is the price of bf16 operands, not of this implementation; the fp32-storage kernels are the exact path.
+Against the fp32-storage kernels on the same inputs the outputs stay within 3e-2; the bf16 path repeats bitwise."""
 import json
 import os
 
@@ -23,7 +28,7 @@ from oracle import gvp_oracle as O
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-FWD_TOL, GRAD_TOL, VS_F32 = 1.5e-2, 6e-2, 3e-2
+FWD_TOL, GRAD_TOL, VS_F32 = 1e-2, 2e-2, 3e-2
 
 
 def _encoder(state=None, num_convs=2, seed=None):
@@ -62,18 +67,22 @@ def test_bf16_forward_backward_vs_oracle(protein_params, case):
     assert out.dtype == torch.bfloat16 and out.shape == (gb.num_nodes, 64)
     P = {k: v.detach().cpu().clone().requires_grad_(v.numel() > 0) for k, v in model.gnn_model.state_dict().items()}
     rxs, rxv = dc["x"][0].clone().requires_grad_(), dc["x"][1].clone().requires_grad_()
-    ref = O.protein_lba_forward(P, (rxs, rxv), dc["edge_index"], dc["ntypes"], dc["etypes"], dc["eattr"], num_convs=nc,
-                                store_dtype=torch.bfloat16)
-    assert rel_err(out.float(), ref) < FWD_TOL
-    r = torch.randn(ref.shape, generator=torch.Generator().manual_seed(3))
-    (out.float() * r.to(DEV)).sum().backward()
-    (ref * r).sum().backward()
+    with O.emulate_gemm_dtype(torch.bfloat16):            # bf16 matrix-core operands, fp32 accumulate (see the oracle)
+        ref = O.protein_lba_forward(P, (rxs, rxv), dc["edge_index"], dc["ntypes"], dc["etypes"], dc["eattr"], num_convs=nc,
+                                    store_dtype=torch.bfloat16)
+        assert rel_err(out.float(), ref) < FWD_TOL
+        r = torch.randn(ref.shape, generator=torch.Generator().manual_seed(3))
+        (out.float() * r.to(DEV)).sum().backward()
+        (ref * r).sum().backward()
     scale = max(float(v.grad.abs().max()) for v in P.values() if v.grad is not None)
+    worst = {}
     for name, p in model.gnn_model.named_parameters():
         if p.numel():
             want = P[name].grad
             assert p.grad.dtype == torch.float32                      # weight gradients are fp32
-            assert float((p.grad.cpu() - want).norm()) <= GRAD_TOL * float(want.norm()) + 2e-3 * scale, name
+            worst[name] = (float((p.grad.cpu() - want).norm()) - 2e-3 * scale) / max(float(want.norm()), 1e-30)
+    bad = {k: round(v, 4) for k, v in worst.items() if v > GRAD_TOL}
+    assert not bad, (bad, sorted(round(v, 4) for v in worst.values())[-8:])
     assert xs.grad.dtype == torch.bfloat16
     l2 = lambda a, b: float((a.cpu().float() - b).norm() / b.norm())
     assert l2(xs.grad, rxs.grad) < GRAD_TOL and l2(xv.grad, rxv.grad) < GRAD_TOL
