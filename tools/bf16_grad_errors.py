@@ -1,3 +1,6 @@
+"""Diagnostic: how far are the bf16 kernels' outputs / weight gradients from (a) the oracle that emulates the same
+roundings (store_dtype + emulate_gemm_dtype: the test's checker), (b) the oracle that only rounds the stored tensors,
+(c) the unrounded fp32 oracle -- per parameter, L2-relative.  Run from the repo root on a GPU box."""
 import os, sys, json, torch
 sys.path[:0] = [os.path.join(os.getcwd(), "caster-dta_amd"), os.getcwd(), os.path.join(os.getcwd(), "tests")]
 import davis_synth as ds
