@@ -75,6 +75,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--drug-stream", default="side", choices=["side", "main"],
                     help="diagnostic: 'main' runs the drug encoder on the protein stream (no overlap)")
+    ap.add_argument("--compile", action="store_true",
+                    help="--scope joint: run the model through torch.compile(dynamic=True), what train_model.py:422 does "
+                         "(the encoders and the attention core stay single custom-op nodes)")
     ap.add_argument("--gine-bwd-wgs", type=int, default=0,
                     help="diagnostic: workgroup cap of the GINE backward (0 = library default of 16)")
     ap.add_argument("--only", default=None, choices=["protein", "drug"],
@@ -233,11 +236,13 @@ def main():
         main_s.wait_stream(side)
         return gp + gd
 
+    jmodel = torch.compile(model, dynamic=True) if (args.compile and args.scope == "joint") else model
+
     def joint_step():
         if collate:
             collate[1][0].collate(collate[1][1], attach_to=mdata["edge_index"])
             collate[0][0].collate(collate[0][1], attach_to=pdata["edge_index"])
-        pred, _ = model(jp, jm)
+        pred, _ = jmodel(jp, jm)
         if not train:
             return pred
         loss = torch.nn.functional.mse_loss(pred, target[:pred.shape[0]])
@@ -386,7 +391,7 @@ def main():
                        "protein_edges_per_gpu": pb.num_edges, "atoms_per_gpu": mb.num_nodes,
                        "drug_edges_per_gpu": mb.num_edges, "encoder": f"CASTER-DTA({convs},{convs})", "pass": args.mode,
                        "activation_storage": "bf16 (protein encoder: bf16 activations in HBM and bf16 matrix-core operands, fp32 accumulate, fp32 weights and gradient buffers)" if args.dtype == "bf16" else "fp32",
-                       "scope": args.scope, "train_mode": bool(dropout_on), "dropout_p": 0.2 if dropout_on else 0.0,
+                       "scope": args.scope, "torch_compile": bool(args.compile and args.scope == "joint"), "train_mode": bool(dropout_on), "dropout_p": 0.2 if dropout_on else 0.0,
                        "csr_build_in_step": ("collate" if args.collate_csr else not args.cache_csr),
                        "hip_graph": graph is not None, "kernels": ops.VARIANT, "parallelism": par},
             "roofline": roof, "cpu_baseline": cpu,

@@ -187,13 +187,15 @@ template <class G>
 __host__ __device__ float gemm_element(const float* W, int idx, bool packed) {
   return (packed && packs_bf16<G>()) ? packed_element<G>(W, idx) : G::element(W, idx);
 }
-// two floats -> one register of two bf16 (RNE).  Written as a 2-vector conversion so that it selects ONE
-// v_cvt_pk_bf16_f32 and the compiler keeps track of the VALU -> MFMA wait states (an inline-asm version of the same
-// instruction is invisible to the hazard recognizer and fed the matrix core stale registers).
+// two floats -> one register of two bf16 (RNE).  Written as two scalar conversions into a 2-vector: the backend
+// pairs them into ONE v_cvt_pk_bf16_f32 (mostly; the rest costs a v_perm) and keeps track of the VALU -> MFMA wait
+// states.  Two formulations that did NOT survive: an inline-asm v_cvt_pk_bf16_f32 is invisible to the hazard
+// recogniser and fed the matrix core stale registers; __builtin_convertvector on a float2 left operand arrays in
+// scratch memory (32 B/lane in every bf16 forward kernel).
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-  typedef float f2 __attribute__((ext_vector_type(2)));
   typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{lo, hi}, bf2));
+  const bf2 r = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, r);
 }
 __device__ __forceinline__ bf4 pack_bf4(float a, float b, float c, float d) {
   return __builtin_bit_cast(bf4, uint2{cvt_pk_bf16(a, b), cvt_pk_bf16(c, d)});
@@ -206,24 +208,31 @@ __device__ __forceinline__ f4 mfma_bf(bf4 a, bf4 b, f4 c) {
 // tiles in lockstep: one LDS fragment read feeds TN independent MFMA chains.
 // With a single tile, long chains are split over two accumulators instead (a
 // dependent f32 MFMA chain issues every 40 cycles, independent ones every 32).
-template <class G, int TN, bool BF = false>
-__device__ __forceinline__ void apply(const float* frag, int mt, const float (&b)[TN][G::NSTEPS], f4 (&acc)[TN], int lane) {
-  if constexpr (BF && packs_bf16<G>()) {
+// k-steps 4Q .. 4Q+3 of the packed path; the step indices are template constants, so every element of `b` is named at
+// compile time (a run-time-looking index, even in a fully unrolled loop, left some operand arrays in scratch memory)
+template <int S, int N>
+__device__ __forceinline__ float step_or_zero(const float (&b)[N]) {
+  if constexpr (S < N) return b[S]; else return 0.f;
+}
+template <class G, int TN, int Q>
+__device__ __forceinline__ void apply_bf16_steps(const float* frag, const float (&b)[TN][G::NSTEPS], f4 (&acc)[TN]) {
+  if constexpr (Q < ceil4(G::NSTEPS)) {
     // (read as a vector of FLOATS: the staging code stores floats, and a load through an integer type may be moved
     // across those stores by type-based alias analysis)
     typedef float f2 __attribute__((ext_vector_type(2)));
-    const f2* f = reinterpret_cast<const f2*>(frag + mt * G::NSTEPS * 64) + lane;
+    const bf4 a = __builtin_bit_cast(bf4, reinterpret_cast<const f2*>(frag)[Q * 64]);
 #pragma unroll
-    for (int q = 0; q < ceil4(G::NSTEPS); ++q) {
-      const bf4 a = __builtin_bit_cast(bf4, f[q * 64]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const float x1 = 4 * q + 1 < G::NSTEPS ? b[j][4 * q + 1 < G::NSTEPS ? 4 * q + 1 : 0] : 0.f;
-        const float x2 = 4 * q + 2 < G::NSTEPS ? b[j][4 * q + 2 < G::NSTEPS ? 4 * q + 2 : 0] : 0.f;
-        const float x3 = 4 * q + 3 < G::NSTEPS ? b[j][4 * q + 3 < G::NSTEPS ? 4 * q + 3 : 0] : 0.f;
-        acc[j] = mfma_bf(a, pack_bf4(b[j][4 * q], x1, x2, x3), acc[j]);
-      }
-    }
+    for (int j = 0; j < TN; ++j)
+      acc[j] = mfma_bf(a, pack_bf4(step_or_zero<4 * Q>(b[j]), step_or_zero<4 * Q + 1>(b[j]), step_or_zero<4 * Q + 2>(b[j]),
+                                   step_or_zero<4 * Q + 3>(b[j])), acc[j]);
+    apply_bf16_steps<G, TN, Q + 1>(frag, b, acc);
+  }
+}
+
+template <class G, int TN, bool BF = false>
+__device__ __forceinline__ void apply(const float* frag, int mt, const float (&b)[TN][G::NSTEPS], f4 (&acc)[TN], int lane) {
+  if constexpr (BF && packs_bf16<G>()) {
+    apply_bf16_steps<G, TN, 0>(frag + mt * G::NSTEPS * 64 + 2 * lane, b, acc);
     return;
   }
   const float* f = frag + mt * G::NSTEPS * 64 + lane;

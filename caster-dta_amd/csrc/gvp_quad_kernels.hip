@@ -71,6 +71,31 @@ __device__ __forceinline__ void stage_slice(float* lds, const float* __restrict_
   }
 }
 
+// Up to three slices (from three places of the image) into consecutive LDS: ALL global loads are issued before the
+// first LDS store, so the copies cost one memory latency together instead of one each (the fused conv + node update
+// (+ head) kernel stages 68-74 KB per workgroup).  A size of 0 skips a slice.
+template <int N0, int N1, int N2>
+__device__ __forceinline__ void stage_slices(float* lds, const float* __restrict__ s0, const float* __restrict__ s1,
+                                             const float* __restrict__ s2, int tid) {
+  static_assert(N0 % 4 == 0 && N1 % 4 == 0 && N2 % 4 == 0, "image slices are whole float4s");
+  constexpr int F0 = N0 / 4, F1 = N1 / 4, F2 = N2 / 4;
+  constexpr int I0 = (F0 + TPB - 1) / TPB, I1 = (F1 + TPB - 1) / TPB, I2 = (F2 + TPB - 1) / TPB;
+  f4* d = reinterpret_cast<f4*>(lds);
+  f4 v0[I0 > 0 ? I0 : 1], v1[I1 > 0 ? I1 : 1], v2[I2 > 0 ? I2 : 1];
+#pragma unroll
+  for (int k = 0; k < I0; ++k) { const int idx = tid + k * TPB; if (idx < F0) v0[k] = reinterpret_cast<const f4*>(s0)[idx]; }
+#pragma unroll
+  for (int k = 0; k < I1; ++k) { const int idx = tid + k * TPB; if (idx < F1) v1[k] = reinterpret_cast<const f4*>(s1)[idx]; }
+#pragma unroll
+  for (int k = 0; k < I2; ++k) { const int idx = tid + k * TPB; if (idx < F2) v2[k] = reinterpret_cast<const f4*>(s2)[idx]; }
+#pragma unroll
+  for (int k = 0; k < I0; ++k) { const int idx = tid + k * TPB; if (idx < F0) d[idx] = v0[k]; }
+#pragma unroll
+  for (int k = 0; k < I1; ++k) { const int idx = tid + k * TPB; if (idx < F1) d[F0 + idx] = v1[k]; }
+#pragma unroll
+  for (int k = 0; k < I2; ++k) { const int idx = tid + k * TPB; if (idx < F2) d[F0 + F1 + idx] = v2[k]; }
+}
+
 // ------------------------------------------------------------------ prepare
 template <int NTN, int NTE>
 __global__ void lba_prepare_kernel(const float* __restrict__ P, EncLayout L, int num_convs, int packed, float* __restrict__ img) {
@@ -296,8 +321,7 @@ __global__ __launch_bounds__(TPB) void node_quad_kernel(NodeQArgs a) {
   f4 s[1], m1s;
   float v[3][1], m1v;
   node_inputs<ST, ST>(a, lane, active, n, a.dh, n * ROW, s, v, m1s, m1v);     // row loads fly while the image is staged
-  stage_slice<IM::ND_SIZE>(lds, a.img_node, threadIdx.x);
-  if (HEAD) stage_slice<IM::HD_SIZE>(lds + IM::ND_SIZE, a.img_head, threadIdx.x);
+  stage_slices<IM::ND_SIZE, (HEAD ? IM::HD_SIZE : 0), 0>(lds, a.img_node, a.img_head, nullptr, threadIdx.x);
   __syncthreads();
   node_tile<HEAD, ST>(lds, lds + IM::ND_SIZE, lane, active, n, s, v, m1s, m1v, a.h_out, a.out);
 }
@@ -517,9 +541,8 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   conv_gather<NTE, EMODE, ST>(a, e0, e1, lane, in);
   if (EMODE == 1 && blockIdx.x == 0 && threadIdx.x < EROW / 4)        // the store's spare row is always all zeros
     Io<ST>::st4(a.e_out, a.E * EROW + 4 * threadIdx.x, f4{0.f, 0.f, 0.f, 0.f});
-  stage_slice<IM::CV_SIZE>(img, a.img, threadIdx.x);
-  if (FUSE > 0) stage_slice<IMN::ND_SIZE>(nd_img, a.node.img_node, threadIdx.x);
-  if (FUSE == 2) stage_slice<IMN::HD_SIZE>(nd_img + IMN::ND_SIZE, a.node.img_head, threadIdx.x);
+  stage_slices<IM::CV_SIZE, (FUSE > 0 ? IMN::ND_SIZE : 0), (FUSE == 2 ? IMN::HD_SIZE : 0)>(
+      img, a.img, a.node.img_node, a.node.img_head, threadIdx.x);      // nd_img = img + CV_SIZE, the head slice behind it
   for (int k = lane; k < nn * ROW; k += WAVE) acc[k] = 0.f;
   STAMP(1);
   __syncthreads();                                  // image staged, accumulators cleared
