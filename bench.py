@@ -99,12 +99,13 @@ def kernel_source_digest():
     return h.hexdigest()[:16]
 
 
-def committed_traffic(workload, kernel):
+def committed_traffic(workload, kernel, dtype="f32"):
     """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
     gfx950 correction applied: tools/pmc_summarise.py).  Only reported when the file was measured on the SAME
     kernel sources and workload; otherwise null (a stale number is worse than none)."""
+    tag = workload if dtype == "f32" else f"{workload}_{dtype}"
     for rnd in ("r02", "r01"):
-        path = os.path.join(REPO, "profiles", rnd, f"pmc_traffic_{workload}.json")
+        path = os.path.join(REPO, "profiles", rnd, f"pmc_traffic_{tag}.json")
         if not os.path.exists(path) and workload == "davis_b64":
             path = os.path.join(REPO, "profiles", rnd, "pmc_traffic.json")
         if not os.path.exists(path):
@@ -358,7 +359,7 @@ def main():
                 bound = "mfma" if mfma["floor_us"] > hbm["floor_us"] else "hbm"
                 top = mfma if bound == "mfma" else hbm
                 roof = dict(bound=bound, achieved=top["achieved"], peak=top["peak"], unit=top["unit"], frac=top["frac"],
-                            traffic=committed_traffic(args.workload, kname), kernel=kname,
+                            traffic=committed_traffic(args.workload, kname, args.dtype), kernel=kname,
                             avg_us=round(avg * 1e6, 2), median_us=round(times[len(times) // 2] * 1e6, 2),
                             bytes_per_launch=nbytes, launches=len(times), hbm=hbm, mfma=mfma,
                             other={k: round(sum(v) / len(v) * 1e6, 2) for k, v in by.items() if k != name})
