@@ -168,3 +168,53 @@ def test_c3_kiba_32_pairs_full_size(protein_params, molecule_params):
     for gf, ga, gb_ in zip(g_full, g_a, g_b):
         ref = ga + gb_
         assert float((gf - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-6 * scale
+
+
+def test_c5_bindingdb_44_bf16_full_size():
+    """BASELINE config 5, one rank's share: 32 pairs at BindingDB-scale lengths (mean ~558 residues), CASTER-DTA(4,4)
+    (four conv layers; seeded random weights -- no (4,4) checkpoint ships), bf16 variant.  Oracle (same roundings:
+    store_dtype + emulate_gemm_dtype, tolerances of tests/test_bf16_storage.py) on the 3 shortest proteins; the full batch
+    equals its graphs run separately (rounding-flip level) and its weight gradients equal the sum over a 16 / 16 split."""
+    from models.protein_gnn import SelectableProteinModelWrapper
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))["protein_gnn_kwargs"]
+    kw = dict(kw, num_convs=4)
+    for k in ("in_channels", "edge_dim", "hidden_channels", "edge_hidden_channels"):
+        kw[k] = tuple(kw[k])
+    torch.manual_seed(44)
+    prot = SelectableProteinModelWrapper(**kw).to(DEV).eval()
+    params = [p for p in prot.parameters() if p.numel()]
+    lengths = ds.real_lengths("bindingdb", 32, seed=5)
+    pb = ds.protein_batch(32, 23, lengths=lengths)
+    assert pb.num_graphs == 32 and 9000 < pb.num_nodes < 40000
+    bf = lambda d: {k: (tuple(t.bfloat16() for t in v) if (isinstance(v, tuple) and k in ("x", "eattr")) else v) for k, v in d.items()}
+    r_all = torch.randn(pb.num_nodes, 64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+
+    def run(gp, r):
+        dp = bf(_to(ds.to_torch(gp)))
+        res = prot(dp["x"], dp["edge_index"], dp["ntypes"], dp["etypes"], eattr=dp["eattr"])
+        assert res.dtype == torch.bfloat16
+        return res.detach().float(), torch.autograd.grad(res, params, r.to(torch.bfloat16))
+
+    res, g_full = run(pb, r_all)
+    assert torch.isfinite(res).all() and all(torch.isfinite(g).all() for g in g_full)
+    # oracle with the same roundings on the 3 shortest proteins
+    ids = [int(i) for i in np.argsort(lengths)[:3]]
+    sub = _slice_graphs(pb, ids)
+    dc = ds.to_torch(sub)
+    rd = lambda t: t.to(torch.bfloat16).float()
+    P = {k: v.detach().cpu() for k, v in prot.gnn_model.state_dict().items()}
+    with O.emulate_gemm_dtype(torch.bfloat16):
+        ref = O.protein_lba_forward(P, tuple(rd(t) for t in dc["x"]), dc["edge_index"], dc["ntypes"], dc["etypes"],
+                                    tuple(rd(t) for t in dc["eattr"]), num_convs=4, store_dtype=torch.bfloat16)
+    got = torch.cat([res[int(pb.ptr[i]):int(pb.ptr[i + 1])] for i in ids])
+    assert rel_err(got, ref) < 1e-2
+    # split 16 / 16: outputs concatenate (same per-edge arithmetic), gradients add
+    a, b = list(range(16)), list(range(16, 32))
+    na = int(pb.ptr[16])
+    res_a, g_a = run(_slice_graphs(pb, a), r_all[:na])
+    res_b, g_b = run(_slice_graphs(pb, b), r_all[na:])
+    assert rel_err(torch.cat([res_a, res_b]), res) < 1e-6
+    scale = max(float(g.abs().max()) for g in g_full)
+    for gf, ga, gb_ in zip(g_full, g_a, g_b):
+        want = ga + gb_
+        assert float((gf - want).abs().max()) <= 2e-4 * float(want.abs().max()) + 1e-6 * scale
