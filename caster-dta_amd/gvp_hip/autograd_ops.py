@@ -105,19 +105,45 @@ def flat_arena(params):
     return torch.empty(0, dtype=p0.dtype, device=p0.device).set_(st, off, (o - off,), (1,))
 
 
-_IMAGES = {}        # arena data_ptr -> (sum of parameter versions, fragment image)
+_IMAGES = {}        # (arena data_ptr, storage type) -> (weakrefs of the first / last parameter, sum of versions, image)
 
 
-def fragment_image(params, flat, layout, dims):
-    """Fragment image of the current weights (one ~5 us launch), cached on the parameters' version counters."""
-    key, ver = (flat.data_ptr(), int(dims.storage)), sum(p._version for p in params)   # bf16 storage packs the fragments
+def invalidate_images():
+    """Drop every cached fragment image (needed only after writing weights through `.data`, which bypasses the version
+    counters the cache watches)."""
+    _IMAGES.clear()
+
+
+_CAPTURE_IMAGE = {}     # key -> image built by the latest FORWARD while a stream capture was in progress
+
+
+def fragment_image(params, flat, layout, dims, backward=False):
+    """Fragment image of the current weights (one ~5 us launch), cached per parameter set: a hit needs the SAME
+    parameter tensor objects (weak references -- a new model whose arena lands on a freed model's address is a miss)
+    at the same sum of version counters (every in-place update, i.e. every optimizer step, raises it)."""
+    import weakref
+    key = (flat.data_ptr(), int(dims.storage))
+    if torch.cuda.is_current_stream_capturing():
+        # a captured step is replayed after the optimizer has changed the weights: the image build must be IN the graph
+        # (once per pass: the backward of the captured step reuses the node its forward recorded)
+        if backward and key in _CAPTURE_IMAGE:
+            return _CAPTURE_IMAGE[key]
+        image = ops.prepare_image(flat, layout, dims)
+        _CAPTURE_IMAGE.clear()
+        _CAPTURE_IMAGE[key] = image
+        return image
+    _CAPTURE_IMAGE.clear()
+    ver = sum(p._version for p in params)
     hit = _IMAGES.get(key)
-    if hit is not None and hit[0] == ver and hit[1].device == flat.device:
-        return hit[1]
+    if hit is not None and hit[0]() is params[0] and hit[1]() is params[-1] and hit[2] == ver and hit[3].device == flat.device:
+        return hit[3]
     image = ops.prepare_image(flat, layout, dims)
     if len(_IMAGES) > 16:
         _IMAGES.clear()
-    _IMAGES[key] = (ver, image)
+    try:
+        _IMAGES[key] = (weakref.ref(params[0]), weakref.ref(params[-1]), ver, image)
+    except TypeError:                      # not weak-referenceable (e.g. a traced stand-in): do not cache
+        pass
     return image
 
 
@@ -238,7 +264,7 @@ def lba_encoder_backward_op(g_out: Tensor, params: List[Tensor], x_s: Tensor, x_
     nt = _i64(ntypes, "ntypes") if layout.nt_node > 0 else None
     et = _i64(etypes, "etypes") if layout.nt_edge > 0 else None
     flat = flat_arena(params)
-    image = fragment_image(params, flat, layout, dims)
+    image = fragment_image(params, flat, layout, dims, backward=True)
     csr = ops.csr_for_backward(edge_index, N)
     hs, dhs, h_last = [state[l] for l in range(nc)], [state[nc + l] for l in range(nc)], state[2 * nc]
     mk = [(masks[2 * l], masks[2 * l + 1]) for l in range(nc)] if masks.numel() else [(None, None)] * nc

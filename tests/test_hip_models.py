@@ -154,3 +154,31 @@ def test_pair_parallel_world1_on_the_hip_encoders(pretrained):
         assert float((g1[k].grad - v.grad).abs().max()) <= 1e-5 * float(v.grad.abs().max()) + 2e-6 * scale, k
         n += 1
     assert n > 100
+
+
+def test_fragment_image_cache_is_per_model(lba_small):
+    """Two freshly built models one after the other (the second one's parameter arena can land on the freed first one's
+    address, with equal version counters): each must run on ITS OWN weights, in the autograd path too."""
+    from models.protein_gnn import SelectableProteinModelWrapper
+    import gc
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))["protein_gnn_kwargs"]
+    for k in ("in_channels", "edge_dim", "hidden_channels", "edge_hidden_channels"):
+        kw[k] = tuple(kw[k])
+    g = lba_small
+    T = torch.from_numpy
+    d = _to(dict(x=(T(g["x_s"]), T(g["x_v"])), edge_index=T(g["edge_index"]), ntypes=T(g["ntypes"]),
+                 etypes=T(g["etypes"]), eattr=(T(g["e_s"]), T(g["e_v"]))))
+    for seed in (1, 2, 3):
+        torch.manual_seed(seed)
+        m = SelectableProteinModelWrapper(**kw).to(DEV).eval()
+        P = {k: v.detach().cpu() for k, v in m.gnn_model.state_dict().items()}
+        ref = O.protein_lba_forward(P, (T(g["x_s"]), T(g["x_v"])), T(g["edge_index"]), T(g["ntypes"]), T(g["etypes"]),
+                                    (T(g["e_s"]), T(g["e_v"])))
+        xs = d["x"][0].clone().requires_grad_()                       # autograd path (the cached-image path)
+        out = m((xs, d["x"][1]), d["edge_index"], d["ntypes"], d["etypes"], eattr=d["eattr"])
+        assert rel_err(out, ref) < TOL, seed
+        with torch.no_grad():
+            assert rel_err(m(**d), ref) < TOL, seed
+        del m, out, xs
+        gc.collect()
+        torch.cuda.empty_cache()
