@@ -145,13 +145,18 @@ __global__ void csr_fill_kernel(const int64_t* __restrict__ ei, int64_t N, int64
 // Position p of target n's segment holds SOME edge of n (arrival order of the fill).  Its final place is its rank
 // among the segment's edge ids; deg independent reads per position instead of a serial per-node insertion sort.
 // Threads t < counters also restore the zeroed-counters contract of `work`.
-__global__ void csr_rank_kernel(const int64_t* __restrict__ ei, int64_t N, int64_t counters,
+// Positions rowptr[N] .. E of the sorted tables exist only when edges were dropped (endpoint out of range): they get
+// eperm = -1, esrc = edst = 0, so a kernel that walks all E positions (the edge-embedding backward) can skip them.
+__global__ void csr_rank_kernel(const int64_t* __restrict__ ei, int64_t N, int64_t E, int64_t counters,
                                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ tmp,
-                                const int32_t* __restrict__ edst, int32_t* __restrict__ eperm,
+                                int32_t* __restrict__ edst, int32_t* __restrict__ eperm,
                                 int32_t* __restrict__ esrc, int32_t* __restrict__ cnt) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < counters) cnt[t] = 0;
-  if (t >= rowptr[N]) return;
+  if (t >= rowptr[N]) {
+    if (t < E) { eperm[t] = -1; esrc[t] = 0; edst[t] = 0; }
+    return;
+  }
   const int32_t n = edst[t], lo = rowptr[n], hi = rowptr[n + 1], key = tmp[t];
   int32_t rank = 0;
   for (int32_t j = lo; j < hi; ++j) rank += tmp[j] < key ? 1 : 0;
@@ -587,7 +592,7 @@ int cgvp_csr_from_coo(const int64_t* edge_index, int64_t N, int64_t E, int32_t* 
   hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), (size_t)(tile + 1024 + 32) * sizeof(int32_t), s, work, N, rowptr);
   if (E > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, work, tmp, edst);
   const int64_t span = E > counters ? E : counters;
-  hipLaunchKernelGGL(csr_rank_kernel, dim3((unsigned)((span + B - 1) / B)), dim3(B), 0, s, edge_index, N, counters, rowptr, tmp,
+  hipLaunchKernelGGL(csr_rank_kernel, dim3((unsigned)((span + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, counters, rowptr, tmp,
                      edst, eperm, esrc, work);
   return launch_status();
 }

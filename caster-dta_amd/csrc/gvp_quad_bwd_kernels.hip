@@ -664,14 +664,16 @@ __global__ __launch_bounds__(BW_TPB, 2) void edge_bwd_kernel(EdgeBArgs a) {
   for (int64_t t = (int64_t)w * gridDim.x + blockIdx.x; t < tiles; t += (int64_t)gridDim.x * BW_WPB) {
     const int lane = opaque_lane(lane0), i = lane & 15, g = lane >> 4;
     const int64_t p = t * TILE + i;
-    const bool active = p < a.E;
+    // positions behind the last VALID edge hold eperm = -1 (edges with out-of-range endpoints are dropped by the CSR
+    // build, which leaves E - rowptr[N] unused positions at the end of the sorted tables)
+    const int32_t eid = p < a.E ? a.eperm[p] : -1;
+    const bool active = eid >= 0;
     f4 es0 = zero, es1 = zero;
     float ev[3] = {0.f, 0.f, 0.f};
     int et[1] = {0};
     f4 d_es[2] = {zero, zero};
     float d_ev[3][1] = {{0.f}, {0.f}, {0.f}};
     if (active) {
-      const int32_t eid = a.eperm[p];
       const int64_t er = (int64_t)eid * EDGE_IN_S;
       es0 = Io<ST>::ld4(a.e_s, er + 4 * g);
       es1 = Io<ST>::ld4(a.e_s, er + 16 + 4 * g);

@@ -96,3 +96,38 @@ def test_drug_random_graph_vs_oracle(molecule_params, n, e):
         want = P[name].grad
         assert float((p.grad.cpu() - want).abs().max()) <= 2e-4 * float(want.abs().max()) + 2e-6 * scale, name
     assert rel_err(xg.grad, xr.grad) < 2e-4
+
+
+def test_out_of_range_edges_are_dropped_everywhere():
+    """cgvp_csr_from_coo drops edges whose endpoints are out of range (the reference's index_select would raise; a GPU
+    kernel must never fault on them).  Forward and every gradient then equal the run on the cleaned edge list -- in
+    particular the edge-embedding backward, which walks all E sorted positions, skips the unused tail."""
+    from models.protein_gnn import SelectableProteinModelWrapper
+    rng = np.random.default_rng(5)
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))["protein_gnn_kwargs"]
+    for k in ("in_channels", "edge_dim", "hidden_channels", "edge_hidden_channels"):
+        kw[k] = tuple(kw[k])
+    torch.manual_seed(9)
+    model = SelectableProteinModelWrapper(**kw).to(DEV).eval()
+    params = [p for p in model.parameters() if p.numel()]
+    n, e = 70, 230
+    d = _protein_inputs(rng, n, e, hubs=False)
+    ei = d["edge_index"].clone()
+    bad = torch.tensor([3, 57, 111, 229])
+    ei[0, bad[:2]] = torch.tensor([n, -1])                 # source out of range
+    ei[1, bad[2:]] = torch.tensor([n + 5, -7])             # target out of range
+    keep = torch.ones(e, dtype=torch.bool)
+    keep[bad] = False
+    to = lambda t: t.to(DEV)
+    r = torch.randn(n, 64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+
+    def run(edge_index, etypes, eattr):
+        out = model((to(d["x"][0]), to(d["x"][1])), to(edge_index), to(d["ntypes"]), to(etypes), eattr=tuple(to(t) for t in eattr))
+        return out.detach(), torch.autograd.grad(out, params, r)
+
+    out_bad, g_bad = run(ei, d["etypes"], d["eattr"])
+    out_ok, g_ok = run(d["edge_index"][:, keep], d["etypes"][keep], tuple(t[keep] for t in d["eattr"]))
+    assert torch.isfinite(out_bad).all() and rel_err(out_bad, out_ok) < 1e-6
+    scale = max(float(g.abs().max()) for g in g_ok)
+    for a, b in zip(g_bad, g_ok):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 2e-6 * scale
