@@ -23,6 +23,9 @@ int offsets(int nt_node, int nt_edge, int num_convs, QuadOffsets* o);
 int prepare(const gvp::EncLayout& L, int num_convs, int packed_bf16, const float* params, float* image, hipStream_t st);
 int node_embed(int nt_node, const float* img, const float* x_s, const float* x_v, const int64_t* ntypes,
                int64_t N, float* h, unsigned long long* rng_state, unsigned long long* rng_out, int bf16, hipStream_t st);
+int pass_begin(const gvp::EncLayout& L, int num_convs, int bf16, const float* params, float* image, const float* x_s,
+               const float* x_v, const int64_t* ntypes, int64_t N, float* h, unsigned long long* rng_state,
+               unsigned long long* rng_out, const int64_t* edge_index, int64_t E, int32_t* counters, hipStream_t st);
 int conv(int nt_edge, const float* img, const float* h, const float* e_s, const float* e_v,
          const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc,
          const int32_t* edst, int64_t N, int64_t E, int mean, float* dh, int fuse, const float* img_node,

@@ -580,14 +580,15 @@ int cgvp_csr_from_coo(const int64_t* edge_index, int64_t N, int64_t E, int32_t* 
   if ((uintptr_t)work & 15) return CGVP_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int64_t counters = (N + 1 + 63) / 64 * 64;
-  if (!work_is_zero) {
+  if (work_is_zero == 0) {
     // whole 256-B multiples: the runtime splits any other size into two fill launches (body + tail)
     hipError_t err = hipMemsetAsync(work, 0, (size_t)counters * sizeof(int32_t), s);
     if (err != hipSuccess) return (int)err;
   }
   int32_t* tmp = ids_scratch;
   const int B = 256;
-  if (E > 0) hipLaunchKernelGGL(csr_count_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, work);
+  if (E > 0 && work_is_zero != 2)     // 2: cgvp_lba_pass_begin already counted into `work`
+    hipLaunchKernelGGL(csr_count_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, work);
   const int64_t tile = N < SCAN_LDS ? (N + 3) / 4 * 4 : SCAN_LDS;
   hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), (size_t)(tile + 1024 + 32) * sizeof(int32_t), s, work, N, rowptr);
   if (E > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, work, tmp, edst);
@@ -635,6 +636,25 @@ int cgvp_lba_prepare(const cgvp_dims* dims, const cgvp_layout* layout, const flo
   if (!layout || !params || !image) return CGVP_ERR_BAD_ARG;
   // bf16 storage: the fragments of every GEMM with K > 4 are packed as bf16 for v_mfma_f32_16x16x16_bf16 (gvp_quad.h)
   if (int rc = quad::prepare(cvt(*layout), num_convs_of(*layout), is_bf16(dims) ? 1 : 0, params, image, (hipStream_t)stream)) return rc;
+  return launch_status();
+}
+
+int cgvp_lba_pass_begin(const cgvp_dims* dims, const cgvp_layout* layout, const float* params, float* image,
+                        const float* x_s, const float* x_v, const int64_t* ntypes, int64_t N, float* h,
+                        uint64_t* rng_state, uint64_t* rng_out, const int64_t* edge_index, int64_t E,
+                        int32_t* csr_counters, void* stream) {
+  if (int rc = check_dims(dims)) return rc;
+  if (N < 0 || E < 0 || !layout || !params || !image || (layout->nt_node > 0 && N > 0 && !ntypes)) return CGVP_ERR_BAD_ARG;
+  if ((rng_state != nullptr) != (rng_out != nullptr)) return CGVP_ERR_BAD_ARG;
+  if (((uintptr_t)rng_state & 7) || ((uintptr_t)rng_out & 7) || ((uintptr_t)h & 15) || ((uintptr_t)image & 15)) return CGVP_ERR_BAD_ARG;
+  if ((edge_index != nullptr) != (csr_counters != nullptr)) return CGVP_ERR_BAD_ARG;
+  if (N > 0 && (!x_s || !x_v || !h)) return CGVP_ERR_BAD_ARG;
+  if (N >= (int64_t)1 << 31 || E >= (int64_t)1 << 31) return CGVP_ERR_BAD_ARG;
+  if (N == 0 && rng_state)           // no embedding block exists to do the hand-off
+    if (int rc = cgvp_rng_next(rng_state, rng_out, stream)) return rc;
+  if (int rc = quad::pass_begin(cvt(*layout), num_convs_of(*layout), is_bf16(dims), params, image, x_s, x_v, ntypes, N, h,
+                                reinterpret_cast<unsigned long long*>(rng_state), reinterpret_cast<unsigned long long*>(rng_out),
+                                edge_index, E, csr_counters, (hipStream_t)stream)) return rc;
   return launch_status();
 }
 

@@ -98,52 +98,57 @@ __device__ __forceinline__ void stage_slices(float* lds, const float* __restrict
 
 // ------------------------------------------------------------------ prepare
 template <int NTN, int NTE>
-__global__ void lba_prepare_kernel(const float* __restrict__ P, EncLayout L, int num_convs, int packed, float* __restrict__ img) {
+__device__ __forceinline__ float image_element(const float* __restrict__ P, const EncLayout& L, int num_convs, int packed, int idx) {
   typedef Image<NTN, NTE> IM;
-  const int total = IM::total(num_convs);
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    float v;
-    if (idx < IM::EMB_SIZE) {
-      v = idx < IM::EMB_LN ? QNode<NTN>::element(P + L.node_gvp, idx, packed != 0) : P[L.node_ln + (idx - IM::EMB_LN)];
-    } else if (idx < IM::head(num_convs)) {
-      const int j = idx - IM::EMB_SIZE;
-      const int l = j / (IM::CV_SIZE + IM::ND_SIZE);
-      int k = j - l * (IM::CV_SIZE + IM::ND_SIZE);
-      const float* C = P + L.conv0 + l * L.conv_stride;
-      if (k < IM::CV_SIZE) {
-        if (k < IM::CV_ELN) v = QEdge<NTE>::element(P + L.edge_gvp, k, packed != 0);
-        else if (k < IM::CV_M0) v = P[L.edge_ln + (k - IM::CV_ELN)];
-        else if (k < IM::CV_M1) v = QMsg0::element(C + CONV_M0, k - IM::CV_M0, packed != 0);
-        else if (k < IM::CV_M2) v = QMsg1::element(C + conv_m1(), k - IM::CV_M1, packed != 0);
-        else v = QMsg2::element(C + conv_m2(), k - IM::CV_M2, packed != 0);
-      } else {
-        k -= IM::CV_SIZE;
-        if (k < IM::ND_FF0) v = C[conv_ln0() + k];
-        else if (k < IM::ND_FF1) v = QFf0::element(C + conv_ff0(), k - IM::ND_FF0, packed != 0);
-        else if (k < IM::ND_LN1) v = QFf1::element(C + conv_ff1(), k - IM::ND_FF1, packed != 0);
-        else v = C[conv_ln1() + (k - IM::ND_LN1)];
-      }
-    } else if (idx < IM::fwd_total(num_convs)) {
-      const int k = idx - IM::head(num_convs);
-      v = k < IM::HD_GVP ? P[L.ln_out + k] : QHead::element(P + L.head, k - IM::HD_GVP, packed != 0);
-    } else if (idx < IM::convT(num_convs, 0)) {
-      v = QNode<NTN>::element_t(P + L.node_gvp, idx - IM::embT(num_convs), packed != 0);
-    } else if (idx < IM::headT(num_convs)) {
-      const int j = idx - IM::convT(num_convs, 0);
-      const int l = j / (IM::TC_SIZE + IM::TN_SIZE);
-      int k = j - l * (IM::TC_SIZE + IM::TN_SIZE);
-      const float* C = P + L.conv0 + l * L.conv_stride;
-      if (k < IM::TC_M0) v = QEdge<NTE>::element_t(P + L.edge_gvp, k, packed != 0);
-      else if (k < IM::TC_M1) v = QMsg0::element_t(C + CONV_M0, k - IM::TC_M0, packed != 0);
-      else if (k < IM::TC_M2) v = QMsg1::element_t(C + conv_m1(), k - IM::TC_M1, packed != 0);
-      else if (k < IM::TC_SIZE) v = QMsg2::element_t(C + conv_m2(), k - IM::TC_M2, packed != 0);
-      else if (k < IM::TC_SIZE + IM::TN_FF1) v = QFf0::element_t(C + conv_ff0(), k - IM::TC_SIZE, packed != 0);
-      else v = QFf1::element_t(C + conv_ff1(), k - IM::TC_SIZE - IM::TN_FF1, packed != 0);
+
+  float v;
+  if (idx < IM::EMB_SIZE) {
+    v = idx < IM::EMB_LN ? QNode<NTN>::element(P + L.node_gvp, idx, packed != 0) : P[L.node_ln + (idx - IM::EMB_LN)];
+  } else if (idx < IM::head(num_convs)) {
+    const int j = idx - IM::EMB_SIZE;
+    const int l = j / (IM::CV_SIZE + IM::ND_SIZE);
+    int k = j - l * (IM::CV_SIZE + IM::ND_SIZE);
+    const float* C = P + L.conv0 + l * L.conv_stride;
+    if (k < IM::CV_SIZE) {
+      if (k < IM::CV_ELN) v = QEdge<NTE>::element(P + L.edge_gvp, k, packed != 0);
+      else if (k < IM::CV_M0) v = P[L.edge_ln + (k - IM::CV_ELN)];
+      else if (k < IM::CV_M1) v = QMsg0::element(C + CONV_M0, k - IM::CV_M0, packed != 0);
+      else if (k < IM::CV_M2) v = QMsg1::element(C + conv_m1(), k - IM::CV_M1, packed != 0);
+      else v = QMsg2::element(C + conv_m2(), k - IM::CV_M2, packed != 0);
     } else {
-      v = QHead::element_t(P + L.head, idx - IM::headT(num_convs), packed != 0);
+      k -= IM::CV_SIZE;
+      if (k < IM::ND_FF0) v = C[conv_ln0() + k];
+      else if (k < IM::ND_FF1) v = QFf0::element(C + conv_ff0(), k - IM::ND_FF0, packed != 0);
+      else if (k < IM::ND_LN1) v = QFf1::element(C + conv_ff1(), k - IM::ND_FF1, packed != 0);
+      else v = C[conv_ln1() + (k - IM::ND_LN1)];
     }
-    img[idx] = v;
+  } else if (idx < IM::fwd_total(num_convs)) {
+    const int k = idx - IM::head(num_convs);
+    v = k < IM::HD_GVP ? P[L.ln_out + k] : QHead::element(P + L.head, k - IM::HD_GVP, packed != 0);
+  } else if (idx < IM::convT(num_convs, 0)) {
+    v = QNode<NTN>::element_t(P + L.node_gvp, idx - IM::embT(num_convs), packed != 0);
+  } else if (idx < IM::headT(num_convs)) {
+    const int j = idx - IM::convT(num_convs, 0);
+    const int l = j / (IM::TC_SIZE + IM::TN_SIZE);
+    int k = j - l * (IM::TC_SIZE + IM::TN_SIZE);
+    const float* C = P + L.conv0 + l * L.conv_stride;
+    if (k < IM::TC_M0) v = QEdge<NTE>::element_t(P + L.edge_gvp, k, packed != 0);
+    else if (k < IM::TC_M1) v = QMsg0::element_t(C + CONV_M0, k - IM::TC_M0, packed != 0);
+    else if (k < IM::TC_M2) v = QMsg1::element_t(C + conv_m1(), k - IM::TC_M1, packed != 0);
+    else if (k < IM::TC_SIZE) v = QMsg2::element_t(C + conv_m2(), k - IM::TC_M2, packed != 0);
+    else if (k < IM::TC_SIZE + IM::TN_FF1) v = QFf0::element_t(C + conv_ff0(), k - IM::TC_SIZE, packed != 0);
+    else v = QFf1::element_t(C + conv_ff1(), k - IM::TC_SIZE - IM::TN_FF1, packed != 0);
+  } else {
+    v = QHead::element_t(P + L.head, idx - IM::headT(num_convs), packed != 0);
   }
+    return v;
+}
+
+template <int NTN, int NTE>
+__global__ void lba_prepare_kernel(const float* __restrict__ P, EncLayout L, int num_convs, int packed, float* __restrict__ img) {
+  const int total = Image<NTN, NTE>::total(num_convs);
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x)
+    img[idx] = image_element<NTN, NTE>(P, L, num_convs, packed, idx);
 }
 
 // ------------------------------------------------------------------ embed
@@ -154,22 +159,14 @@ struct EmbedQArgs {
   unsigned long long* rng_state; unsigned long long* rng_out;
 };
 
+// the embedding of the 16 residues of this wave's tile; `lds` = the embed slice of the image, staged by the caller
 template <int NTN, typename ST>
-__global__ __launch_bounds__(TPB) void embed_quad_kernel(EmbedQArgs a) {
+__device__ __forceinline__ void embed_tile(const EmbedQArgs& a, const float* lds, int64_t block) {
   typedef Image<NTN, 0> IM;
   typedef QNode<NTN> Q;
-  __shared__ __attribute__((aligned(16))) float lds[IM::EMB_SIZE];
-  stage_slice<IM::EMB_SIZE>(lds, a.img, threadIdx.x);
-  if (a.rng_state && blockIdx.x == 0 && threadIdx.x == 0) {
-    const unsigned long long off = a.rng_state[1] + 1;
-    a.rng_state[1] = off;
-    a.rng_out[0] = a.rng_state[0];
-    a.rng_out[1] = off;
-  }
-  __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
-  const int64_t n = ((int64_t)blockIdx.x * WPB + w) * TILE + i;
+  const int64_t n = (block * WPB + w) * TILE + i;
   const bool active = n < a.N;
   float bs[1][Q::SSTEPS], bv[1][3][1];
   int type[1] = {0};
@@ -194,6 +191,61 @@ __global__ __launch_bounds__(TPB) void embed_quad_kernel(EmbedQArgs a) {
 #pragma unroll
     for (int p = 0; p < 3; ++p) Io<ST>::st(a.h, n * ROW + NS + 3 * g + p, v[0][p][0]);
   }
+}
+__device__ __forceinline__ void rng_handoff(const EmbedQArgs& a) {
+  if (a.rng_state && blockIdx.x == 0 && threadIdx.x == 0) {
+    const unsigned long long off = a.rng_state[1] + 1;
+    a.rng_state[1] = off;
+    a.rng_out[0] = a.rng_state[0];
+    a.rng_out[1] = off;
+  }
+}
+
+template <int NTN, typename ST>
+__global__ __launch_bounds__(TPB) void embed_quad_kernel(EmbedQArgs a) {
+  typedef Image<NTN, 0> IM;
+  __shared__ __attribute__((aligned(16))) float lds[IM::EMB_SIZE];
+  stage_slice<IM::EMB_SIZE>(lds, a.img, threadIdx.x);
+  rng_handoff(a);
+  __syncthreads();
+  embed_tile<NTN, ST>(a, lds, blockIdx.x);
+}
+
+// First launch of a protein TRAINING pass (cgvp_lba_pass_begin): three independent pieces of work share one grid --
+//   blocks [0, embed_blocks)            gvp_node on 64 residues each; they build their 1.2k-float slice of the fragment
+//                                       image straight from the arena, so they do not wait for ...
+//   next prep_blocks blocks             ... the fragment image of the current weights (cgvp_lba_prepare's work), and
+//   the remaining count_blocks blocks   the per-target edge counts of the CSR build (cgvp_csr_from_coo's first launch).
+// Two launches less at the head of every step (~5 us each at 64 x 300 residues: these kernels are launch latency).
+struct PassBeginArgs {
+  EmbedQArgs e;
+  const float* params; EncLayout L; int num_convs; int packed; float* image;
+  const int64_t* ei; int64_t E; int64_t Ncount; int32_t* counters;
+  int embed_blocks, prep_blocks;
+};
+template <int NTN, int NTE, typename ST>
+__global__ __launch_bounds__(TPB) void pass_begin_kernel(PassBeginArgs a) {
+  typedef Image<NTN, NTE> IM;
+  __shared__ __attribute__((aligned(16))) float lds[IM::EMB_SIZE];
+  const int b = blockIdx.x;
+  if (b >= a.embed_blocks + a.prep_blocks) {                       // CSR count (malformed edges are dropped, never fault)
+    const int64_t e = (int64_t)(b - a.embed_blocks - a.prep_blocks) * TPB + threadIdx.x;
+    if (e < a.E) {
+      const int64_t s = a.ei[e], d = a.ei[a.E + e];
+      if (s >= 0 && s < a.Ncount && d >= 0 && d < a.Ncount) atomicAdd(&a.counters[d], 1);
+    }
+    return;
+  }
+  if (b >= a.embed_blocks) {                                        // fragment image
+    const int total = IM::total(a.num_convs);
+    for (int idx = (b - a.embed_blocks) * TPB + threadIdx.x; idx < total; idx += a.prep_blocks * TPB)
+      a.image[idx] = image_element<NTN, NTE>(a.params, a.L, a.num_convs, a.packed, idx);
+    return;
+  }
+  for (int k = threadIdx.x; k < IM::EMB_SIZE; k += TPB) lds[k] = image_element<NTN, NTE>(a.params, a.L, a.num_convs, a.packed, k);
+  rng_handoff(a.e);
+  __syncthreads();
+  embed_tile<NTN, ST>(a.e, lds, b);
 }
 
 // ------------------------------------------------------------------ node update
@@ -680,6 +732,30 @@ int node_embed(int nt_node, const float* img, const float* x_s, const float* x_v
     default: return CGVP_ERR_UNSUPPORTED_DIMS;
   }
 #undef EMB_LAUNCH
+  return 0;
+}
+
+template <int NTN, int NTE>
+int pass_begin_impl(const PassBeginArgs& a, int blocks, int bf16, hipStream_t st) {
+  if (bf16) hipLaunchKernelGGL((pass_begin_kernel<NTN, NTE, bf16s>), dim3(blocks), dim3(TPB), 0, st, a);
+  else hipLaunchKernelGGL((pass_begin_kernel<NTN, NTE, float>), dim3(blocks), dim3(TPB), 0, st, a);
+  return 0;
+}
+int pass_begin(const EncLayout& L, int num_convs, int bf16, const float* params, float* image, const float* x_s,
+               const float* x_v, const int64_t* ntypes, int64_t N, float* h, unsigned long long* rng_state,
+               unsigned long long* rng_out, const int64_t* edge_index, int64_t E, int32_t* counters, hipStream_t st) {
+  QuadOffsets o;
+  if (int rc = offsets(L.nt_node, L.nt_edge, num_convs, &o)) return rc;
+  PassBeginArgs a{};
+  a.e = EmbedQArgs{nullptr, x_s, x_v, ntypes, N, h, rng_state, rng_out};
+  a.params = params; a.L = L; a.num_convs = num_convs; a.packed = bf16 ? 1 : 0; a.image = image;
+  a.ei = edge_index; a.E = (edge_index && counters) ? E : 0; a.Ncount = N; a.counters = counters;
+  a.embed_blocks = (int)((N + WPB * TILE - 1) / (WPB * TILE));
+  a.prep_blocks = (o.total + TPB - 1) / TPB;
+  const int blocks = a.embed_blocks + a.prep_blocks + (int)((a.E + TPB - 1) / TPB);
+#define CALL(A, B) pass_begin_impl<A, B>(a, blocks, bf16, st)
+  DISPATCH_NT(L.nt_node, L.nt_edge, CALL)
+#undef CALL
   return 0;
 }
 

@@ -15,11 +15,11 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CGVP_LIB_PATH: A/B builds of the same ABI (diagnostics); the default is the in-tree library
 LIB_PATH = os.environ.get("CGVP_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libcaster_gvp.so")
-ABI_VERSION = 22
+ABI_VERSION = 23
 # sha256 of include/caster_gvp.h with comments, blank space and the CGVP_ABI_VERSION line removed, as
 # `abi_header_digest()` computes it.  tests/test_abi.py fails when the header's declarations change
 # without CGVP_ABI_VERSION, ABI_VERSION and this digest being updated together.
-ABI_HEADER_SHA256 = "7559857992608802490aaefe4285340f696592e07b6f76ecbad2a324a98389e2"
+ABI_HEADER_SHA256 = "de7cd26d51aafae247878355a436e9d4f9b32aba755ae6364c754b22a9bfac17"
 
 
 class HipLibraryError(RuntimeError):
@@ -72,6 +72,7 @@ _SIGNATURES = {
     "cgvp_lba_layout": (C.c_int, [C.POINTER(Dims), _I32, _I32, _I32, C.POINTER(Layout)]),
     "cgvp_lba_image_floats": (C.c_int64, [C.POINTER(Dims), C.POINTER(Layout)]),
     "cgvp_lba_prepare": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _P]),
+    "cgvp_lba_pass_begin": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _I64, _P, _P]),
     "cgvp_node_embed_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "cgvp_rng_next": (C.c_int, [_P, _P, _P]),
     "cgvp_conv_fwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P,

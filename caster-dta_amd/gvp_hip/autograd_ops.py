@@ -117,6 +117,33 @@ def invalidate_images():
 _CAPTURE_IMAGE = {}     # key -> image built by the latest FORWARD while a stream capture was in progress
 
 
+_IMAGE_FLOATS = {}
+
+
+def image_floats(layout, dims):
+    key = (layout.nt_node, layout.nt_edge, layout.total, int(dims.storage))
+    n = _IMAGE_FLOATS.get(key)
+    if n is None:
+        n = _IMAGE_FLOATS[key] = int(_lib.lib().cgvp_lba_image_floats(C.byref(dims), C.byref(layout)))
+    return n
+
+
+def remember_image(params, flat, dims, image):
+    """Register an image another launch built (cgvp_lba_pass_begin) for the backward of the same pass / later eager calls."""
+    import weakref
+    key = (flat.data_ptr(), int(dims.storage))
+    if torch.cuda.is_current_stream_capturing():
+        _CAPTURE_IMAGE.clear()
+        _CAPTURE_IMAGE[key] = image
+        return
+    if len(_IMAGES) > 16:
+        _IMAGES.clear()
+    try:
+        _IMAGES[key] = (weakref.ref(params[0]), weakref.ref(params[-1]), sum(p._version for p in params), image)
+    except TypeError:
+        pass
+
+
 def fragment_image(params, flat, layout, dims, backward=False):
     """Fragment image of the current weights (one ~5 us launch), cached per parameter set: a hit needs the SAME
     parameter tensor objects (weak references -- a new model whose arena lands on a freed model's address is a miss)
@@ -169,9 +196,9 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
     flat = flat_arena(params)
     if flat.numel() != layout.total:
         raise RuntimeError(f"parameter arena has {flat.numel()} floats, kernels expect {layout.total}")
-    image = fragment_image(params, flat, layout, dims) if ops.VARIANT == "mfma" else None
     f32, act = dict(dtype=torch.float32, device=dev), dict(dtype=sdt, device=dev)
     if not save_state:
+        image = fragment_image(params, flat, layout, dims) if ops.VARIANT == "mfma" else None
         csr = ops.csr_for_forward(edge_index, N)
         out = ops.lba_encoder_forward(flat, layout, dims, nc, x_s, x_v, ntypes, e_s, e_v, etypes, csr,
                                       aggr_mean=mean, image=image)
@@ -196,15 +223,21 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
     out = torch.empty(N, dims.out_s, **act)
     e_emb = torch.empty(E + 1, EROW, **act)
     with torch.cuda.device(dev):
-        d, lay, P, I = C.byref(dims), C.byref(layout), _ptr(flat), _ptr(image)
-        # (forking the node embedding -- which does not need the tables -- onto a second stream beside the CSR build, and
-        # d(node embedding) beside d(edge embedding) in the backward, was measured in round 2: the two cross-queue joins
-        # cost more than the ~14 us of overlap they buy, 0.286 vs 0.252 ms per protein step; one stream it is)
+        d, lay, P = C.byref(dims), C.byref(layout), _ptr(flat)
+        # ONE launch for the three independent things a pass starts with: the node embedding, the fragment image of the
+        # current weights and the edge counts of the CSR build (each is launch latency at these sizes).
+        # (Forking them onto a second stream instead was measured in round 2: every cross-queue join costs ~10 us.)
         st = _stream()
-        _lib.check(L.cgvp_node_embed_fwd(d, lay, P, I, _ptr(x_s), _ptr(x_v), _ptr(nt), N, _ptr(hs[0]),
-                                         _ptr(rstate), _ptr(seed if rstate is not None else None), st),
-                   "cgvp_node_embed_fwd")
-        csr = ops.csr_for_forward(edge_index, N)
+        image = torch.empty(image_floats(layout, dims), **f32)
+        memo = ops.csr_memo(edge_index, N)
+        counters = ops.csr_counters(dev, N) if (memo is None and E > 0) else None
+        ei = ops._i64(edge_index, "edge_index") if counters is not None else None
+        _lib.check(L.cgvp_lba_pass_begin(d, lay, P, _ptr(image), _ptr(x_s), _ptr(x_v), _ptr(nt), N, _ptr(hs[0]),
+                                         _ptr(rstate), _ptr(seed if rstate is not None else None),
+                                         _ptr(ei), E, _ptr(counters), st), "cgvp_lba_pass_begin")
+        remember_image(params, flat, dims, image)
+        I = _ptr(image)
+        csr = ops.csr_for_forward(edge_index, N, counted=counters)
         rows = csr.table_rows if csr.table_rows is not None else E
         if tuple(e_s.shape) != (rows, dims.edge_in_s) or tuple(e_v.shape) != (rows, dims.edge_in_v, 3) or csr.num_edges != E:
             raise NotImplementedError("feature shapes do not match the compiled CASTER-DTA configuration")

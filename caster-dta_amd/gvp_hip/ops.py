@@ -116,7 +116,9 @@ class Csr:
     table_rows: int = None      # set by CsrStore.collate(table=True): eperm indexes a resident feature table of this many rows
 
 
-def build_csr(edge_index, num_nodes):
+def build_csr(edge_index, num_nodes, counted=None):
+    """`counted`: the counters buffer a cgvp_lba_pass_begin launch on this stream has already filled with the per-target
+    edge counts of this very edge_index (csr_counters(...)): the build then skips its count launch."""
     ei = _i64(edge_index, "edge_index")
     if ei.dim() != 2 or ei.shape[0] != 2:
         raise ValueError(f"edge_index must be [2, E], got {tuple(ei.shape)}")
@@ -129,11 +131,16 @@ def build_csr(edge_index, num_nodes):
     edst = torch.empty(max(E, 1), **i32)
     ids = torch.empty(max(E, 1), **i32)
     with torch.cuda.device(dev):
-        work = _zeroed_counters(dev, (num_nodes + 1 + 63) // 64 * 64)
+        work = counted if counted is not None else csr_counters(dev, num_nodes)
         rc = _lib.lib().cgvp_csr_from_coo(_ptr(ei), num_nodes, E, _ptr(rowptr), _ptr(eperm), _ptr(esrc),
-                                          _ptr(edst), _ptr(work), 1, _ptr(ids), _stream())
+                                          _ptr(edst), _ptr(work), 2 if counted is not None else 1, _ptr(ids), _stream())
     _lib.check(rc, "cgvp_csr_from_coo")
     return Csr(rowptr, eperm, esrc, edst, num_nodes, E)
+
+
+def csr_counters(dev, num_nodes):
+    """The zeroed per-target counters of a CSR build on the current stream (see _zeroed_counters)."""
+    return _zeroed_counters(dev, (num_nodes + 1 + 63) // 64 * 64)
 
 
 _COUNTERS = {}      # (device index, stream handle) -> int32 counters, zero between calls (cgvp_csr_from_coo keeps them so)
@@ -273,7 +280,16 @@ class _timed:
             KERNEL_EVENTS.append((self.name,) + self.ev)
 
 
-def cached_csr(edge_index, num_nodes):
+def csr_memo(edge_index, num_nodes):
+    """The memoised CSR of this tensor object, or None (see cached_csr)."""
+    if CSR_CACHE_ENABLED:
+        memo = getattr(edge_index, "_cgvp_csr", None)
+        if memo is not None and memo[0] == edge_index._version and memo[1].num_nodes == num_nodes:
+            return memo[1]
+    return None
+
+
+def cached_csr(edge_index, num_nodes, counted=None):
     """CSR of `edge_index`, memoised ON the tensor object itself (attribute
     `_cgvp_csr`), so protein layers, repeated forwards on one batch and the
     backward pass share one build.  The memo dies with the tensor and is ignored
@@ -283,7 +299,7 @@ def cached_csr(edge_index, num_nodes):
         memo = getattr(edge_index, "_cgvp_csr", None)
         if memo is not None and memo[0] == edge_index._version and memo[1].num_nodes == num_nodes:
             return memo[1]
-    csr = build_csr(edge_index, num_nodes)
+    csr = build_csr(edge_index, num_nodes, counted)
     if CSR_CACHE_ENABLED:
         try:
             edge_index._cgvp_csr = (edge_index._version, csr)
@@ -292,11 +308,11 @@ def cached_csr(edge_index, num_nodes):
     return csr
 
 
-def csr_for_forward(edge_index, num_nodes):
+def csr_for_forward(edge_index, num_nodes, counted=None):
     """`cached_csr`, plus a forward -> backward hand-off that does not depend on CSR_CACHE_ENABLED: the tables
     of the latest forward over this tensor object are left on it for the backward of the same step (autograd
     hands the saved `edge_index` back as the same Python object in eager mode)."""
-    csr = cached_csr(edge_index, num_nodes)
+    csr = cached_csr(edge_index, num_nodes, counted)
     try:
         edge_index._cgvp_csr_step = (edge_index._version, csr)
     except (AttributeError, RuntimeError):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 22
+#define CGVP_ABI_VERSION 23
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
@@ -92,9 +92,12 @@ typedef struct {
  *   work         per-target counters: N+1 ints rounded UP to a multiple of 64, 16-B aligned.  They must be zero when
  *                the kernels start: pass work_is_zero = 0 and the call zero-fills them first (one more launch), or
  *                keep a buffer that was zero-filled once and pass work_is_zero = 1 -- every call leaves the
- *                counters it used zeroed again.
+ *                counters it used zeroed again.  work_is_zero = 2: the counters already hold the per-target counts
+ *                (cgvp_lba_pass_begin produced them on this stream): the count launch is skipped.
  *   ids_scratch  E ints (edge ids in arrival order, consumed by the ranking launch)
- * Four launches on `stream` (count, scan, fill, rank), stable: a target's edges stay in edge-id order. */
+ * Four launches on `stream` (count, scan, fill, rank; three after cgvp_lba_pass_begin), stable: a target's edges stay
+ * in edge-id order.  Edges with an endpoint outside [0, N) are dropped; the unused positions at the end of the sorted
+ * tables hold eperm = -1, esrc = edst = 0. */
 int cgvp_csr_from_coo(const int64_t* edge_index, int64_t num_nodes, int64_t num_edges,
                       int32_t* rowptr, int32_t* eperm, int32_t* esrc, int32_t* edst,
                       int32_t* work, int32_t work_is_zero, int32_t* ids_scratch, void* stream);
@@ -139,6 +142,20 @@ int cgvp_lba_prepare(const cgvp_dims* dims, const cgvp_layout* layout, const flo
  * wave tile, 4 lanes per item, the production path); image == NULL runs the
  * scalar one-item-per-lane kernels straight from the arena (kept as an
  * independent second implementation for cross-checks and A/B timing). */
+
+/* First launch of a protein TRAINING pass: three independent pieces of work in ONE launch (each of them is launch
+ * latency at CASTER-DTA batch sizes) --
+ *   (1) gvp_node on all residues: exactly cgvp_node_embed_fwd (MFMA kernels), incl. the generator hand-off;
+ *   (2) the fragment image of the current weights, written to `image` (exactly cgvp_lba_prepare); the embedding blocks
+ *       take their slice straight from `params`, so (1) does not wait for (2);
+ *   (3) optional (edge_index and csr_counters both non-NULL): the per-target edge counts of the CSR build into
+ *       `csr_counters` (int32 [>= N + 1 rounded up to 64], all zero on entry) -- then call cgvp_csr_from_coo on the same
+ *       stream with the same buffer as `work` and work_is_zero = 2 ("already counted").
+ * Replaces protein_gnn.py:368-375 plus the per-step weight / batch bookkeeping in front of it. */
+int cgvp_lba_pass_begin(const cgvp_dims* dims, const cgvp_layout* layout, const float* params, float* image,
+                        const float* x_s, const float* x_v, const int64_t* ntypes, int64_t num_nodes, float* h,
+                        uint64_t* rng_state, uint64_t* rng_out, const int64_t* edge_index, int64_t num_edges,
+                        int32_t* csr_counters, void* stream);
 
 /* gvp_node = Sequential(GVP, LayerNorm) on one-hot(ntypes) ++ x_s, x_v
  * (protein_gnn.py:368-375).  x_s [N][17], x_v [N][3][3], ntypes [N] -> h [N][28]. */
