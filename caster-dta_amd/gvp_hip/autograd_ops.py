@@ -198,10 +198,24 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
         raise RuntimeError(f"parameter arena has {flat.numel()} floats, kernels expect {layout.total}")
     f32, act = dict(dtype=torch.float32, device=dev), dict(dtype=sdt, device=dev)
     if not save_state:
-        image = fragment_image(params, flat, layout, dims) if ops.VARIANT == "mfma" else None
-        csr = ops.csr_for_forward(edge_index, N)
+        image, h0 = None, None
+        if ops.VARIANT == "mfma" and tuple(x_s.shape) == (N, dims.node_in_s) and tuple(x_v.shape) == (N, dims.node_in_v, 3):
+            # inference: the same first launch as a training pass (node embedding + image + edge counts), no generator
+            image = torch.empty(image_floats(layout, dims), **f32)
+            h0 = torch.empty(N, ROW, **act)
+            memo = ops.csr_memo(edge_index, N)
+            counters = ops.csr_counters(dev, N) if (memo is None and E > 0) else None
+            ei = ops._i64(edge_index, "edge_index") if counters is not None else None
+            nt0 = _i64(ntypes, "ntypes") if layout.nt_node > 0 else None
+            with torch.cuda.device(dev):
+                _lib.check(L.cgvp_lba_pass_begin(C.byref(dims), C.byref(layout), _ptr(flat), _ptr(image), _ptr(x_s), _ptr(x_v),
+                                                 _ptr(nt0), N, _ptr(h0), None, None, _ptr(ei), E, _ptr(counters), _stream()),
+                           "cgvp_lba_pass_begin")
+            csr = ops.csr_for_forward(edge_index, N, counted=counters)
+        else:
+            csr = ops.csr_for_forward(edge_index, N)
         out = ops.lba_encoder_forward(flat, layout, dims, nc, x_s, x_v, ntypes, e_s, e_v, etypes, csr,
-                                      aggr_mean=mean, image=image)
+                                      aggr_mean=mean, image=image, h0=h0)
         return (out, torch.empty(0, **act), torch.empty(0, **f32), torch.empty(0, dtype=torch.int64, device=dev),
                 torch.empty(0, **act))
     if tuple(x_s.shape) != (N, dims.node_in_s) or tuple(x_v.shape) != (N, dims.node_in_v, 3):

@@ -359,10 +359,11 @@ def prepare_image(params, layout, dims):
 
 
 def lba_encoder_forward(params, layout, dims, num_convs, x_s, x_v, ntypes, e_s, e_v, etypes, csr,
-                        aggr_mean=False, return_stages=False, image=None):
+                        aggr_mean=False, return_stages=False, image=None, h0=None):
     """VectorProteinGNN_LBAModel.forward (protein_gnn.py:361-388), eval mode,
     as 1 + 2*num_convs launches: node embed, then (conv, node update) per layer
-    with the output head fused into the last node update."""
+    with the output head fused into the last node update.  `h0`: the node embedding, when the caller's
+    cgvp_lba_pass_begin launch already produced it (together with `image`)."""
     L = _lib.lib()
     sdt = torch.bfloat16 if dims.storage == BF16 else torch.float32
     x_s, x_v = _act(x_s, "x_s", sdt), _act(x_v, "x_v", sdt)
@@ -382,7 +383,7 @@ def lba_encoder_forward(params, layout, dims, num_convs, x_s, x_v, ntypes, e_s, 
     nt = _i64(ntypes, "ntypes") if layout.nt_node > 0 else None
     et = _i64(etypes, "etypes") if layout.nt_edge > 0 else None
     dev = x_s.device
-    h = torch.empty(N, ROW, dtype=sdt, device=dev)
+    h = h0 if h0 is not None else torch.empty(N, ROW, dtype=sdt, device=dev)
     h2 = torch.empty(N, ROW, dtype=sdt, device=dev)
     # edge embedding store: layer 0 writes gvp_edge + LayerNorm of every edge (sorted order), later layers read it
     e_emb = torch.empty(E + 1, EROW, dtype=sdt, device=dev) if (VARIANT == "mfma" and num_convs > 1) else None
@@ -396,8 +397,9 @@ def lba_encoder_forward(params, layout, dims, num_convs, x_s, x_v, ntypes, e_s, 
     with torch.cuda.device(dev):
         st = _stream()
         d, lay, P, I = C.byref(dims), C.byref(layout), _ptr(params), _ptr(image)
-        _lib.check(L.cgvp_node_embed_fwd(d, lay, P, I, _ptr(x_s), _ptr(x_v), _ptr(nt), N, _ptr(h), None, None, st),
-                   "cgvp_node_embed_fwd")
+        if h0 is None:
+            _lib.check(L.cgvp_node_embed_fwd(d, lay, P, I, _ptr(x_s), _ptr(x_v), _ptr(nt), N, _ptr(h), None, None, st),
+                       "cgvp_node_embed_fwd")
         if return_stages:
             stages["node_embed"] = h.clone()
         for layer in range(num_convs):
