@@ -657,7 +657,10 @@ int launch_fwd(GineFArgs& a, hipStream_t st) {
   typedef GineQ<CIN, CHID, COUT, NT, NET, ED> Q;
   const int64_t tiles = (a.N + TILE - 1) / TILE;
   int64_t wgs = (tiles + GF_WPB - 1) / GF_WPB;
-  const int G = (int)(wgs < 1 ? 1 : (wgs > 1024 ? 1024 : wgs));
+#ifndef CGVP_GINE_FWD_MAX_WGS
+#define CGVP_GINE_FWD_MAX_WGS 1024
+#endif
+  const int G = (int)(wgs < 1 ? 1 : (wgs > CGVP_GINE_FWD_MAX_WGS ? CGVP_GINE_FWD_MAX_WGS : wgs));
   const size_t lds = (size_t)((Q::GE::NFRAG + Q::G0::NFRAG + Q::G1::NFRAG) * 64 + GF_WPB * Q::ROWS) * sizeof(float);
   if (hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(gine_quad_fwd_kernel<CIN, CHID, COUT, NT, NET, ED>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))

@@ -123,7 +123,16 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int32_t* __restrict__ cn
     int32_t run = carry + wave_base + inc - sum;   // exclusive prefix of this thread's chunk
     for (int i = lo; i < hi; ++i) { const int32_t c = sbuf[i]; sbuf[i] = run; run += c; }
     __syncthreads();
-    for (int i = t; i < n; i += 1024) { const int32_t x = sbuf[i]; rowptr[base + i] = x; cnt[base + i] = x; }
+    if ((((uintptr_t)(rowptr + base)) & 15) == 0) {                   // 16-B stores (the usual case: allocator-aligned rowptr)
+      for (int q = t; q < n4; q += 1024) {
+        const int4 x = reinterpret_cast<const int4*>(sbuf)[q];
+        reinterpret_cast<int4*>(rowptr + base)[q] = x;
+        reinterpret_cast<int4*>(cnt + base)[q] = x;
+      }
+      if (t < (n & 3)) { const int32_t x = sbuf[(n4 << 2) + t]; rowptr[base + (n4 << 2) + t] = x; cnt[base + (n4 << 2) + t] = x; }
+    } else {
+      for (int i = t; i < n; i += 1024) { const int32_t x = sbuf[i]; rowptr[base + i] = x; cnt[base + i] = x; }
+    }
     carry += total;
     __syncthreads();
     if (N == 0) break;

@@ -845,9 +845,21 @@ __global__ __launch_bounds__(RED_COLS * RED_RG) void reduce_segments_kernel(SegT
   const int c = threadIdx.x & (RED_COLS - 1), rg = threadIdx.x / RED_COLS;
   const int j = blockIdx.x * RED_COLS + c;
   if (blockIdx.x * RED_COLS >= sg.len) return;          // whole block out of range (uniform)
+  // four independent partial sums: the row loads of a thread are 4 deep in flight instead of one dependent add at a time
   float s = 0.f;
-  if (j < sg.len)
-    for (int r = rg; r < sg.rows; r += RED_RG) s += sg.slab[(size_t)r * sg.stride + sg.col0 + j];
+  if (j < sg.len) {
+    const float* col = sg.slab + sg.col0 + j;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = rg;
+    for (; r + 3 * RED_RG < sg.rows; r += 4 * RED_RG) {
+      s0 += col[(size_t)r * sg.stride];
+      s1 += col[(size_t)(r + RED_RG) * sg.stride];
+      s2 += col[(size_t)(r + 2 * RED_RG) * sg.stride];
+      s3 += col[(size_t)(r + 3 * RED_RG) * sg.stride];
+    }
+    for (; r < sg.rows; r += RED_RG) s0 += col[(size_t)r * sg.stride];
+    s = (s0 + s1) + (s2 + s3);
+  }
   part[rg][c] = s;
   __syncthreads();
   if (rg == 0 && j < sg.len) {
