@@ -203,6 +203,8 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
             # inference: the same first launch as a training pass (node embedding + image + edge counts), no generator
             image = torch.empty(image_floats(layout, dims), **f32)
             h0 = torch.empty(N, ROW, **act)
+            if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+                raise ValueError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
             memo = ops.csr_memo(edge_index, N)
             counters = ops.csr_counters(dev, N) if (memo is None and E > 0) else None
             ei = ops._i64(edge_index, "edge_index") if counters is not None else None
@@ -243,6 +245,8 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
         # (Forking them onto a second stream instead was measured in round 2: every cross-queue join costs ~10 us.)
         st = _stream()
         image = torch.empty(image_floats(layout, dims), **f32)
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise ValueError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
         memo = ops.csr_memo(edge_index, N)
         counters = ops.csr_counters(dev, N) if (memo is None and E > 0) else None
         ei = ops._i64(edge_index, "edge_index") if counters is not None else None

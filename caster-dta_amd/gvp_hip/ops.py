@@ -119,9 +119,14 @@ class Csr:
 def build_csr(edge_index, num_nodes, counted=None):
     """`counted`: the counters buffer a cgvp_lba_pass_begin launch on this stream has already filled with the per-target
     edge counts of this very edge_index (csr_counters(...)): the build then skips its count launch."""
-    ei = _i64(edge_index, "edge_index")
-    if ei.dim() != 2 or ei.shape[0] != 2:
-        raise ValueError(f"edge_index must be [2, E], got {tuple(ei.shape)}")
+    try:
+        ei = _i64(edge_index, "edge_index")
+        if ei.dim() != 2 or ei.shape[0] != 2:
+            raise ValueError(f"edge_index must be [2, E], got {tuple(ei.shape)}")
+    except Exception:
+        if counted is not None:
+            counted.zero_()        # a pass_begin launch has already counted into them
+        raise
     E = int(ei.shape[1])
     dev = ei.device
     i32 = dict(dtype=torch.int32, device=dev)
@@ -134,6 +139,8 @@ def build_csr(edge_index, num_nodes, counted=None):
         work = counted if counted is not None else csr_counters(dev, num_nodes)
         rc = _lib.lib().cgvp_csr_from_coo(_ptr(ei), num_nodes, E, _ptr(rowptr), _ptr(eperm), _ptr(esrc),
                                           _ptr(edst), _ptr(work), 2 if counted is not None else 1, _ptr(ids), _stream())
+    if rc != 0:
+        work.zero_()               # the persistent counters must not stay half-used (the next build assumes zeros)
     _lib.check(rc, "cgvp_csr_from_coo")
     return Csr(rowptr, eperm, esrc, edst, num_nodes, E)
 
