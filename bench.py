@@ -371,7 +371,7 @@ def main():
     value = pairs_per_step * args.steps / dt
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # a reported baseline of the N = 1 line only
         cpu = cpu_baseline(args, wl, state, pb, mb, train)
 
     if rank == 0:
