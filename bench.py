@@ -204,6 +204,9 @@ def main():
     pre_idx = [i for i, p in enumerate(all_params) if id(p) in pre_ids]      # rank-local gradients under pair parallelism
     joint_bucket = torch.zeros(sum(all_params[i].numel() for i in pre_idx), device=dev)
     if args.scope == "joint" and collectives and (world > 1 or force_coll):
+        if rehearsal:
+            raise SystemExit("--scope joint gathers device tensors inside the model (all_gather_into_tensor): it needs RCCL, "
+                             "the gloo rehearsal (BENCH_REHEARSAL=1) covers --scope encoders only")
         model.enable_pair_parallel()
 
     def encoders_step():
