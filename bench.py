@@ -100,6 +100,26 @@ def kernel_source_digest():
     return h.hexdigest()[:16]
 
 
+def measured_copy_gbs(dev, nbytes=1 << 30, reps=5):
+    """Device-to-device copy bandwidth of this box (read + write bytes / time, best of `reps`), torch's copy kernel."""
+    try:
+        src = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty_like(src)
+        best = None
+        for _ in range(reps + 1):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            dst.copy_(src)
+            b.record()
+            b.synchronize()
+            t = a.elapsed_time(b) * 1e-3
+            best = t if best is None or t < best else best
+        del src, dst
+        return round(2 * nbytes / best / 1e9, 1)
+    except Exception:
+        return None
+
+
 def committed_traffic(workload, kernel, dtype="f32"):
     """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
     gfx950 correction applied: tools/pmc_summarise.py).  Only reported when the file was measured on the SAME
@@ -348,7 +368,8 @@ def main():
                 kname = {"conv_fwd": "conv_quad_kernel" if ops.VARIANT == "mfma" else "conv_fwd_kernel",
                          "conv_bwd": "conv_bwd_kernel"}[name]
                 hbm = dict(achieved=round(nbytes / avg / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                           frac=round(nbytes / avg / 1e9 / PEAK_HBM_GBS, 4), floor_us=round(nbytes / PEAK_HBM_GBS / 1e3, 2))
+                           frac=round(nbytes / avg / 1e9 / PEAK_HBM_GBS, 4), floor_us=round(nbytes / PEAK_HBM_GBS / 1e3, 2),
+                           device_copy_gbs=measured_copy_gbs(dev))      # the box's own copy bandwidth, for context
                 tiles = (E + 15) // 16                # 16 sorted edges per wave tile
                 n32, n16 = MFMA_PER_TILE[args.dtype][name]
                 issued = (n32 * 2048.0 + n16 * 8192.0) * tiles
