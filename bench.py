@@ -302,10 +302,13 @@ def main():
         out = step()
         torch.cuda.synchronize()
         graph = None
-        # --scope joint is launched eagerly: capturing the torch head (library GEMMs called from the autograd thread)
-        # into a HIP graph faulted on replay on this ROCm build (round 2, gpurun_out/r2_joint2.err); the encoders
-        # scope -- only this library's kernels -- replays from a graph
-        if not args.no_graph and args.scope == "encoders" and args.drug_stream == "side":
+        # both scopes replay from a HIP graph (earlier in round 2 a captured joint step faulted on replay; with the
+        # per-model weight-image handling and the in-graph image build it captures and replays cleanly).  torch.compile
+        # and the multi-rank joint scope (collectives inside the model) stay eager.
+        # (the eval-mode joint forward also stays eager: it materialises the padded attention weights, whose shape needs a
+        # host-side maximum)
+        eager_joint = args.scope == "joint" and (args.compile or not train or (collectives and (world > 1 or force_coll)))
+        if not args.no_graph and not eager_joint and args.drug_stream == "side":
             s = torch.cuda.Stream(device=dev)
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):

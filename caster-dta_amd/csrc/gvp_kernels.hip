@@ -54,6 +54,20 @@ inline int launch_status() {
 //   rank   : every position ranks its edge id inside its segment (deg reads, all independent) and writes
 //            eperm / esrc at the ranked position: segments end up ordered by edge id = the reference's index_add
 //            order, run-to-run reproducible; the same launch zeroes the counters again for the next call.
+// Zero fill by a kernel of our own.  hipMemsetAsync is NOT used anywhere in this library: captured into a HIP graph, a
+// memset of a size that is not a multiple of 256 B (the runtime splits it into body + tail fills) left the buffer
+// un-zeroed on the second and later replays on this ROCm build (round 2: the GINE input gradients turned into garbage from
+// replay 1 on; tests/test_hip_models.py::test_joint_training_step_replays_from_a_hip_graph).
+__global__ void zero_words_kernel(uint32_t* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+inline void zero_words(void* p, size_t words, hipStream_t s) {
+  if (words == 0) return;
+  size_t blocks = (words + 1023) / 1024;                     // 4 words per thread at most
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p), words);
+}
+
 __global__ void csr_count_kernel(const int64_t* __restrict__ ei, int64_t N, int64_t E,
                                  int32_t* __restrict__ cnt) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -590,9 +604,7 @@ int cgvp_csr_from_coo(const int64_t* edge_index, int64_t N, int64_t E, int32_t* 
   hipStream_t s = (hipStream_t)stream;
   const int64_t counters = (N + 1 + 63) / 64 * 64;
   if (work_is_zero == 0) {
-    // whole 256-B multiples: the runtime splits any other size into two fill launches (body + tail)
-    hipError_t err = hipMemsetAsync(work, 0, (size_t)counters * sizeof(int32_t), s);
-    if (err != hipSuccess) return (int)err;
+    zero_words(work, (size_t)counters, s);
   }
   int32_t* tmp = ids_scratch;
   const int B = 256;
@@ -880,8 +892,7 @@ int cgvp_conv_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float*
   if (int rc = quad::bwd_block_sizes(layout->nt_node, layout->nt_edge, &emb, &ce, &ct, &nd, &hd)) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (!g_src_zeroed) {
-    hipError_t err = hipMemsetAsync(g_src, 0, (size_t)N * ROW * sizeof(float), st);
-    if (err != hipSuccess) return (int)err;
+    zero_words(g_src, (size_t)N * ROW, st);
   }
   if (int rc = quad::conv_bwd(layout->nt_edge, image + o.conv0 + layer * o.layer_stride,
                               image + o.convT0 + layer * o.layerT_stride, h, e_emb, rowptr, esrc, edst, N, E,
@@ -1011,8 +1022,7 @@ int cgvp_gine_conv_bwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
   if (((uintptr_t)g_out & 15) || ((uintptr_t)mask & 15)) return CGVP_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (g_x) {
-    hipError_t err = hipMemsetAsync(g_x, 0, (size_t)N * (cin - num_ntypes) * sizeof(float), st);
-    if (err != hipSuccess) return (int)err;
+    zero_words(g_x, (size_t)N * (cin - num_ntypes), st);
   }
   int rows = 0, row_len = 0;
   if (int rc = quad::gine_bwd(cin, chid, cout, num_ntypes, num_etypes, edge_dim, x, ntypes, eattr, etypes, rowptr, eperm,

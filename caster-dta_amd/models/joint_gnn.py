@@ -247,6 +247,13 @@ class JointGNN(nn.Module):
         mbatch = molecule_graph_data.get("batch", None)
         residue = self.protein_gnn(**{k: v for k, v in protein_graph_data.items() if k != "ptr"})    # MI355X kernels
         atom = self.molecule_gnn(**{k: v for k, v in molecule_graph_data.items() if k != "ptr"})     # MI355X kernels
+        return self.head(residue, atom, protein_graph_data, molecule_graph_data)
+
+    def head(self, residue, atom, protein_graph_data={}, molecule_graph_data={}):
+        """Everything after the two encoders (joint_gnn.py:188-286): residue / atom stacks, cross attention, pooling,
+        affinity head.  `residue` [N, D], `atom` [Na, D] are the encoders' outputs; the dicts supply batch / ptr."""
+        pbatch = protein_graph_data.get("batch", None)
+        mbatch = molecule_graph_data.get("batch", None)
         hdt = self.output_layer.weight.dtype
         if residue.dtype != hdt and not torch.is_autocast_enabled():   # bf16-storage encoders feeding an fp32 head
             residue = residue.to(hdt)
