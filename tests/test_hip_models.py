@@ -245,3 +245,62 @@ def test_joint_training_step_replays_from_a_hip_graph(pretrained):
     captured = [g.clone() for g in out]
     assert not same(captured, eager)
     assert same(captured, step())                                    # eager on the updated weights
+
+
+def test_bench_style_two_stream_step_replays_correctly(pretrained):
+    """What bench.py times: protein forward + backward on the capture stream, drug forward + backward on a side stream,
+    CSR tables rebuilt inside the step, all of it one HIP graph.  Three replays in a row return the eager gradients of
+    both encoders (dropout off to compare)."""
+    from gvp_hip import ops
+    from models.joint_gnn import JointGNN
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))
+    kw["protein_gnn_kwargs"] = dict(kw["protein_gnn_kwargs"], dropout_rate=0.0)
+    kw["molecule_gnn_kwargs"] = dict(kw["molecule_gnn_kwargs"], dropout_rate=0.0)
+    model = JointGNN(protein_gnn_kwargs=kw["protein_gnn_kwargs"], molecule_gnn_kwargs=kw["molecule_gnn_kwargs"],
+                     **kw["joint_gnn_kwargs"])
+    model.load_state_dict(pretrained, strict=True)
+    model = model.to(DEV).train()
+    p, m = ds.pair_batch(8, 4, lengths=[40, 75, 33, 120, 64, 51, 90, 17])
+    pd, md = _to(ds.to_torch(p)), _to(ds.to_torch(m))
+    pp = [q for q in model.protein_gnn.parameters() if q.numel()]
+    mp = [q for q in model.molecule_gnn.parameters() if q.numel()]
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    g_res = torch.randn(p.num_nodes, 64, device=DEV, generator=gen)
+    g_atm = torch.randn(m.num_nodes, 64, device=DEV, generator=gen)
+    side = torch.cuda.Stream()
+
+    def step():
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        res = model.protein_gnn(**pd)
+        with torch.cuda.stream(side):
+            atm = model.molecule_gnn(**md)
+        gp = torch.autograd.grad([res], pp, [g_res])
+        with torch.cuda.stream(side):
+            gd = torch.autograd.grad([atm], mp, [g_atm])
+        main.wait_stream(side)
+        return gp + gd
+
+    old = ops.CSR_CACHE_ENABLED
+    ops.CSR_CACHE_ENABLED = False
+    try:
+        eager = [g.clone() for g in step()]
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            out = step()
+        scale = max(float(g.abs().max()) for g in eager)
+        for rep in range(3):
+            graph.replay()
+            torch.cuda.synchronize()
+            for a, b in zip(out, eager):
+                assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 2e-6 * scale, rep
+    finally:
+        ops.CSR_CACHE_ENABLED = old
