@@ -79,6 +79,11 @@ def parse():
     ap.add_argument("--compile", action="store_true",
                     help="--scope joint: run the model through torch.compile(dynamic=True), what train_model.py:422 does "
                          "(the encoders and the attention core stay single custom-op nodes)")
+    ap.add_argument("--autocast", default=None, choices=["bf16", "fp16"],
+                    help="--scope joint: run the step under torch.autocast as train_model.py:561 does (the torch head then "
+                         "computes in half precision; the encoder ops' autocast rule keeps them in fp32)")
+    ap.add_argument("--compile-graph", action="store_true",
+                    help="with --compile: additionally capture the compiled step into a HIP graph (experiment)")
     ap.add_argument("--gine-bwd-wgs", type=int, default=0,
                     help="diagnostic: workgroup cap of the GINE backward (0 = library default of 16)")
     ap.add_argument("--only", default=None, choices=["protein", "drug"],
@@ -267,7 +272,12 @@ def main():
         if collate:
             collate[1][0].collate(collate[1][1], attach_to=mdata["edge_index"])
             collate[0][0].collate(collate[0][1], attach_to=pdata["edge_index"])
-        pred, _ = jmodel(jp, jm)
+        if args.autocast:
+            with torch.autocast("cuda", dtype=torch.bfloat16 if args.autocast == "bf16" else torch.float16):
+                pred, _ = jmodel(jp, jm)
+            pred = pred.float()
+        else:
+            pred, _ = jmodel(jp, jm)
         if not train:
             return pred
         loss = torch.nn.functional.mse_loss(pred, target[:pred.shape[0]])
@@ -307,7 +317,8 @@ def main():
         # and the multi-rank joint scope (collectives inside the model) stay eager.
         # (the eval-mode joint forward also stays eager: it materialises the padded attention weights, whose shape needs a
         # host-side maximum)
-        eager_joint = args.scope == "joint" and (args.compile or not train or (collectives and (world > 1 or force_coll)))
+        eager_joint = args.scope == "joint" and ((args.compile and not args.compile_graph) or not train or
+                                                 (collectives and (world > 1 or force_coll)))
         if not args.no_graph and not eager_joint and args.drug_stream == "side":
             s = torch.cuda.Stream(device=dev)
             s.wait_stream(torch.cuda.current_stream())
@@ -422,7 +433,7 @@ def main():
                        "protein_edges_per_gpu": pb.num_edges, "atoms_per_gpu": mb.num_nodes,
                        "drug_edges_per_gpu": mb.num_edges, "encoder": f"CASTER-DTA({convs},{convs})", "pass": args.mode,
                        "activation_storage": "bf16 (protein encoder: bf16 activations in HBM and bf16 matrix-core operands, fp32 accumulate, fp32 weights and gradient buffers)" if args.dtype == "bf16" else "fp32",
-                       "scope": args.scope, "untimed_warmup_steps": max(args.warmup, MIN_WARMUP), "torch_compile": bool(args.compile and args.scope == "joint"), "train_mode": bool(dropout_on), "dropout_p": 0.2 if dropout_on else 0.0,
+                       "scope": args.scope, "untimed_warmup_steps": max(args.warmup, MIN_WARMUP), "torch_compile": bool(args.compile and args.scope == "joint"), "autocast": args.autocast if args.scope == "joint" else None, "train_mode": bool(dropout_on), "dropout_p": 0.2 if dropout_on else 0.0,
                        "csr_build_in_step": ("collate" if args.collate_csr else not args.cache_csr),
                        "hip_graph": graph is not None, "kernels": ops.VARIANT, "parallelism": par},
             "roofline": roof, "cpu_baseline": cpu,
