@@ -113,3 +113,49 @@ def test_bf16_training_mode_and_joint_head(pretrained):
     pred.square().mean().backward()
     bad = [n for n, q in model.named_parameters() if q.numel() and (q.grad is None or not torch.isfinite(q.grad).all())]
     assert not bad, bad
+
+
+def test_bf16_kernels_vs_reference_amp_fixture(protein_params, lba_sparse):
+    """g1 against the REFERENCE's own reduced-precision numerics: tests/golden/lba_amp_bf16.npz holds the unmodified
+    reference encoder on the lba_sparse batch under torch.autocast("cpu", dtype=torch.bfloat16) -- what
+    train_model.py:561 runs on a CPU device (output bf16, reference-autograd gradients).  The reference's autocast
+    rounds every nn.Linear output to bf16 and keeps everything between them in whatever dtype falls out; the kernels
+    round at different points (bf16 stage hand-offs, bf16 MFMA operands, fp32 accumulate / norms / gates), so the two
+    are not bit-comparable; what can be stated is that the kernels sit as close to the fp32 reference as the
+    reference's own AMP does, and within the sum of both distances of the AMP result.
+    Measured on MI355X (printed below): AMP-ref vs fp32-ref 7.3e-3 (fixture); kernels vs fp32-ref and kernels vs
+    AMP-ref are asserted at the bounds KERNEL_VS_F32 / KERNEL_VS_AMP."""
+    from conftest import load_npz
+    amp, g = load_npz("lba_amp_bf16.npz"), lba_sparse
+    assert str(amp["out_dtype"]) == "torch.bfloat16"
+    T = torch.from_numpy
+    ref32, ref_amp = T(g["out"]), T(amp["out"])
+    amp_vs_f32 = rel_err(ref_amp, ref32)
+    assert 1e-3 < amp_vs_f32 < 2e-2
+    model = _encoder(protein_params)
+    b = lambda a: T(a).to(DEV).to(torch.bfloat16)
+    xs, xv = b(g["x_s"]).requires_grad_(), b(g["x_v"]).requires_grad_()
+    out = model((xs, xv), T(g["edge_index"]).to(DEV), T(g["ntypes"]).to(DEV), T(g["etypes"]).to(DEV),
+                eattr=(b(g["e_s"]), b(g["e_v"])))
+    assert out.dtype == torch.bfloat16
+    k_vs_f32, k_vs_amp = rel_err(out.float(), ref32), rel_err(out.float(), ref_amp)
+    print(f"\nbf16 kernels vs fp32 reference {k_vs_f32:.2e}; reference AMP vs fp32 reference {amp_vs_f32:.2e}; "
+          f"kernels vs reference AMP {k_vs_amp:.2e}")
+    KERNEL_VS_F32, KERNEL_VS_AMP = 1.5e-2, 2.5e-2
+    assert k_vs_f32 < KERNEL_VS_F32 and k_vs_amp < KERNEL_VS_AMP
+    assert k_vs_f32 < 2.0 * amp_vs_f32                         # no further from the exact result than the reference's AMP (x2 slack)
+    # gradients of the fixture's upstream gradient r (same r as the AMP fixture): L2 distance per weight tensor,
+    # relative to the tensor's own norm, kernels vs fp32 reference next to reference-AMP vs fp32 reference
+    (out.float() * T(amp["r"]).to(DEV)).sum().backward()
+    rows = []
+    for name, p in model.gnn_model.named_parameters():
+        if not p.numel():
+            continue
+        g32, gamp, gk = T(g["g_" + name]).double(), T(amp["g_" + name]).double(), p.grad.cpu().double()
+        n = float(g32.norm()) + 1e-30
+        rows.append((name, float((gk - g32).norm()) / n, float((gamp - g32).norm()) / n))
+    worst_k, worst_a = max(r[1] for r in rows), max(r[2] for r in rows)
+    med_k, med_a = float(np.median([r[1] for r in rows])), float(np.median([r[2] for r in rows]))
+    print(f"weight gradients, L2 relative to the fp32 reference gradients: kernels median {med_k:.2e} worst {worst_k:.2e}; "
+          f"reference AMP median {med_a:.2e} worst {worst_a:.2e}")
+    assert med_k < 2.0 * med_a + 1e-2 and worst_k < 2.0 * worst_a + 5e-2

@@ -11,7 +11,8 @@ import pytest
 from conftest import GOLDEN
 
 REF = "/root/reference"
-FILES = ("lba_small.npz", "lba_sparse.npz", "gvp_units.npz", "pretrained_state.npz", "gvp_stacks.npz")
+FILES = ("lba_small.npz", "lba_sparse.npz", "gvp_units.npz", "pretrained_state.npz", "gvp_stacks.npz", "edge_feats.npz",
+         "lba_amp_bf16.npz")
 
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "models")), reason="reference tree not present")
