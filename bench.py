@@ -361,14 +361,22 @@ def main():
         # ---- roofline leg: per-launch duration of the dominant conv kernel, HIP events on its launch stream
         roof = None
         if rank == 0:
-            ops.KERNEL_EVENTS = []
+            # the library's opt-in diagnostics bracket every conv-layer launch of the whole-pass entry points with HIP
+            # events on the launch stream (cgvp_debug_kernel_timing; eager steps, outside the timed region above)
+            import ctypes
+            from gvp_hip import _lib
+            L_ = _lib.lib()
+            L_.cgvp_debug_kernel_timing(1)
             for _ in range(min(args.steps, 50)):
                 step()
             torch.cuda.synchronize()
+            L_.cgvp_debug_kernel_timing(0)
+            cap = 4096
+            ms, kinds = (ctypes.c_float * cap)(), (ctypes.c_int32 * cap)()
+            n_timed = min(L_.cgvp_debug_kernel_times(ms, kinds, cap), cap)
             by = {}
-            for (name, a, b) in ops.KERNEL_EVENTS:
-                by.setdefault(name, []).append(a.elapsed_time(b) * 1e-3)
-            ops.KERNEL_EVENTS = None
+            for i in range(n_timed):
+                by.setdefault("conv_bwd" if kinds[i] == 1 else "conv_fwd", []).append(ms[i] * 1e-3)
             N, E = pb.num_nodes, pb.num_edges
             # algorithmic bytes of one conv launch (bf16 storage: float terms halved, 16 B/edge of indices kept)
             conv_bytes = (224 * N + 156 * E) if args.dtype == "f32" else (112 * N + 86 * E)

@@ -6,7 +6,7 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="$HERE/../lib"
 TMP="$HERE/../lib/_obj"
 mkdir -p "$OUT" "$TMP"
-SRCS=(gvp_kernels gvp_quad_kernels gvp_quad_bwd_kernels gine_quad_kernels)
+SRCS=(gvp_kernels gvp_quad_kernels gvp_quad_bwd_kernels gine_quad_kernels pass_api)
 [ -f "$HERE/attn_kernels.hip" ] && SRCS+=(attn_kernels)
 [ -f "$HERE/feat_kernels.hip" ] && SRCS+=(feat_kernels)
 pids=()

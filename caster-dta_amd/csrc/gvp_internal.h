@@ -71,4 +71,9 @@ int gine_fwd(int cin, int chid, int cout, int nt, int net, int ed, const float* 
 int reduce_slab(const float* slab, int rows, int stride, int col0, int len, float* dst, hipStream_t st);
 int reduce_segments(const cgvp_segment* segs, int nsegs, float* grad_params, hipStream_t st, int overwrite = 0);
 int bwd_block_sizes(int nt_node, int nt_edge, int* emb, int* conv_edge, int* conv_total, int* node, int* head);
+// gvp_kernels.hip
+void zero_words(void* p, size_t words, hipStream_t s);     // the library's own zero fill (never hipMemsetAsync: see gvp_kernels.hip)
+int csr_build(const int64_t* edge_index, int64_t N, int64_t E, int32_t* rowptr, int32_t* eperm, int32_t* esrc,
+              int32_t* edst, int32_t* work, int work_is_zero, int32_t* ids_scratch, unsigned long long* rng_state,
+              unsigned long long* rng_out, hipStream_t stream);
 }  // namespace quad

@@ -62,15 +62,21 @@ __global__ void zero_words_kernel(uint32_t* __restrict__ p, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
 }
 inline void zero_words(void* p, size_t words, hipStream_t s) {
-  if (words == 0) return;
+  if (words == 0 || !p) return;
   size_t blocks = (words + 1023) / 1024;                     // 4 words per thread at most
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p), words);
 }
 
 __global__ void csr_count_kernel(const int64_t* __restrict__ ei, int64_t N, int64_t E,
-                                 int32_t* __restrict__ cnt) {
+                                 int32_t* __restrict__ cnt, unsigned long long* rng_state, unsigned long long* rng_out) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (rng_state && e == 0) {             // optional: advance the persistent dropout generator (cgvp_rng_next's work)
+    const unsigned long long off = rng_state[1] + 1;
+    rng_state[1] = off;
+    rng_out[0] = rng_state[0];
+    rng_out[1] = off;
+  }
   if (e >= E) return;
   int64_t s = ei[e], d = ei[E + e];
   if (s < 0 || s >= N || d < 0 || d >= N) return;   // malformed edge: dropped, never faults
@@ -597,11 +603,24 @@ const char* cgvp_build_info(void) { return "libcaster_gvp gfx950 (HIP, wave64), 
 int cgvp_csr_from_coo(const int64_t* edge_index, int64_t N, int64_t E, int32_t* rowptr,
                       int32_t* eperm, int32_t* esrc, int32_t* edst, int32_t* work, int32_t work_is_zero,
                       int32_t* ids_scratch, void* stream) {
+  return quad::csr_build(edge_index, N, E, rowptr, eperm, esrc, edst, work, work_is_zero, ids_scratch, nullptr, nullptr,
+                         (hipStream_t)stream);
+}
+}  // extern "C"
+
+namespace quad {
+void zero_words(void* p, size_t words, hipStream_t s) { ::zero_words(p, words, s); }
+
+// cgvp_csr_from_coo; rng_state / rng_out (both or neither): the count launch also advances the dropout generator
+// (cgvp_rng_next's work) -- with E == 0 or work_is_zero == 2 there is no count launch and a 1-thread launch does it.
+int csr_build(const int64_t* edge_index, int64_t N, int64_t E, int32_t* rowptr, int32_t* eperm, int32_t* esrc,
+              int32_t* edst, int32_t* work, int work_is_zero, int32_t* ids_scratch, unsigned long long* rng_state,
+              unsigned long long* rng_out, hipStream_t stream) {
   if (N < 0 || E < 0 || !rowptr || !work || (E > 0 && (!edge_index || !eperm || !esrc || !edst || !ids_scratch)))
     return CGVP_ERR_BAD_ARG;
   if (N >= (int64_t)1 << 31 || E >= (int64_t)1 << 31) return CGVP_ERR_BAD_ARG;
   if ((uintptr_t)work & 15) return CGVP_ERR_BAD_ARG;
-  hipStream_t s = (hipStream_t)stream;
+  hipStream_t s = stream;
   const int64_t counters = (N + 1 + 63) / 64 * 64;
   if (work_is_zero == 0) {
     zero_words(work, (size_t)counters, s);
@@ -609,7 +628,9 @@ int cgvp_csr_from_coo(const int64_t* edge_index, int64_t N, int64_t E, int32_t* 
   int32_t* tmp = ids_scratch;
   const int B = 256;
   if (E > 0 && work_is_zero != 2)     // 2: cgvp_lba_pass_begin already counted into `work`
-    hipLaunchKernelGGL(csr_count_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, work);
+    hipLaunchKernelGGL(csr_count_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, work, rng_state, rng_out);
+  else if (rng_state)
+    hipLaunchKernelGGL(rng_next_kernel, dim3(1), dim3(1), 0, s, rng_state, rng_out);
   const int64_t tile = N < SCAN_LDS ? (N + 3) / 4 * 4 : SCAN_LDS;
   hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), (size_t)(tile + 1024 + 32) * sizeof(int32_t), s, work, N, rowptr);
   if (E > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, work, tmp, edst);
@@ -618,6 +639,9 @@ int cgvp_csr_from_coo(const int64_t* edge_index, int64_t N, int64_t E, int32_t* 
                      edst, eperm, esrc, work);
   return launch_status();
 }
+}  // namespace quad
+
+extern "C" {
 
 int cgvp_csr_collate(const int32_t* st_rowptr, const int32_t* st_eperm, const int32_t* st_esrc,
                      const int32_t* st_edst, const int64_t* st_node_off, const int64_t* st_edge_off,

@@ -871,6 +871,19 @@ __global__ __launch_bounds__(RED_COLS * RED_RG) void reduce_segments_kernel(SegT
   }
 }
 
+// the same for segments of a handful of rows (the GINE backward on <= 32 workgroups): one thread per column, small
+// workgroups that fit beside the protein backward's CU-filling kernels
+__global__ __launch_bounds__(256) void reduce_segments_rows_kernel(SegTable t, float* __restrict__ grad, int overwrite) {
+  const cgvp_segment sg = t.s[blockIdx.y];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= sg.len) return;
+  const float* col = sg.slab + sg.col0 + j;
+  float s = 0.f;
+  for (int r = 0; r < sg.rows; ++r) s += col[(size_t)r * sg.stride];
+  if (overwrite) grad[sg.dst + j] = s;
+  else atomicAdd(grad + sg.dst + j, s);
+}
+
 inline int grid_for(int64_t tiles) {          // workgroups = slab rows; tiles go round-robin over them
   return (int)(tiles < 1 ? 1 : (tiles > BW_MAX_GRID ? BW_MAX_GRID : tiles));
 }
@@ -894,7 +907,16 @@ int reduce_segments(const cgvp_segment* segs, int nsegs, float* grad_params, hip
   if (nsegs <= 0) return 0;
   SegTable t;
   int maxlen = 0;
-  for (int i = 0; i < nsegs; ++i) { t.s[i] = segs[i]; maxlen = segs[i].len > maxlen ? segs[i].len : maxlen; }
+  int maxrows = 0;
+  for (int i = 0; i < nsegs; ++i) {
+    t.s[i] = segs[i];
+    maxlen = segs[i].len > maxlen ? segs[i].len : maxlen;
+    maxrows = segs[i].rows > maxrows ? segs[i].rows : maxrows;
+  }
+  if (maxrows <= 32) {
+    hipLaunchKernelGGL(reduce_segments_rows_kernel, dim3((maxlen + 255) / 256, nsegs), dim3(256), 0, st, t, grad_params, overwrite);
+    return 0;
+  }
   hipLaunchKernelGGL(reduce_segments_kernel, dim3((maxlen + RED_COLS - 1) / RED_COLS, nsegs), dim3(RED_COLS * RED_RG), 0,
                      st, t, grad_params, overwrite);
   return 0;

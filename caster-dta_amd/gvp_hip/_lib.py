@@ -15,11 +15,11 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CGVP_LIB_PATH: A/B builds of the same ABI (diagnostics); the default is the in-tree library
 LIB_PATH = os.environ.get("CGVP_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libcaster_gvp.so")
-ABI_VERSION = 23
+ABI_VERSION = 24
 # sha256 of include/caster_gvp.h with comments, blank space and the CGVP_ABI_VERSION line removed, as
 # `abi_header_digest()` computes it.  tests/test_abi.py fails when the header's declarations change
 # without CGVP_ABI_VERSION, ABI_VERSION and this digest being updated together.
-ABI_HEADER_SHA256 = "de7cd26d51aafae247878355a436e9d4f9b32aba755ae6364c754b22a9bfac17"
+ABI_HEADER_SHA256 = "446e3bdcdbfc4724f8df3735625f425cb0648e0b48e636c306c72d8b839ac316"
 
 
 class HipLibraryError(RuntimeError):
@@ -58,6 +58,36 @@ class AttnProblem(C.Structure):
 
 class GineW(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("eps", "we", "be", "w0", "b0", "w1", "b1")]
+
+
+class LbaBatch(C.Structure):
+    """cgvp_lba_batch: one batched protein graph as the whole-pass entry points take it."""
+    _fields_ = [("num_nodes", C.c_int64), ("num_edges", C.c_int64)] + [(n, C.c_void_p) for n in (
+        "x_s", "x_v", "ntypes", "e_s", "e_v", "etypes", "edge_index", "rowptr", "eperm", "esrc", "edst")]
+
+
+class LbaFwdWs(C.Structure):
+    """cgvp_lba_fwd_ws: byte offsets of the sub-buffers of a protein forward workspace."""
+    _fields_ = [(n, C.c_int64) for n in ("seed", "image", "state", "e_emb", "rowptr", "eperm", "esrc", "edst",
+                                         "ids_scratch", "total", "state_rows", "node_stride")]
+
+
+GINE_MAX_LAYERS = 8      # CGVP_GINE_MAX_LAYERS
+
+
+class GineCfg(C.Structure):
+    _fields_ = [("num_layers", C.c_int32), ("widths", C.c_int32 * (GINE_MAX_LAYERS + 1)), ("num_ntypes", C.c_int32),
+                ("num_etypes", C.c_int32), ("edge_dim", C.c_int32), ("act_slope", C.c_float)]
+
+
+class GineBatch(C.Structure):
+    _fields_ = [("num_nodes", C.c_int64), ("num_edges", C.c_int64)] + [(n, C.c_void_p) for n in (
+        "x", "ntypes", "eattr", "etypes", "edge_index", "rowptr", "eperm", "esrc", "edst")]
+
+
+class GineFwdWs(C.Structure):
+    _fields_ = [("seed", C.c_int64), ("hidden", C.c_int64 * GINE_MAX_LAYERS)] + [(n, C.c_int64) for n in (
+        "rowptr", "eperm", "esrc", "edst", "ids_scratch", "total")]
 
 
 _P = C.c_void_p
@@ -100,6 +130,21 @@ _SIGNATURES = {
     "cgvp_attn_fwd": (C.c_int, [C.POINTER(AttnProblem), _I32, _I64, _I32, C.c_float, _P]),
     "cgvp_attn_bwd": (C.c_int, [C.POINTER(AttnProblem), _I32, _I64, _I32, C.c_float, _P]),
     "cgvp_attn_weights": (C.c_int, [C.POINTER(AttnProblem), _I32, _I64, _I32, C.c_float, _P]),
+    "cgvp_lba_fwd_workspace": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _I64, _I64, _I32, C.POINTER(LbaFwdWs)]),
+    "cgvp_lba_forward_pass": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, C.POINTER(LbaBatch), _I32, C.c_float, _P, _P,
+                                        _P, _P, _I32, _I32, _P, _P]),
+    "cgvp_lba_forward_plan": (C.c_int, [_I64, _I64, _I32, _I32, _I32, C.POINTER(_I32)]),
+    "cgvp_lba_bwd_workspace_bytes": (C.c_int64, [C.POINTER(Dims), C.POINTER(Layout), _I64, _I64]),
+    "cgvp_lba_backward_pass": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), C.POINTER(LbaBatch), _I32, C.c_float, _P, _P,
+                                         _P, _P, _P, _P, _P, _P]),
+    "cgvp_gine_fwd_workspace": (C.c_int, [C.POINTER(GineCfg), _I64, _I64, _I32, C.POINTER(GineFwdWs)]),
+    "cgvp_gine_forward_pass": (C.c_int, [C.POINTER(GineCfg), C.POINTER(GineW), C.POINTER(GineBatch), C.c_float, _P, _P, _P,
+                                         _P, _I32, _I32, _P, _P]),
+    "cgvp_gine_bwd_workspace_bytes": (C.c_int64, [C.POINTER(GineCfg), _I64, _I64]),
+    "cgvp_gine_backward_pass": (C.c_int, [C.POINTER(GineCfg), C.POINTER(GineW), C.POINTER(GineBatch), C.c_float, _P, _P,
+                                          _P, _P, _P, _P, _I32, _P]),
+    "cgvp_debug_kernel_timing": (C.c_int, [_I32]),
+    "cgvp_debug_kernel_times": (C.c_int, [_P, _P, _I32]),
     "cgvp_gine_bwd_workspace_floats": (C.c_int64, []),
     "cgvp_gine_conv_bwd": (C.c_int, [_P, _P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32,
                                      C.POINTER(GineW), C.c_float, _P, C.POINTER(Rng), _P, _P, _P, _P, _I32, _P]),

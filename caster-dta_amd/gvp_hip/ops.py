@@ -150,19 +150,23 @@ def csr_counters(dev, num_nodes):
     return _zeroed_counters(dev, (num_nodes + 1 + 63) // 64 * 64)
 
 
-_COUNTERS = {}      # (device index, stream handle) -> int32 counters, zero between calls (cgvp_csr_from_coo keeps them so)
+_COUNTERS = {}      # (device index, stream handle) -> [int32 counters, newest last]; zero between calls (every build leaves them so)
 
 
 def _zeroed_counters(dev, n):
     """The CSR build's per-target counters: one persistent buffer per (device, stream), zero-filled ONCE when it is
     created or grown -- every build leaves the counters it used zeroed again, so a step needs no fill launch.  Keyed by
-    stream because builds on different streams (protein / drug) run concurrently."""
+    stream because builds on different streams (protein / drug) run concurrently.
+    LIFETIME: a buffer handed out once is never freed -- a HIP graph captured with it keeps counting into it on every
+    replay, whatever the eager code does afterwards.  Growing (a larger batch arrives) appends a new generation and
+    keeps the old ones alive; sizes double, so the dead weight is bounded by the live size."""
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    buf = _COUNTERS.get(key)
-    if buf is None or buf.numel() < n:
-        buf = torch.zeros(max(n * 2, 4096), dtype=torch.int32, device=dev)
-        _COUNTERS[key] = buf
-    return buf
+    gens = _COUNTERS.setdefault(key, [])
+    if not gens or gens[-1].numel() < n:
+        # (created inside a stream capture -- no warm-up ran on this stream -- the fill is recorded into the graph and
+        # re-zeroes an already-zero buffer on every replay: harmless)
+        gens.append(torch.zeros(max(n * 2, 4096), dtype=torch.int32, device=dev))
+    return gens[-1]
 
 
 class CsrStore:

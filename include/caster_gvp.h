@@ -14,7 +14,7 @@
  *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream);
  *     launches are asynchronous, no call synchronises;
  *   - return value: 0 = launched, >0 = hipError_t from the launch,
- *     <0 = CGVP_ERR_* argument error.  Re-entrant, no global state.
+ *     <0 = CGVP_ERR_* argument error.  Re-entrant, no global state (except the opt-in DIAGNOSTICS at the end).
  *   - node state between stages is the merged row [s(16) | v(4x3)] = 28 floats
  *     per residue, exactly gvp_layers.py:101 `_merge` of the (16,4) hidden tuple.
  */
@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 23
+#define CGVP_ABI_VERSION 24
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
@@ -424,6 +424,110 @@ int cgvp_attn_bwd(const cgvp_attn_problem* problems, int32_t num_problems, int64
  * of cgvp_attn_fwd.  Inference only. */
 int cgvp_attn_weights(const cgvp_attn_problem* problems, int32_t num_problems, int64_t num_pairs, int32_t heads,
                       float scale, void* stream);
+
+/* ------------------------------------------------------------ WHOLE-PASS ENTRY POINTS (the production path)
+ * ONE call per encoder pass: each of the four functions below issues the complete launch sequence of
+ * VectorProteinGNN_LBAModel.forward (protein_gnn.py:361-388) / its autograd, resp. HomoMoleculeGNN_GINE.forward
+ * (molecule_gnn.py:254-268) / its autograd, on `stream`.  This is how the training loop of the reference
+ * (train_model.py:548-587: a NEW batch -- new N, E, edge_index -- every step) drives the library: per step 4 host
+ * calls and 4 caller-allocated buffers instead of ~25 launches' worth of argument marshalling and ~30 small tensors.
+ * Everything a pass produces for its backward lives in ONE caller-allocated forward workspace whose sub-buffer byte
+ * offsets the *_fwd_workspace functions report (all offsets are multiples of 256); the backward passes read it and
+ * use a second scratch workspace of *_bwd_workspace_bytes.  The library keeps no state and allocates nothing: both
+ * workspaces, the dropout generator state (`rng_state`, 2 x uint64, persistent across passes) and the CSR counters
+ * (`csr_counters`, int32 [>= N + 1 rounded up to 64], zero on entry, left zero on exit, persistent; one per stream) are
+ * the caller's, so a caller that captures a step into a HIP graph decides their lifetime (hand out graph-owned or
+ * never-freed buffers).  The fine-grained entry points above remain (tests of single stages, A/B timing). */
+typedef struct {
+  int64_t num_nodes, num_edges;
+  const float* x_s;  const float* x_v;  const int64_t* ntypes;     /* [N][17], [N][3][3], [N] (NULL when num_ntypes == 0)   */
+  const float* e_s;  const float* e_v;  const int64_t* etypes;     /* [E or table rows][32], [..][1][3], [..]                */
+  const int64_t* edge_index;   /* [2][E] as PyG delivers it; may be NULL when the four tables below are given               */
+  const int32_t* rowptr; const int32_t* eperm; const int32_t* esrc; const int32_t* edst;  /* prebuilt CSR (cgvp_csr_collate) or all NULL */
+} cgvp_lba_batch;
+
+typedef struct {              /* byte offsets inside the forward workspace                                                   */
+  int64_t seed;               /* uint64[2] {seed, offset} of this pass's dropout (written by its first kernel)               */
+  int64_t image;              /* fragment image of the weights the pass ran with (float[cgvp_lba_image_floats])              */
+  int64_t state;              /* [state_rows][node_stride][28] activations: h_0..h_{L-1}, dh_0..dh_{L-1}, head input          */
+  int64_t e_emb;              /* [E + 1][CGVP_EDGE_ROW] edge embedding store, sorted-edge order                               */
+  int64_t rowptr, eperm, esrc, edst, ids_scratch;   /* CSR tables int32 [N+1], [E], [E], [E], [E] (built unless the batch brings them) */
+  int64_t total;              /* bytes to allocate                                                                            */
+  int64_t state_rows, node_stride;
+} cgvp_lba_fwd_ws;
+/* save_state != 0: training pass (everything the backward needs is kept); 0: inference (ping-pong rows only). */
+int cgvp_lba_fwd_workspace(const cgvp_dims* dims, const cgvp_layout* layout, int64_t num_nodes, int64_t num_edges,
+                           int32_t save_state, cgvp_lba_fwd_ws* out);
+
+/* flags for cgvp_lba_forward_pass */
+#define CGVP_PASS_UNFUSED 1   /* never use the one-launch-per-layer kernel (A/B timing; the default picks it for E <= 4 N) */
+/* dropout: dropout_p > 0 selects training-mode dropout (gvp_layers.py:187-219): from explicit `masks` ([2 L][N][20],
+ * test hook) when given, else drawn in-kernel from `rng_state` (required then), which the pass advances.
+ * out: [N][64] residue embeddings (element type = dims->storage). */
+int cgvp_lba_forward_pass(const cgvp_dims* dims, const cgvp_layout* layout, const float* params,
+                          const cgvp_lba_batch* batch, int32_t aggr_mean, float dropout_p, uint64_t* rng_state,
+                          const float* masks, int32_t* csr_counters, void* workspace, int32_t save_state,
+                          int32_t flags, float* out, void* stream);
+
+/* The launch plan cgvp_lba_forward_pass follows for these sizes (host-only, no GPU work): returns the number of
+ * kernel launches of the pass and sets *fused_layers to 1 when every GVPConvLayer is ONE launch (conv + node update
+ * (+ head); chosen for E <= 4 N unless CGVP_PASS_UNFUSED), 0 when it is two. */
+int cgvp_lba_forward_plan(int64_t num_nodes, int64_t num_edges, int32_t num_convs, int32_t prebuilt_csr, int32_t flags,
+                          int32_t* fused_layers);
+
+int64_t cgvp_lba_bwd_workspace_bytes(const cgvp_dims* dims, const cgvp_layout* layout, int64_t num_nodes,
+                                     int64_t num_edges);
+/* Autograd of cgvp_lba_forward_pass(save_state = 1): g_out [N][64] fp32 -> grad_params (arena layout, every element
+ * STORED: no zero fill needed) and, when both are non-NULL, g_x_s [N][17] / g_x_v [N][3][3].  `batch`, aggr_mean,
+ * dropout_p and masks must be the forward's; `fwd_workspace` is the buffer the forward filled (read only). */
+int cgvp_lba_backward_pass(const cgvp_dims* dims, const cgvp_layout* layout, const cgvp_lba_batch* batch,
+                           int32_t aggr_mean, float dropout_p, const float* masks, const void* fwd_workspace,
+                           const float* g_out, void* bwd_workspace, float* grad_params, float* g_x_s, float* g_x_v,
+                           void* stream);
+
+#define CGVP_GINE_MAX_LAYERS 8
+typedef struct {
+  int32_t num_layers;                          /* L = num_convs                                                       */
+  int32_t widths[CGVP_GINE_MAX_LAYERS + 1];    /* channel widths: widths[0] = in + num_ntypes (52), ..., widths[L] = out */
+  int32_t num_ntypes, num_etypes, edge_dim;    /* 11, 5, 9                                                             */
+  float act_slope;                             /* LeakyReLU slope (0 = ReLU, 1 = identity)                              */
+} cgvp_gine_cfg;
+typedef struct {
+  int64_t num_nodes, num_edges;
+  const float* x; const int64_t* ntypes;       /* [N][widths[0] - num_ntypes], [N]                                     */
+  const float* eattr; const int64_t* etypes;   /* [E][edge_dim], [E]                                                   */
+  const int64_t* edge_index;
+  const int32_t* rowptr; const int32_t* eperm; const int32_t* esrc; const int32_t* edst;
+} cgvp_gine_batch;
+typedef struct {
+  int64_t seed;                                /* uint64[2]                                                            */
+  int64_t hidden[CGVP_GINE_MAX_LAYERS];        /* hidden[l]: output of layer l, l < L - 1 ([N][widths[l + 1]] fp32)     */
+  int64_t rowptr, eperm, esrc, edst, ids_scratch;
+  int64_t total;
+} cgvp_gine_fwd_ws;
+int cgvp_gine_fwd_workspace(const cgvp_gine_cfg* cfg, int64_t num_nodes, int64_t num_edges, int32_t save_state,
+                            cgvp_gine_fwd_ws* out);
+/* w: HOST array of num_layers cgvp_gine_w; masks: NULL or HOST array of num_layers - 1 device pointers ([N][widths[l+1]],
+ * explicit inter-layer dropout factors, test hook); otherwise dropout_p > 0 draws in-kernel from rng_state. */
+int cgvp_gine_forward_pass(const cgvp_gine_cfg* cfg, const cgvp_gine_w* w, const cgvp_gine_batch* batch,
+                           float dropout_p, uint64_t* rng_state, const float* const* masks, int32_t* csr_counters,
+                           void* workspace, int32_t save_state, int32_t variant, float* out, void* stream);
+int64_t cgvp_gine_bwd_workspace_bytes(const cgvp_gine_cfg* cfg, int64_t num_nodes, int64_t num_edges);
+/* g_out [N][widths[L]] -> grad_flat: the layers' weight gradients back to back, each in state_dict order
+ * (eps | nn.lins.0.weight | nn.lins.0.bias | nn.lins.1.weight | nn.lins.1.bias | lin.weight | lin.bias), every element
+ * STORED; g_x [N][widths[0] - num_ntypes] or NULL. */
+int cgvp_gine_backward_pass(const cgvp_gine_cfg* cfg, const cgvp_gine_w* w, const cgvp_gine_batch* batch,
+                            float dropout_p, const float* const* masks, const void* fwd_workspace, const float* g_out,
+                            void* bwd_workspace, float* grad_flat, float* g_x, int32_t max_workgroups, void* stream);
+
+/* ------------------------------------------------------------ DIAGNOSTICS
+ * The ONE piece of process-global state in the library, off by default, not thread-safe; bench.py's roofline leg uses
+ * it to time the dominant kernel in situ: while enabled, the whole-pass entry points bracket every conv-layer launch
+ * (kind 0 = forward conv layer, 1 = conv backward) with a pair of HIP events on the pass's stream.
+ * cgvp_debug_kernel_times synchronises the pairs recorded so far, writes their elapsed milliseconds and kinds (up to
+ * `capacity`), forgets them and returns how many there were.  Not for use during stream capture. */
+int cgvp_debug_kernel_timing(int32_t enable);
+int cgvp_debug_kernel_times(float* ms, int32_t* kinds, int32_t capacity);
 
 /* Library self-description (checked by the loader and the CPU test-suite). */
 int cgvp_abi_version(void);

@@ -123,8 +123,9 @@ def test_bf16_kernels_vs_reference_amp_fixture(protein_params, lba_sparse):
     round at different points (bf16 stage hand-offs, bf16 MFMA operands, fp32 accumulate / norms / gates), so the two
     are not bit-comparable; what can be stated is that the kernels sit as close to the fp32 reference as the
     reference's own AMP does, and within the sum of both distances of the AMP result.
-    Measured on MI355X (printed below): AMP-ref vs fp32-ref 7.3e-3 (fixture); kernels vs fp32-ref and kernels vs
-    AMP-ref are asserted at the bounds KERNEL_VS_F32 / KERNEL_VS_AMP."""
+    Measured on MI355X (printed below): AMP-ref vs fp32-ref 7.3e-3 (fixture); kernels vs fp32-ref 5.5e-3; kernels vs
+    AMP-ref 7.4e-3 -- asserted at the bounds KERNEL_VS_F32 / KERNEL_VS_AMP; weight gradients (L2 per tensor, relative
+    to the fp32 reference gradient): kernels median 6.1e-2, reference AMP median 5.0e-2."""
     from conftest import load_npz
     amp, g = load_npz("lba_amp_bf16.npz"), lba_sparse
     assert str(amp["out_dtype"]) == "torch.bfloat16"
@@ -148,11 +149,12 @@ def test_bf16_kernels_vs_reference_amp_fixture(protein_params, lba_sparse):
     # relative to the tensor's own norm, kernels vs fp32 reference next to reference-AMP vs fp32 reference
     (out.float() * T(amp["r"]).to(DEV)).sum().backward()
     rows = []
+    scale = max(float(np.abs(v).max()) for k, v in g.items() if k.startswith("g_"))
     for name, p in model.gnn_model.named_parameters():
         if not p.numel():
             continue
         g32, gamp, gk = T(g["g_" + name]).double(), T(amp["g_" + name]).double(), p.grad.cpu().double()
-        n = float(g32.norm()) + 1e-30
+        n = float(g32.norm()) + 1e-3 * scale * p.numel() ** 0.5          # floor: analytically-zero gradients are rounding noise
         rows.append((name, float((gk - g32).norm()) / n, float((gamp - g32).norm()) / n))
     worst_k, worst_a = max(r[1] for r in rows), max(r[2] for r in rows)
     med_k, med_a = float(np.median([r[1] for r in rows])), float(np.median([r[2] for r in rows]))

@@ -41,9 +41,12 @@ def _molecule(state, train=False):
 
 # ------------------------------------------------------------------------------------------------ CPU
 def test_ops_are_registered_with_schemas():
-    for name in ("lba_encoder", "lba_encoder_backward", "gine_encoder", "gine_encoder_backward"):
+    for name in ("lba_encoder", "gine_encoder", "gine_encoder_backward"):
         op = getattr(torch.ops.caster_gvp, name).default
         assert "Tensor[] params" in str(op._schema)
+    # the protein backward needs no parameters: the fragment image of the weights the forward ran with is in `ws`
+    assert "Tensor ws" in str(torch.ops.caster_gvp.lba_encoder_backward.default._schema)
+    assert "Tensor[] csr" in str(torch.ops.caster_gvp.lba_encoder.default._schema)
 
 
 def test_fake_kernels_propagate_shapes_without_a_gpu(protein_params, molecule_params):
@@ -55,26 +58,61 @@ def test_fake_kernels_propagate_shapes_without_a_gpu(protein_params, molecule_pa
         params = [f(*protein_params[k].shape) for k in lba_param_keys(2) if protein_params[k].numel()]
         N, E = 77, 250
         args = (params, f(N, 17), f(N, 3, 3), f(N, dt=torch.int64), f(E, 32), f(E, 1, 3), f(E, dt=torch.int64),
-                f(2, E, dt=torch.int64), CFG)
-        out, state, masks, seed, e_emb = torch.ops.caster_gvp.lba_encoder(*args, 0.2, True)
-        assert out.shape == (N, 64) and state.shape == (5, N + (N & 1), 28) and masks.numel() == 0      # masks live in the kernels
-        assert seed.shape == (2,) and seed.dtype == torch.int64 and e_emb.shape == (E + 1, 36)
-        out, state, masks, seed, e_emb = torch.ops.caster_gvp.lba_encoder(*args, 0.0, False)
-        assert out.shape == (N, 64) and state.numel() == 0 and masks.numel() == 0 and seed.numel() == 0 and e_emb.numel() == 0
-        g, gxs, gxv = torch.ops.caster_gvp.lba_encoder_backward(f(N, 64), *args[:8], f(5, N + (N & 1), 28), f(0),
-                                                                f(2, dt=torch.int64), f(E + 1, 36), CFG, 0.2, True)
+                f(2, E, dt=torch.int64), [], CFG)
+        out, ws, masks = torch.ops.caster_gvp.lba_encoder(*args, 0.2, True)
+        assert out.shape == (N, 64) and masks.numel() == 0                 # masks live in the kernels
+        assert ws.dtype == torch.uint8 and ws.shape == (_c_lba_ws_bytes(N, E, True),)
+        out, ws0, masks = torch.ops.caster_gvp.lba_encoder(*args, 0.0, False)
+        assert out.shape == (N, 64) and ws0.numel() == 0 and masks.numel() == 0
+        g, gxs, gxv = torch.ops.caster_gvp.lba_encoder_backward(f(N, 64), *args[1:9], ws, f(0), CFG, 0.2, True)
         assert g.shape == (15117,) and gxs.shape == (N, 17) and gxv.shape == (N, 3, 3)
         keys = ("eps", "nn.lins.0.weight", "nn.lins.0.bias", "nn.lins.1.weight", "nn.lins.1.bias", "lin.weight", "lin.bias")
         mparams = [f(*molecule_params[f"conv_list.{l}.{k}"].shape) for l in range(2) for k in keys]
         Na, Ea = 40, 130
-        margs = (mparams, f(Na, 41), f(Na, dt=torch.int64), f(Ea, 9), f(Ea, dt=torch.int64), f(2, Ea, dt=torch.int64),
+        margs = (mparams, f(Na, 41), f(Na, dt=torch.int64), f(Ea, 9), f(Ea, dt=torch.int64), f(2, Ea, dt=torch.int64), [],
                  [52, 16, 64], 11, 5, 0.01)
-        out, hidden, mk, mseed = torch.ops.caster_gvp.gine_encoder(*margs, 0.2, True)
-        assert out.shape == (Na, 64) and [tuple(h.shape) for h in hidden] == [(Na, 16)] and mk[0].numel() == 0
-        assert mseed.shape == (2,)
-        gflat, gx = torch.ops.caster_gvp.gine_encoder_backward(f(Na, 64), *margs[:6], hidden, mk, mseed, [52, 16, 64],
+        out, mws, mk = torch.ops.caster_gvp.gine_encoder(*margs, 0.2, True)
+        assert out.shape == (Na, 64) and mk[0].numel() == 0 and mws.shape == (_c_gine_ws_bytes(Na, Ea, [52, 16, 64], True),)
+        gflat, gx = torch.ops.caster_gvp.gine_encoder_backward(f(Na, 64), *margs[:7], mws, mk, [52, 16, 64],
                                                                11, 5, 0.01, 0.2, True, 0)
         assert gflat.shape == (7390,) and gx.shape == (Na, 41)
+
+
+def _c_lba_ws_bytes(N, E, save, storage=0, nc=2):
+    """cgvp_lba_fwd_workspace (host-only C function, no GPU)."""
+    import ctypes as C
+    from gvp_hip import _lib, ops
+    dims = ops.make_dims(storage=storage)
+    layout = ops.lba_layout(dims, 20, 1, nc)
+    w = _lib.LbaFwdWs()
+    assert _lib.lib().cgvp_lba_fwd_workspace(C.byref(dims), C.byref(layout), N, E, 1 if save else 0, C.byref(w)) == 0
+    return int(w.total)
+
+
+def _c_gine_ws_bytes(N, E, widths, save):
+    import ctypes as C
+    from gvp_hip import _lib
+    cfg = autograd_ops._gine_cfg(widths, 11, 5, 9, 0.01)
+    w = _lib.GineFwdWs()
+    assert _lib.lib().cgvp_gine_fwd_workspace(C.byref(cfg), N, E, 1 if save else 0, C.byref(w)) == 0
+    return int(w.total)
+
+
+def test_python_workspace_formulas_match_the_library():
+    """The fake kernels size `ws` with Python mirrors of cgvp_*_fwd_workspace: they must agree for every N, E, depth,
+    storage type and mode, or compiled graphs would allocate the wrong workspace."""
+    from gvp_hip import ops
+    for N, E in ((0, 0), (1, 0), (5, 3), (77, 250), (300, 898), (19200, 57484), (1001, 20020)):
+        for nc in (1, 2, 4):
+            for storage, es in ((0, 4), (1, 2)):
+                for save in (True, False):
+                    dims = ops.make_dims(storage=storage)
+                    sdt = torch.bfloat16 if storage else torch.float32
+                    img = autograd_ops._dims_layout([17, 3, 32, 1, 16, 4, 32, 1, 64, 20, 1, nc, 0], sdt)[2]
+                    assert autograd_ops.lba_fwd_ws_bytes(N, E, nc, img, es, save) == _c_lba_ws_bytes(N, E, save, storage, nc)
+        for widths in ([52, 64], [52, 16, 64], [52, 16, 16, 16, 64]):
+            for save in (True, False):
+                assert autograd_ops.gine_fwd_ws_bytes(N, E, widths, save) == _c_gine_ws_bytes(N, E, widths, save)
 
 
 # ------------------------------------------------------------------------------------------------ GPU
@@ -86,11 +124,11 @@ def test_opcheck(protein_params, molecule_params):
     pd, md = _to(ds.to_torch(p)), _to(ds.to_torch(m))
     params = prot.gnn_model._arena.params
     xs = pd["x"][0].clone().requires_grad_()
-    args = (params, xs, pd["x"][1], pd["ntypes"], pd["eattr"][0], pd["eattr"][1], pd["etypes"], pd["edge_index"],
+    args = (params, xs, pd["x"][1], pd["ntypes"], pd["eattr"][0], pd["eattr"][1], pd["etypes"], pd["edge_index"], [],
             CFG, 0.0, True)
     torch.library.opcheck(torch.ops.caster_gvp.lba_encoder.default, args)
     mparams = [mol.gnn_model.conv_list[l].kernel_weights()[k] for l in range(2) for k in autograd_ops._GINE_KEYS]
-    margs = (mparams, md["x"].clone().requires_grad_(), md["ntypes"], md["eattr"], md["etypes"], md["edge_index"],
+    margs = (mparams, md["x"].clone().requires_grad_(), md["ntypes"], md["eattr"], md["etypes"], md["edge_index"], [],
              [52, 16, 64], 11, 5, 0.01, 0.0, True)
     torch.library.opcheck(torch.ops.caster_gvp.gine_encoder.default, margs)
 

@@ -1,0 +1,60 @@
+"""What does a captured hipMemsetAsync do when the graph is replayed?  (Round-2 finding: a memset whose size is not a
+multiple of 256 B left its target un-zeroed from the second replay on; round-2 fault `gpurun_out/r2_joint2.err`: "write
+access to a read-only page" on replay of a captured joint step that still contained such memsets.)
+
+One graph per size: [fill the whole buffer with 1s (torch kernel)] -> hipMemsetAsync(buf + 64, 0, size) -> copy buf to a
+snapshot.  Every replay must leave exactly bytes [64, 64 + size) zero and every other byte (guards in front and behind)
+untouched.  Prints, per size and replay, how many target bytes were NOT zeroed and how many guard bytes were changed.
+Diagnostic only -- the library no longer issues hipMemsetAsync (own zero_words kernel)."""
+import ctypes as C
+import sys
+
+import torch
+
+hip = C.CDLL("libamdhip64.so")
+hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+hip.hipMemsetAsync.restype = C.c_int
+
+
+def probe(size, replays=4):
+    dev = torch.device("cuda:0")
+    n = 64 + size + 4096
+    buf = torch.empty(n, dtype=torch.uint8, device=dev)
+    snap = torch.empty_like(buf)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+
+    def body():
+        buf.fill_(1)
+        rc = hip.hipMemsetAsync(C.c_void_p(buf.data_ptr() + 64), 0, size, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, rc
+        snap.copy_(buf)
+    with torch.cuda.stream(s):
+        body()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        body()
+    rows = []
+    for r in range(replays):
+        snap.fill_(7)
+        g.replay()
+        torch.cuda.synchronize()
+        h = snap.cpu()
+        not_zeroed = int((h[64:64 + size] != 0).sum())
+        guards = int((h[:64] != 1).sum()) + int((h[64 + size:] != 1).sum())
+        rows.append((not_zeroed, guards))
+    return rows
+
+
+if __name__ == "__main__":
+    sizes = [256, 1024, 76804, 100, 260, 4 * 22507, 2150400, 419840 + 4, 163840 + 12]
+    bad = 0
+    for size in sizes:
+        rows = probe(size)
+        flag = "" if all(r == (0, 0) for r in rows) else "   <-- WRONG"
+        bad += bool(flag)
+        print(f"size {size:>8} (mod 256 = {size % 256:>3}): (target bytes not zeroed, guard bytes changed) per replay = {rows}{flag}")
+    print("captured hipMemsetAsync replays correctly for every size" if not bad else f"{bad} sizes replay wrongly")
+    sys.exit(0)

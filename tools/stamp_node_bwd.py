@@ -17,7 +17,7 @@ d = {k: (tuple(t.to(dev) for t in v) if isinstance(v, tuple) else v.to(dev)) for
 h = ctypes.CDLL(_lib.LIB_PATH)
 enc = model.protein_gnn.gnn_model
 from gvp_hip import autograd_ops
-params = enc._arena_buffer(); dims, layout = enc._hip_config(); image = autograd_ops.fragment_image(enc.op_params(), params, layout, dims)
+params = enc._arena_buffer(); dims, layout = enc._hip_config(); image = ops.prepare_image(params, layout, dims)
 N = pb.num_nodes
 L = _lib.lib()
 f32 = dict(dtype=torch.float32, device=dev)
