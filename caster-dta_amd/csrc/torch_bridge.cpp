@@ -1,0 +1,392 @@
+// torch_bridge.cpp -- the EAGER fast path between PyTorch and libcaster_gvp.so (host code, compiled with g++).
+//
+// Why it exists: the reference's training loop (train_model.py:548-587) calls the model eagerly with a NEW batch every
+// step; the hot path's device time is ~0.26 ms per 64-pair step, and driving it through Python -- a torch.library custom
+// op with a 60-tensor parameter list, ctypes marshalling, a Python backward that hands 60 gradient views back to the
+// engine -- costs 0.7 ms of host time per encoder pass pair (measured, tools/host_profile_encoders.py).  Here the same
+// two things happen in C++:
+//   * ONE call per pass into the C ABI (cgvp_*_forward_pass / cgvp_*_backward_pass, include/caster_gvp.h), workspaces
+//     from PyTorch's caching allocator on PyTorch's current stream;
+//   * the autograd node of the pass (torch::autograd::Node): its apply() runs the backward pass and returns the
+//     parameter gradients as views of ONE gradient arena.
+// The torch.library custom ops (gvp_hip/autograd_ops.py) stay the path torch.compile traces; both call the same C
+// entry points, so the launch sequence lives in one place.  No arithmetic happens here.
+#include <torch/extension.h>
+#include <torch/csrc/autograd/function.h>
+#include <torch/csrc/autograd/functions/utils.h>
+#include <torch/csrc/autograd/variable.h>
+
+#include <c10/hip/HIPStream.h>
+
+#include "../../include/caster_gvp.h"
+
+namespace {
+
+using torch::autograd::Node;
+using torch::autograd::variable_list;
+
+struct NotImplemented : public std::runtime_error { using std::runtime_error::runtime_error; };     // -> Python NotImplementedError
+
+void check(int rc, const char* what) {
+  if (rc == 0) return;
+  if (rc == CGVP_ERR_UNSUPPORTED_DIMS)
+    throw NotImplemented(std::string(what) + ": dimensions outside the compiled CASTER-DTA(s,v) configuration");
+  if (rc < 0) throw py::value_error(std::string(what) + ": bad argument (code " + std::to_string(rc) + ")");
+  throw std::runtime_error(std::string(what) + ": HIP launch failed with hipError_t " + std::to_string(rc));
+}
+
+void* current_stream(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+// an activation / index buffer as the kernels want it: on the GPU, contiguous, 16-B aligned
+at::Tensor ready(const at::Tensor& t, const char* name, c10::optional<at::ScalarType> dtype = c10::nullopt) {
+  TORCH_CHECK(t.is_cuda(), name, ": caster-dta_amd runs on MI355X only (got a ", t.device(), " tensor); there is no CPU path");
+  at::Tensor r = t;
+  if (dtype && r.scalar_type() != *dtype) r = r.to(*dtype);
+  if (!r.is_contiguous()) r = r.contiguous();
+  if (reinterpret_cast<uintptr_t>(r.data_ptr()) % 16) r = r.clone();
+  return r;
+}
+void* ptr(const at::Tensor& t) { return (t.defined() && t.numel() > 0) ? t.data_ptr() : nullptr; }
+void* ptr(const c10::optional<at::Tensor>& t) { return t ? ptr(*t) : nullptr; }
+
+struct LbaCfg {
+  cgvp_dims dims;
+  cgvp_layout layout;
+  int nc;
+  int mean;
+};
+LbaCfg make_cfg(const std::vector<int64_t>& c, bool bf16) {
+  TORCH_CHECK(c.size() == 13, "cfg must hold 13 integers");
+  LbaCfg r;
+  r.dims = cgvp_dims{(int32_t)c[0], (int32_t)c[1], (int32_t)c[2], (int32_t)c[3], (int32_t)c[4], (int32_t)c[5],
+                     (int32_t)c[6], (int32_t)c[7], (int32_t)c[8], bf16 ? CGVP_BF16 : CGVP_F32};
+  check(cgvp_lba_layout(&r.dims, (int32_t)c[9], (int32_t)c[10], (int32_t)c[11], &r.layout), "cgvp_lba_layout");
+  r.nc = (int)c[11];
+  r.mean = c[12] != 0;
+  return r;
+}
+
+// The arena-ordered parameter list as one flat fp32 buffer: zero-copy when the tensors are consecutive views of one
+// storage (what gvp_hip.arena.ParamArena maintains), one cat otherwise.
+at::Tensor flat_arena(const std::vector<at::Tensor>& params, bool* zero_copy) {
+  const at::Tensor& p0 = params[0];
+  const char* base = static_cast<const char*>(p0.data_ptr());
+  const char* at_ = base;
+  bool ok = p0.scalar_type() == at::kFloat;
+  for (const at::Tensor& p : params) {
+    if (!ok) break;
+    ok = p.scalar_type() == at::kFloat && p.is_contiguous() && static_cast<const char*>(p.data_ptr()) == at_ &&
+         p.storage().is_alias_of(p0.storage());
+    at_ += p.numel() * 4;
+  }
+  *zero_copy = ok;
+  if (ok) {
+    int64_t n = (at_ - base) / 4;
+    return at::from_blob(const_cast<char*>(base), {n}, p0.options().requires_grad(false));
+  }
+  std::vector<at::Tensor> flat;
+  flat.reserve(params.size());
+  for (const at::Tensor& p : params) flat.push_back(p.detach().reshape({-1}).to(at::kFloat));
+  return at::cat(flat);
+}
+
+struct Tables { const int32_t* rowptr = nullptr; const int32_t* eperm = nullptr; const int32_t* esrc = nullptr; const int32_t* edst = nullptr; };
+Tables tables_of(const std::vector<at::Tensor>& csr) {
+  Tables t;
+  if (csr.empty()) return t;
+  TORCH_CHECK(csr.size() == 4, "csr must be [] or [rowptr, eperm, esrc, edst]");
+  for (const at::Tensor& c : csr) TORCH_CHECK(c.is_cuda() && c.scalar_type() == at::kInt && c.is_contiguous(), "csr tables must be contiguous int32 CUDA tensors");
+  t.rowptr = csr[0].data_ptr<int32_t>(); t.eperm = csr[1].data_ptr<int32_t>();
+  t.esrc = csr[2].data_ptr<int32_t>(); t.edst = csr[3].data_ptr<int32_t>();
+  return t;
+}
+
+// ===================================================================================== protein encoder
+struct LbaBackward : public Node {
+  LbaCfg cfg;
+  at::Tensor x_s, x_v, ntypes, e_s, e_v, etypes, ws, masks;
+  std::vector<at::Tensor> csr;
+  std::vector<std::vector<int64_t>> shapes;
+  std::vector<int64_t> numels;
+  at::ScalarType x_dtype;
+  int64_t N = 0, E = 0;
+  double dropout_p = 0;
+  bool need_x = false;
+
+  variable_list apply(variable_list&& grads) override {
+    const size_t np = shapes.size();
+    variable_list out(np + 2);
+    if (grads.empty() || !grads[0].defined()) return out;
+    TORCH_CHECK(ws.defined(), "caster_gvp: backward through a protein encoder pass whose saved state was already released "
+                              "(call backward once, or pass retain_graph=True)");
+    c10::DeviceGuard guard(x_s.device());
+    at::Tensor g_out = ready(grads[0], "grad_output", at::kFloat);
+    auto f32 = x_s.options().dtype(at::kFloat).requires_grad(false);
+    at::Tensor gparams = at::empty({(int64_t)cfg.layout.total}, f32);
+    const int64_t nbytes = cgvp_lba_bwd_workspace_bytes(&cfg.dims, &cfg.layout, N, E);
+    if (nbytes < 0) check((int)nbytes, "cgvp_lba_bwd_workspace_bytes");
+    at::Tensor bws = at::empty({nbytes}, f32.dtype(at::kByte));
+    at::Tensor g_x_s, g_x_v;
+    if (need_x) {
+      g_x_s = at::empty({N, (int64_t)cfg.dims.node_in_s}, f32);
+      g_x_v = at::empty({N, (int64_t)cfg.dims.node_in_v, 3}, f32);
+    }
+    const Tables t = tables_of(csr);
+    cgvp_lba_batch b{N, E, (const float*)ptr(x_s), (const float*)ptr(x_v), (const int64_t*)ptr(ntypes),
+                     (const float*)ptr(e_s), (const float*)ptr(e_v), (const int64_t*)ptr(etypes), nullptr,
+                     t.rowptr, t.eperm, t.esrc, t.edst};
+    check(cgvp_lba_backward_pass(&cfg.dims, &cfg.layout, &b, cfg.mean, (float)dropout_p, (const float*)ptr(masks), ptr(ws),
+                                 (const float*)ptr(g_out), ptr(bws), (float*)ptr(gparams), (float*)ptr(g_x_s),
+                                 (float*)ptr(g_x_v), current_stream(x_s)),
+          "cgvp_lba_backward_pass");
+    int64_t off = 0;
+    for (size_t i = 0; i < np; ++i) {
+      if (task_should_compute_output(i)) out[i] = gparams.narrow(0, off, numels[i]).view(shapes[i]);
+      off += numels[i];
+    }
+    if (need_x) {
+      out[np] = x_dtype == at::kFloat ? g_x_s : g_x_s.to(x_dtype);
+      out[np + 1] = x_dtype == at::kFloat ? g_x_v : g_x_v.to(x_dtype);
+    }
+    return out;
+  }
+  void release_variables() override {
+    ws.reset(); masks.reset(); x_s.reset(); x_v.reset(); e_s.reset(); e_v.reset(); ntypes.reset(); etypes.reset();
+    csr.clear();
+  }
+  std::string name() const override { return "CasterGvpLbaEncoderBackward"; }
+};
+
+// -> (out [N, out_s], ws: the forward workspace (uint8; undefined when the pass saved nothing), whether the parameters
+//     were consecutive views of one arena (else they were concatenated: the caller re-seats them for the next pass))
+std::tuple<at::Tensor, at::Tensor, bool> lba_encoder(std::vector<at::Tensor> params, at::Tensor x_s_in, at::Tensor x_v_in,
+                                               at::Tensor ntypes_in, at::Tensor e_s_in, at::Tensor e_v_in,
+                                               at::Tensor etypes_in, at::Tensor edge_index_in, std::vector<at::Tensor> csr,
+                                               std::vector<int64_t> cfgv, double dropout_p, bool save_state,
+                                               c10::optional<at::Tensor> masks, c10::optional<at::Tensor> rng_state,
+                                               c10::optional<at::Tensor> counters, bool fuse) {
+  TORCH_CHECK(!params.empty(), "no parameters");
+  const bool bf16 = x_s_in.scalar_type() == at::kBFloat16;
+  const at::ScalarType sdt = bf16 ? at::kBFloat16 : at::kFloat;
+  TORCH_CHECK(x_s_in.scalar_type() == at::kFloat || bf16, "x_s: expected float32 or bfloat16, got ", x_s_in.scalar_type());
+  const LbaCfg cfg = make_cfg(cfgv, bf16);
+  at::Tensor x_s = ready(x_s_in, "x_s", sdt), x_v = ready(x_v_in, "x_v", sdt);
+  at::Tensor e_s = ready(e_s_in, "eattr_s", sdt), e_v = ready(e_v_in, "eattr_v", sdt);
+  TORCH_CHECK(edge_index_in.dim() == 2 && edge_index_in.size(0) == 2, "edge_index must be [2, E]");
+  const int64_t N = x_s.size(0), E = edge_index_in.size(1);
+  const bool tables = !csr.empty();
+  if (x_s.dim() != 2 || x_s.size(1) != cfg.dims.node_in_s || x_v.dim() != 3 || x_v.size(0) != N ||
+      x_v.size(1) != cfg.dims.node_in_v || e_s.dim() != 2 || e_s.size(1) != cfg.dims.edge_in_s || e_v.dim() != 3 ||
+      e_v.size(1) != cfg.dims.edge_in_v || e_s.size(0) != e_v.size(0) || (!tables && e_s.size(0) != E))
+    throw NotImplemented("feature shapes do not match the compiled CASTER-DTA configuration");
+  at::Tensor ntypes, etypes, edge_index;
+  if (cfg.layout.nt_node > 0) ntypes = ready(ntypes_in, "ntypes", at::kLong);
+  if (cfg.layout.nt_edge > 0) etypes = ready(etypes_in, "etypes", at::kLong);
+  if (!tables) edge_index = ready(edge_index_in, "edge_index", at::kLong);
+  bool zero_copy = false;
+  at::Tensor flat = flat_arena(params, &zero_copy);
+  TORCH_CHECK(flat.numel() == cfg.layout.total, "parameter arena has ", flat.numel(), " floats, kernels expect ", cfg.layout.total);
+  const bool drop = dropout_p > 0 && save_state;
+  const bool draw = drop && !(masks && masks->numel() > 0);
+  TORCH_CHECK(!draw || rng_state, "training-mode dropout needs the persistent generator state");
+  TORCH_CHECK(tables || counters, "the CSR build needs the persistent counters");
+  c10::DeviceGuard guard(x_s.device());
+  cgvp_lba_fwd_ws wsd;
+  check(cgvp_lba_fwd_workspace(&cfg.dims, &cfg.layout, N, E, save_state ? 1 : 0, &wsd), "cgvp_lba_fwd_workspace");
+  auto opts = x_s.options().requires_grad(false);
+  at::Tensor ws = at::empty({wsd.total}, opts.dtype(at::kByte));
+  at::Tensor out = at::empty({N, (int64_t)cfg.dims.out_s}, opts.dtype(sdt));
+  const Tables t = tables_of(csr);
+  cgvp_lba_batch b{N, E, (const float*)ptr(x_s), (const float*)ptr(x_v), (const int64_t*)ptr(ntypes),
+                   (const float*)ptr(e_s), (const float*)ptr(e_v), (const int64_t*)ptr(etypes),
+                   (const int64_t*)ptr(edge_index), t.rowptr, t.eperm, t.esrc, t.edst};
+  const int rc = cgvp_lba_forward_pass(&cfg.dims, &cfg.layout, (const float*)ptr(flat), &b, cfg.mean,
+                                       save_state ? (float)dropout_p : 0.f, draw ? (uint64_t*)ptr(rng_state) : nullptr,
+                                       drop ? (const float*)ptr(masks) : nullptr, tables ? nullptr : (int32_t*)ptr(counters),
+                                       ptr(ws), save_state ? 1 : 0, fuse ? 0 : CGVP_PASS_UNFUSED, (float*)ptr(out),
+                                       current_stream(x_s));
+  if (rc != 0 && counters) counters->zero_();     // the persistent counters must not stay half-used
+  check(rc, "cgvp_lba_forward_pass");
+  if (!save_state) return {out, at::Tensor(), zero_copy};
+  // autograd: one node for the whole pass
+  bool any = false;
+  for (const at::Tensor& p : params) any = any || p.requires_grad();
+  const bool need_x = x_s_in.requires_grad() || x_v_in.requires_grad();
+  if (at::GradMode::is_enabled() && (any || need_x)) {
+    auto node = std::shared_ptr<LbaBackward>(new LbaBackward(), torch::autograd::deleteNode);
+    torch::autograd::edge_list edges = torch::autograd::collect_next_edges(params, x_s_in, x_v_in);
+    node->set_next_edges(std::move(edges));
+    node->cfg = cfg;
+    node->x_s = x_s; node->x_v = x_v; node->ntypes = ntypes; node->e_s = e_s; node->e_v = e_v; node->etypes = etypes;
+    node->ws = ws;
+    if (drop && masks && masks->numel() > 0) node->masks = *masks;
+    node->csr = csr;
+    node->N = N; node->E = E; node->dropout_p = drop ? dropout_p : 0.0; node->need_x = need_x;
+    node->x_dtype = x_s_in.scalar_type();
+    node->shapes.reserve(params.size());
+    for (const at::Tensor& p : params) { node->shapes.push_back(p.sizes().vec()); node->numels.push_back(p.numel()); }
+    torch::autograd::set_history(out, node);
+  }
+  return {out, ws, zero_copy};
+}
+
+// ===================================================================================== drug encoder
+struct GineMeta {
+  cgvp_gine_cfg cfg;
+  int L;
+};
+GineMeta gine_meta(const std::vector<int64_t>& widths, int64_t nt, int64_t net, int64_t edge_dim, double slope) {
+  GineMeta m;
+  m.L = (int)widths.size() - 1;
+  TORCH_CHECK(m.L >= 1 && m.L <= CGVP_GINE_MAX_LAYERS, "the GINE pass supports 1..", CGVP_GINE_MAX_LAYERS, " layers");
+  m.cfg.num_layers = m.L;
+  for (int i = 0; i <= CGVP_GINE_MAX_LAYERS; ++i) m.cfg.widths[i] = i <= m.L ? (int32_t)widths[i] : 0;
+  m.cfg.num_ntypes = (int32_t)nt; m.cfg.num_etypes = (int32_t)net; m.cfg.edge_dim = (int32_t)edge_dim; m.cfg.act_slope = (float)slope;
+  return m;
+}
+// params: 7 tensors per layer in slab / state_dict order  eps | w0 | b0 | w1 | b1 | we | be
+void gine_weights(const std::vector<at::Tensor>& params, int L, std::vector<at::Tensor>& keep, std::vector<cgvp_gine_w>& w) {
+  TORCH_CHECK((int)params.size() == 7 * L, "expected 7 parameter tensors per GINE layer");
+  keep.reserve(params.size());
+  for (const at::Tensor& p : params) keep.push_back(ready(p.detach(), "weight", at::kFloat));
+  w.resize(L);
+  for (int l = 0; l < L; ++l) {
+    const at::Tensor* k = &keep[7 * l];
+    w[l] = cgvp_gine_w{(const float*)k[0].data_ptr(), (const float*)k[5].data_ptr(), (const float*)k[6].data_ptr(),
+                       (const float*)k[1].data_ptr(), (const float*)k[2].data_ptr(), (const float*)k[3].data_ptr(),
+                       (const float*)k[4].data_ptr()};
+  }
+}
+
+struct GineBackward : public Node {
+  GineMeta meta;
+  std::vector<at::Tensor> params, csr, masks;
+  at::Tensor x, ntypes, eattr, etypes, ws;
+  int64_t N = 0, E = 0;
+  double dropout_p = 0;
+  bool need_x = false;
+  int max_workgroups = 0;
+
+  variable_list apply(variable_list&& grads) override {
+    const size_t np = params.size();
+    variable_list out(np + 1);
+    if (grads.empty() || !grads[0].defined()) return out;
+    TORCH_CHECK(ws.defined(), "caster_gvp: backward through a drug encoder pass whose saved state was already released "
+                              "(call backward once, or pass retain_graph=True)");
+    c10::DeviceGuard guard(x.device());
+    at::Tensor g_out = ready(grads[0], "grad_output", at::kFloat);
+    auto f32 = x.options().dtype(at::kFloat).requires_grad(false);
+    int64_t total = 0;
+    for (const at::Tensor& p : params) total += p.numel();
+    at::Tensor gflat = at::empty({total}, f32);
+    const int64_t nbytes = cgvp_gine_bwd_workspace_bytes(&meta.cfg, N, E);
+    if (nbytes < 0) check((int)nbytes, "cgvp_gine_bwd_workspace_bytes");
+    at::Tensor bws = at::empty({nbytes}, f32.dtype(at::kByte));
+    at::Tensor g_x;
+    if (need_x) g_x = at::empty({N, (int64_t)(meta.cfg.widths[0] - meta.cfg.num_ntypes)}, f32);
+    std::vector<at::Tensor> keep;
+    std::vector<cgvp_gine_w> w;
+    gine_weights(params, meta.L, keep, w);
+    const Tables t = tables_of(csr);
+    cgvp_gine_batch b{N, E, (const float*)ptr(x), (const int64_t*)ptr(ntypes), (const float*)ptr(eattr),
+                      (const int64_t*)ptr(etypes), nullptr, t.rowptr, t.eperm, t.esrc, t.edst};
+    std::vector<const float*> mp;
+    for (const at::Tensor& m : masks) mp.push_back((const float*)ptr(m));
+    check(cgvp_gine_backward_pass(&meta.cfg, w.data(), &b, (float)dropout_p, mp.empty() ? nullptr : mp.data(), ptr(ws),
+                                  (const float*)ptr(g_out), ptr(bws), (float*)ptr(gflat), (float*)ptr(g_x), max_workgroups,
+                                  current_stream(x)),
+          "cgvp_gine_backward_pass");
+    int64_t off = 0;
+    for (size_t i = 0; i < np; ++i) {
+      const int64_t n = params[i].numel();
+      if (task_should_compute_output(i)) out[i] = gflat.narrow(0, off, n).view(params[i].sizes());
+      off += n;
+    }
+    if (need_x) out[np] = g_x;
+    return out;
+  }
+  void release_variables() override {
+    ws.reset(); x.reset(); eattr.reset(); ntypes.reset(); etypes.reset(); params.clear(); csr.clear(); masks.clear();
+  }
+  std::string name() const override { return "CasterGvpGineEncoderBackward"; }
+};
+
+std::tuple<at::Tensor, at::Tensor> gine_encoder(std::vector<at::Tensor> params, at::Tensor x_in, at::Tensor ntypes_in,
+                                                at::Tensor eattr_in, at::Tensor etypes_in, at::Tensor edge_index_in,
+                                                std::vector<at::Tensor> csr, std::vector<int64_t> widths, int64_t num_ntypes,
+                                                int64_t num_etypes, double slope, double dropout_p, bool save_state,
+                                                std::vector<at::Tensor> masks, c10::optional<at::Tensor> rng_state,
+                                                c10::optional<at::Tensor> counters, int64_t variant, int64_t bwd_workgroups) {
+  TORCH_CHECK(x_in.scalar_type() == at::kFloat, "x: expected float32, got ", x_in.scalar_type());
+  TORCH_CHECK(eattr_in.scalar_type() == at::kFloat, "eattr: expected float32, got ", eattr_in.scalar_type());
+  at::Tensor x = ready(x_in, "x"), eattr = ready(eattr_in, "eattr");
+  TORCH_CHECK(edge_index_in.dim() == 2 && edge_index_in.size(0) == 2, "edge_index must be [2, E]");
+  TORCH_CHECK(x.dim() == 2 && eattr.dim() == 2, "x must be [N, F], eattr [E, D]");
+  const int64_t N = x.size(0), E = edge_index_in.size(1);
+  const GineMeta meta = gine_meta(widths, num_ntypes, num_etypes, eattr.size(1), slope);
+  if (x.size(1) != widths[0] - num_ntypes) throw py::value_error("x has " + std::to_string(x.size(1)) + " columns, expected " + std::to_string(widths[0] - num_ntypes));
+  const bool tables = !csr.empty();
+  at::Tensor ntypes, etypes, edge_index;
+  if (num_ntypes > 0) ntypes = ready(ntypes_in, "ntypes", at::kLong);
+  if (num_etypes > 0) etypes = ready(etypes_in, "etypes", at::kLong);
+  if (!tables) edge_index = ready(edge_index_in, "edge_index", at::kLong);
+  std::vector<at::Tensor> keep;
+  std::vector<cgvp_gine_w> w;
+  gine_weights(params, meta.L, keep, w);
+  const bool drop = dropout_p > 0 && save_state && meta.L > 1;
+  const bool pinned = drop && !masks.empty();
+  const bool draw = drop && !pinned;
+  TORCH_CHECK(!draw || rng_state, "training-mode dropout needs the persistent generator state");
+  TORCH_CHECK(tables || counters, "the CSR build needs the persistent counters");
+  c10::DeviceGuard guard(x.device());
+  cgvp_gine_fwd_ws wsd;
+  check(cgvp_gine_fwd_workspace(&meta.cfg, N, E, save_state ? 1 : 0, &wsd), "cgvp_gine_fwd_workspace");
+  auto opts = x.options().requires_grad(false);
+  at::Tensor ws = at::empty({wsd.total}, opts.dtype(at::kByte));
+  at::Tensor out = at::empty({N, widths.back()}, opts);
+  const Tables t = tables_of(csr);
+  cgvp_gine_batch b{N, E, (const float*)ptr(x), (const int64_t*)ptr(ntypes), (const float*)ptr(eattr),
+                    (const int64_t*)ptr(etypes), (const int64_t*)ptr(edge_index), t.rowptr, t.eperm, t.esrc, t.edst};
+  std::vector<const float*> mp;
+  if (pinned) {
+    TORCH_CHECK((int)masks.size() == meta.L - 1, "expected one mask per layer but the last");
+    for (at::Tensor& m : masks) { m = ready(m, "mask", at::kFloat); mp.push_back((const float*)ptr(m)); }
+  }
+  const int rc = cgvp_gine_forward_pass(&meta.cfg, w.data(), &b, save_state ? (float)dropout_p : 0.f,
+                                        draw ? (uint64_t*)ptr(rng_state) : nullptr, pinned ? mp.data() : nullptr,
+                                        tables ? nullptr : (int32_t*)ptr(counters), ptr(ws), save_state ? 1 : 0, (int32_t)variant,
+                                        (float*)ptr(out), current_stream(x));
+  if (rc != 0 && counters) counters->zero_();
+  check(rc, "cgvp_gine_forward_pass");
+  if (!save_state) return {out, at::Tensor()};
+  bool any = false;
+  for (const at::Tensor& p : params) any = any || p.requires_grad();
+  const bool need_x = x_in.requires_grad();
+  if (at::GradMode::is_enabled() && (any || need_x)) {
+    auto node = std::shared_ptr<GineBackward>(new GineBackward(), torch::autograd::deleteNode);
+    node->set_next_edges(torch::autograd::collect_next_edges(params, x_in));
+    node->meta = meta;
+    node->params.reserve(params.size());
+    for (const at::Tensor& p : params) node->params.push_back(p.detach());
+    node->csr = csr;
+    if (pinned) node->masks = masks;
+    node->x = x; node->ntypes = ntypes; node->eattr = eattr; node->etypes = etypes; node->ws = ws;
+    node->N = N; node->E = E; node->dropout_p = drop ? dropout_p : 0.0; node->need_x = need_x;
+    node->max_workgroups = (int)bwd_workgroups;
+    torch::autograd::set_history(out, node);
+  }
+  return {out, ws};
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  py::register_exception_translator([](std::exception_ptr p) {
+    try { if (p) std::rethrow_exception(p); }
+    catch (const NotImplemented& e) { PyErr_SetString(PyExc_NotImplementedError, e.what()); }
+  });
+  m.doc() = "eager fast path of caster-dta_amd: C++ autograd nodes over the whole-pass C ABI of libcaster_gvp.so";
+  m.def("lba_encoder", &lba_encoder, "VectorProteinGNN_LBAModel.forward (protein_gnn.py:361-388) with autograd");
+  m.def("gine_encoder", &gine_encoder, "HomoMoleculeGNN_GINE.forward (molecule_gnn.py:254-268) with autograd");
+  m.def("abi_version", []() { return cgvp_abi_version(); });
+}

@@ -194,6 +194,29 @@ def lib():
     return _lib
 
 
+_bridge = False
+
+
+def bridge():
+    """The C++ eager fast path (csrc/torch_bridge.cpp -> lib/caster_gvp_torch.so): C++ autograd nodes over the whole-pass
+    entry points.  None when it is not built or CGVP_BRIDGE=0 -- the torch.library custom ops (the same kernels, driven
+    from Python) are then used in eager mode as well."""
+    global _bridge
+    if _bridge is False:
+        _bridge = None
+        path = os.path.join(os.path.dirname(LIB_PATH), "caster_gvp_torch.so")
+        if os.environ.get("CGVP_BRIDGE", "1") != "0" and os.path.exists(path) and not os.environ.get("CGVP_LIB_PATH"):
+            import importlib.util
+            lib()                                    # libcaster_gvp.so first (version check; the bridge links against it)
+            spec = importlib.util.spec_from_file_location("caster_gvp_torch", path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            if mod.abi_version() != ABI_VERSION:
+                raise HipLibraryError(f"{path} was built against C ABI {mod.abi_version()}, binding expects {ABI_VERSION}; rebuild")
+            _bridge = mod
+    return _bridge
+
+
 def check(rc, what):
     if rc == 0:
         return

@@ -337,7 +337,7 @@ def _numel(shape):
 
 def _lba_backward(ctx, g_out, g_ws, g_masks):
     if g_out is None:
-        return (None,) * 12
+        return (None,) * 8 + ([None] * ctx.ncsr, None, None, None)
     x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, ws, masks, *csr = ctx.saved_tensors
     need_x = bool(ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
     gflat, g_x_s, g_x_v = torch.ops.caster_gvp.lba_encoder_backward(
@@ -346,8 +346,8 @@ def _lba_backward(ctx, g_out, g_ws, g_masks):
     grads = [g.view(s) for g, s in zip(torch.split(gflat, [_numel(s) for s in ctx.shapes]), ctx.shapes)]
     if need_x and x_s.dtype != torch.float32:                 # input gradients are produced in fp32
         g_x_s, g_x_v = g_x_s.to(x_s.dtype), g_x_v.to(x_v.dtype)
-    return (grads, g_x_s if need_x else None, g_x_v if need_x else None, None, None, None, None, None, None, None,
-            None, None)
+    return (grads, g_x_s if need_x else None, g_x_v if need_x else None, None, None, None, None, None, [None] * ctx.ncsr,
+            None, None, None)
 
 
 torch.library.register_autograd("caster_gvp::lba_encoder", _lba_backward, setup_context=_lba_setup)
@@ -375,10 +375,39 @@ def lba_encoder(model, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, train_dro
            model.hidden_channels[0], model.hidden_channels[1], model.edge_hidden_channels[0],
            model.edge_hidden_channels[1], model.out_channels[0], model.num_ntypes, model.num_etypes,
            model.num_convs, 1 if model.aggr == "mean" else 0]
+    p = float(model.dropout_rate) if train_dropout else 0.0
+    br = _eager_bridge()
+    if br is not None:
+        # eager mode: the C++ autograd node (csrc/torch_bridge.cpp) -- same C entry points, a fraction of the host time
+        dev, N = x_s.device, x_s.shape[0]
+        csr = _memo_tables(edge_index, N)
+        masks, draw = None, False
+        if p > 0 and save_state:
+            if PINNED_MASKS is not None:
+                masks = PINNED_MASKS(2 * model.num_convs, N, MROW, p, dev)
+            else:
+                draw = True
+        with torch.cuda.device(dev):
+            out, ws, zero_copy = br.lba_encoder(model.op_params(), x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, csr, cfg, p,
+                                                save_state, masks, rng_state("lba", dev) if draw else None,
+                                                None if csr else ops.csr_counters(dev, N), ops.FUSE_LAYER)
+        if draw:
+            _LAST_WS["lba"] = (ws, 0)
+        if not zero_copy and model._onehot_ntypes and model._onehot_etypes:
+            model._arena.rebuild()          # something re-materialised the parameters: re-seat them as arena views
+        return out
     out, _, _ = torch.ops.caster_gvp.lba_encoder(
         model.op_params(), x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, _memo_tables(edge_index, x_s.shape[0]), cfg,
-        float(model.dropout_rate) if train_dropout else 0.0, save_state)
+        p, save_state)
     return out
+
+
+def _eager_bridge():
+    """The C++ fast path, when it applies: eager mode (Dynamo traces the custom ops instead), MFMA kernels, no autocast
+    (the custom ops carry the autocast rule)."""
+    if torch.compiler.is_compiling() or ops.VARIANT != "mfma" or torch.is_autocast_enabled("cuda"):
+        return None
+    return _lib.bridge()
 
 
 # ===================================================================================== drug encoder
@@ -541,9 +570,9 @@ def _gine_setup(ctx, inputs, output):
 
 
 def _gine_backward(ctx, g_out, g_ws, g_masks):
-    if g_out is None:
-        return (None,) * 13
     widths, num_ntypes, num_etypes, slope, dropout_p, n_params, n_csr = ctx.meta
+    if g_out is None:
+        return (None,) * 6 + ([None] * n_csr,) + (None,) * 6
     x, ntypes, eattr, etypes, edge_index, ws, *rest = ctx.saved_tensors
     params, csr, masks = rest[:n_params], rest[n_params:n_params + n_csr], rest[n_params + n_csr:]
     need_x = bool(ctx.needs_input_grad[1])
@@ -551,7 +580,7 @@ def _gine_backward(ctx, g_out, g_ws, g_masks):
         g_out.contiguous(), params, x, ntypes, eattr, etypes, edge_index, list(csr), ws, list(masks), widths, num_ntypes,
         num_etypes, slope, dropout_p, need_x, GINE_BWD_WORKGROUPS)
     grads = [g.view(s) for g, s in zip(torch.split(gflat, [_numel(s) for s in ctx.shapes]), ctx.shapes)]
-    return (grads, g_x if need_x else None, None, None, None, None, None, None, None, None, None, None, None)
+    return (grads, g_x if need_x else None, None, None, None, None, [None] * n_csr, None, None, None, None, None, None)
 
 
 # Cap on the CUs of the GINE backward (0 = the library default of 16: inside JointGNN it runs beside the
@@ -575,7 +604,27 @@ def gine_encoder(model, x, ntypes, eattr, etypes, edge_index, slope, train_dropo
     """HomoMoleculeGNN_GINE.forward through the custom op (autograd, inter-layer dropout when training)."""
     if eattr.requires_grad:
         raise NotImplementedError("gradients w.r.t. bond features are not produced by the backward kernels")
+    p = float(model.dropout_rate) if train_dropout else 0.0
+    br = _eager_bridge()
+    if br is not None:
+        dev, N = x.device, x.shape[0]
+        csr = _memo_tables(edge_index, N)
+        widths = list(model._widths)
+        masks, draw = [], False
+        if p > 0 and save_state and len(widths) > 2:
+            if PINNED_MASKS is not None:
+                masks = [PINNED_MASKS(1, N, widths[l + 1], p, dev)[0].contiguous() for l in range(len(widths) - 2)]
+            else:
+                draw = True
+        with torch.cuda.device(dev):
+            out, ws = br.gine_encoder(gine_params(model), x, ntypes, eattr, etypes, edge_index, csr, widths, model.num_ntypes,
+                                      model.num_etypes, float(slope), p, save_state, masks,
+                                      rng_state("gine", dev) if draw else None, None if csr else ops.csr_counters(dev, N),
+                                      0, GINE_BWD_WORKGROUPS)
+        if draw:
+            _LAST_WS["gine"] = (ws, 0)
+        return out
     out, _, _ = torch.ops.caster_gvp.gine_encoder(
         gine_params(model), x, ntypes, eattr, etypes, edge_index, _memo_tables(edge_index, x.shape[0]), list(model._widths),
-        model.num_ntypes, model.num_etypes, float(slope), float(model.dropout_rate) if train_dropout else 0.0, save_state)
+        model.num_ntypes, model.num_etypes, float(slope), p, save_state)
     return out

@@ -9,8 +9,8 @@ checkpoints keep their keys (`conv_list.{l}.eps`, `.lin.{weight,bias}`,
 
     x'_i = act( Lin1( act( Lin0( (1 + eps) x_i + sum_{j->i} ReLU(x_j + W_e e_ji + b_e) ) ) ) )
 
-runs as ONE launch of libcaster_gvp.so per layer (one wave per atom, one lane per
-channel).  No eager/CPU fallback.
+runs as ONE launch of libcaster_gvp.so per layer (16-atom MFMA tiles, csrc/gine_quad_kernels.hip), the whole encoder
+pass as one host call (cgvp_gine_forward_pass).  No eager/CPU fallback.
 """
 import warnings
 from functools import partial

@@ -213,13 +213,15 @@ class VectorProteinGNN_LBAModel(BaseProteinGNN):
             raise TypeError("the MI355X kernels are fp32; call .float() on the model")
         if self.out_channels[1] != 0:
             raise NotImplementedError("the fused head produces scalars only (out_channels = (n, 0))")
-        if self._onehot_ntypes and self._onehot_etypes and not torch.compiler.is_compiling():
+        from gvp_hip import autograd_ops
+        if self._onehot_ntypes and self._onehot_etypes and not torch.compiler.is_compiling() \
+                and autograd_ops._eager_bridge() is None:       # (the C++ fast path checks the arena itself)
             self._arena_buffer()
         needs_grad = torch.is_grad_enabled() and (
             any(p.requires_grad for p in self._arena.params) or any(t.requires_grad for t in (x_s, x_v, e_s, e_v)))
         train_dropout = self.training and self.dropout_rate > 0
-        from gvp_hip import autograd_ops
-        # ONE custom op (caster_gvp::lba_encoder) for the whole encoder: 1 + num_convs launches (+ the CSR build)
+        # ONE host call (C++ autograd node in eager mode, the caster_gvp::lba_encoder custom op under torch.compile)
+        # for the whole encoder pass: 1 + num_convs launches (+ the CSR build)
         return autograd_ops.lba_encoder(self, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, train_dropout,
                                         save_state=bool(needs_grad or train_dropout))
 

@@ -304,3 +304,100 @@ def test_bench_style_two_stream_step_replays_correctly(pretrained):
                 assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 2e-6 * scale, rep
     finally:
         ops.CSR_CACHE_ENABLED = old
+
+
+def test_captured_step_survives_regrow_reseed_and_frees_with_dropout_on(pretrained):
+    """Lifetime of what a captured step writes to (the hazards named there: the CSR counters were
+    re-allocated when a larger batch arrived, the generator state was re-drawn after torch.manual_seed, cached images
+    were evicted -- each a use-after-free for a live graph).  Now: both workspaces of a pass come from the graph's own
+    pool, the fragment image lives in the forward workspace, the counters are never freed (a larger batch appends a
+    generation), the generator state is re-seeded IN PLACE.
+    The bench-style two-stream training step of both encoders at davis_b64 size, DROPOUT ON, is captured; then, on the
+    capture stream, a larger batch runs eagerly (counters grow), torch.manual_seed re-seeds, junk is allocated and freed
+    and the allocator's cache is emptied; the graph is replayed three times: finite, different masks every replay, and
+    every gradient equals an EAGER step run with the replay's own {seed, offset}."""
+    from gvp_hip import autograd_ops, ops
+    from models.joint_gnn import JointGNN
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))
+    model = JointGNN(protein_gnn_kwargs=kw["protein_gnn_kwargs"], molecule_gnn_kwargs=kw["molecule_gnn_kwargs"],
+                     **kw["joint_gnn_kwargs"])
+    model.load_state_dict(pretrained, strict=True)
+    model = model.to(DEV).train()
+    p, m = ds.pair_batch(64, 0)                                   # davis_b64: 19,200 residues, ~57k edges
+    big_p, big_m = ds.pair_batch(80, 1, length=330)               # more nodes than the counters were sized for
+    pd, md = _to(ds.to_torch(p)), _to(ds.to_torch(m))
+    bpd, bmd = _to(ds.to_torch(big_p)), _to(ds.to_torch(big_m))
+    pp = [q for q in model.protein_gnn.parameters() if q.numel()]
+    mp = [q for q in model.molecule_gnn.parameters() if q.numel()]
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    g_res = torch.randn(p.num_nodes, 64, device=DEV, generator=gen)
+    g_atm = torch.randn(m.num_nodes, 64, device=DEV, generator=gen)
+    side = torch.cuda.Stream()
+
+    def step(a=pd, b=md, gr=g_res, ga=g_atm):
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        res = model.protein_gnn(**a)
+        with torch.cuda.stream(side):
+            atm = model.molecule_gnn(**b)
+        gp = torch.autograd.grad([res], pp, [gr])
+        with torch.cuda.stream(side):
+            gd = torch.autograd.grad([atm], mp, [ga])
+        main.wait_stream(side)
+        return gp + gd
+
+    old = ops.CSR_CACHE_ENABLED
+    ops.CSR_CACHE_ENABLED = False
+    try:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        counters_before = {k: [t.data_ptr() for t in v] for k, v in ops._COUNTERS.items()}
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            out = step()
+        ws_lba, ws_gine = autograd_ops._LAST_WS["lba"], autograd_ops._LAST_WS["gine"]      # the graph's own workspaces
+        seed_of = lambda w: w[0][w[1]:w[1] + 16].view(torch.int64)
+        graph.replay()
+        torch.cuda.synchronize()
+        first = [g.clone() for g in out]
+        # ---- the hazards, all on the capture stream
+        with torch.cuda.stream(s):
+            gr2 = torch.randn(big_p.num_nodes, 64, device=DEV)
+            ga2 = torch.randn(big_m.num_nodes, 64, device=DEV)
+            step(bpd, bmd, gr2, ga2)                               # larger batch: the per-stream counters grow
+            torch.manual_seed(4242)                                # re-seed: in place
+            step(bpd, bmd, gr2, ga2)
+            junk = [torch.empty(1 << 22, device=DEV).normal_() for _ in range(8)]
+            del junk
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        grown = any(len(v) > len(counters_before.get(k, [])) for k, v in ops._COUNTERS.items())
+        assert grown                                               # a new generation was appended ...
+        for k, ptrs in counters_before.items():                    # ... and every old buffer is still alive, same address
+            assert [t.data_ptr() for t in ops._COUNTERS[k]][:len(ptrs)] == ptrs
+        seeds = []
+        for rep in range(3):
+            graph.replay()
+            torch.cuda.synchronize()
+            assert all(torch.isfinite(g).all() for g in out), rep
+            seeds.append((seed_of(ws_lba).clone(), seed_of(ws_gine).clone()))
+        assert int(seeds[2][0][1]) == int(seeds[1][0][1]) + 1      # the generator advances on every replay
+        replayed = [g.clone() for g in out]
+        assert not all(torch.equal(a, b) for a, b in zip(first, replayed))      # other masks than the first replay
+        # ---- the last replay against an eager step with the same {seed, offset}
+        for kind, sd in (("lba", seeds[2][0]), ("gine", seeds[2][1])):
+            st = autograd_ops.rng_state(kind, torch.device(DEV))
+            st.copy_(torch.stack([sd[0], sd[1] - 1]))
+        eager = step()
+        torch.cuda.synchronize()
+        assert torch.equal(autograd_ops.last_seed("lba"), seeds[2][0]) and torch.equal(autograd_ops.last_seed("gine"), seeds[2][1])
+        scale = max(float(g.abs().max()) for g in eager)
+        for a, b in zip(replayed, eager):
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 2e-6 * scale
+    finally:
+        ops.CSR_CACHE_ENABLED = old
