@@ -91,6 +91,12 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="activation storage of the protein encoder (bf16 = BASELINE config 5: bf16 storage / fp32 "
                          "accumulate; gradients and weights stay fp32; the drug encoder stays fp32 storage)")
+    ap.add_argument("--epoch", default="nominal", choices=["off", "nominal", "real"],
+                    help="second leg (N = 1, --scope encoders, davis_b64 only): ONE EPOCH the way train_model.py:548-587 drives "
+                         "the model -- 329 DIFFERENT batches of 64 pairs drawn from 442 unique proteins x 68 unique drugs (the "
+                         "Davis table sizes), a new edge_index every step, eager (no HIP graph); 'nominal' = 300-residue "
+                         "proteins, 'real' = lengths drawn from the Davis sequence-length table; reported in config.epoch")
+    ap.add_argument("--epoch-steps", type=int, default=329, help="batches in the epoch leg (Davis: 21,039 train pairs / 64)")
     ap.add_argument("--cpu-runs", type=int, default=20, help="timed CPU-baseline runs per thread count (median)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (0 = choose for ~10-30 s)")
     return ap.parse_args()
@@ -416,6 +422,11 @@ def main():
     pairs_per_step = wl["pairs"] * world
     value = pairs_per_step * args.steps / dt
 
+    epoch = None
+    if rank == 0 and world == 1 and args.epoch != "off" and args.scope == "encoders" and args.workload == "davis_b64" \
+            and args.only is None and not collectives:
+        epoch = epoch_leg(args, model, dev, train, prot_params, drug_params)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # a reported baseline of the N = 1 line only
         cpu = cpu_baseline(args, wl, state, pb, mb, train)
@@ -443,12 +454,100 @@ def main():
                        "activation_storage": "bf16 (protein encoder: bf16 activations in HBM and bf16 matrix-core operands, fp32 accumulate, fp32 weights and gradient buffers)" if args.dtype == "bf16" else "fp32",
                        "scope": args.scope, "untimed_warmup_steps": max(args.warmup, MIN_WARMUP), "torch_compile": bool(args.compile and args.scope == "joint"), "autocast": args.autocast if args.scope == "joint" else None, "train_mode": bool(dropout_on), "dropout_p": 0.2 if dropout_on else 0.0,
                        "csr_build_in_step": ("collate" if args.collate_csr else not args.cache_csr),
-                       "hip_graph": graph is not None, "kernels": ops.VARIANT, "parallelism": par},
+                       "hip_graph": graph is not None, "kernels": ops.VARIANT, "parallelism": par,
+                       "timed_region": ("replays of ONE captured step on one batch (CSR build, dropout draw and weight-image build "
+                                        "inside every replay)" if graph is not None else "eager steps on one batch"),
+                       "epoch": epoch},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def epoch_leg(args, model, dev, train, prot_params, drug_params):
+    """BASELINE config 2 as stated ("Davis full epoch ... batch 64"): every step a DIFFERENT batch -- other proteins, other
+    N / E, a new edge_index -- launched eagerly through the nn.Module API, exactly the call pattern of
+    train_model.py:548-587 (forward of both encoders, backward with every weight gradient, dropout on).  The batches are
+    assembled on the device beforehand (inputs resident in HBM) from 442 unique protein graphs and 68 unique drug graphs,
+    the sizes of the Davis tables (data/deepdta_data/davis: 442 proteins x 68 ligands).  Two numbers: the wall time per
+    step (host issue + device, synchronised once at the end of the epoch) and the host time to issue a step."""
+    import numpy as np
+    import davis_synth as ds
+    rng = np.random.default_rng(2024)
+    n_prot, n_drug, B, steps = 442, 68, 64, args.epoch_steps
+    if args.epoch == "real":
+        lengths = ds.real_lengths("davis", n_prot, seed=7)
+    else:
+        lengths = [300] * n_prot
+    t_gen = time.perf_counter()
+    prots = [ds.protein_graph(int(L), rng, 4.0, "dist") for L in lengths]
+    drugs = [ds.drug_graph(rng) for _ in range(n_drug)]
+    f = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    P = [dict(x_s=f(g["x_s"]), x_v=f(g["x_v"]), ei=f(g["edge_index"]), e_s=f(g["e_s"]), e_v=f(g["e_v"]), nt=f(g["ntypes"]),
+              et=f(g["etypes"]), n=g["x_s"].shape[0]) for g in prots]
+    D = [dict(x=f(g["x_s"]), ei=f(g["edge_index"]), ea=f(g["e_s"]), nt=f(g["ntypes"]), et=f(g["etypes"]), n=g["x_s"].shape[0])
+         for g in drugs]
+    batches = []
+    for _ in range(steps):
+        pi, di = rng.integers(0, n_prot, B), rng.integers(0, n_drug, B)
+        off = np.concatenate([[0], np.cumsum([P[i]["n"] for i in pi])])
+        pd = dict(x=(torch.cat([P[i]["x_s"] for i in pi]), torch.cat([P[i]["x_v"] for i in pi])),
+                  edge_index=torch.cat([P[i]["ei"] + int(o) for i, o in zip(pi, off)], 1).contiguous(),
+                  ntypes=torch.cat([P[i]["nt"] for i in pi]), etypes=torch.cat([P[i]["et"] for i in pi]),
+                  eattr=(torch.cat([P[i]["e_s"] for i in pi]), torch.cat([P[i]["e_v"] for i in pi])))
+        doff = np.concatenate([[0], np.cumsum([D[i]["n"] for i in di])])
+        md = dict(x=torch.cat([D[i]["x"] for i in di]),
+                  edge_index=torch.cat([D[i]["ei"] + int(o) for i, o in zip(di, doff)], 1).contiguous(),
+                  ntypes=torch.cat([D[i]["nt"] for i in di]), etypes=torch.cat([D[i]["et"] for i in di]),
+                  eattr=torch.cat([D[i]["ea"] for i in di]))
+        if args.dtype == "bf16":
+            pd = dict(pd, x=tuple(t.bfloat16() for t in pd["x"]), eattr=tuple(t.bfloat16() for t in pd["eattr"]))
+        batches.append((pd, md, int(off[-1]), int(doff[-1])))
+    maxn, maxa = max(b[2] for b in batches), max(b[3] for b in batches)
+    gen = torch.Generator(device=dev).manual_seed(99)
+    g_res = torch.randn(maxn, 64, device=dev, generator=gen)
+    if args.dtype == "bf16":
+        g_res = g_res.bfloat16()
+    g_atm = torch.randn(maxa, 64, device=dev, generator=gen)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+    side = torch.cuda.Stream(device=dev)
+
+    def step(pd, md, n, na):
+        main_s = torch.cuda.current_stream()
+        side.wait_stream(main_s)
+        residues = model.protein_gnn(**pd)
+        with torch.cuda.stream(side):
+            atoms = model.molecule_gnn(**md)
+        if not train:
+            main_s.wait_stream(side)
+            return residues, atoms
+        gp = torch.autograd.grad([residues], prot_params, [g_res[:n]])
+        with torch.cuda.stream(side):
+            gd = torch.autograd.grad([atoms], drug_params, [g_atm[:na]])
+        main_s.wait_stream(side)
+        return gp + gd
+
+    with torch.set_grad_enabled(train):
+        for b in batches[:MIN_WARMUP]:
+            step(*b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b in batches:
+            step(*b)
+        t_issue = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+    edges = [int(b[0]["edge_index"].shape[1]) for b in batches]
+    return {"what": "one epoch of DIFFERENT batches, eager (no HIP graph), nn.Module API, C++ autograd fast path" if
+            __import__("gvp_hip._lib", fromlist=["bridge"]).bridge() is not None else
+            "one epoch of DIFFERENT batches, eager (no HIP graph), nn.Module API, Python custom ops",
+            "variant": args.epoch, "steps": steps, "pairs_per_step": B, "unique_proteins": n_prot, "unique_drugs": n_drug,
+            "ms_per_step": round(t_all / steps * 1e3, 4), "host_issue_ms_per_step": round(t_issue / steps * 1e3, 4),
+            "pairs_per_s": round(B * steps / t_all, 1),
+            "residues_per_step": [min(b[2] for b in batches), max(b[2] for b in batches)],
+            "protein_edges_per_step": [min(edges), max(edges)], "setup_s": round(t_gen, 1)}
 
 
 def _cgroup_cpus():

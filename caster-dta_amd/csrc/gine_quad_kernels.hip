@@ -662,9 +662,7 @@ int launch_fwd(GineFArgs& a, hipStream_t st) {
 #endif
   const int G = (int)(wgs < 1 ? 1 : (wgs > CGVP_GINE_FWD_MAX_WGS ? CGVP_GINE_FWD_MAX_WGS : wgs));
   const size_t lds = (size_t)((Q::GE::NFRAG + Q::G0::NFRAG + Q::G1::NFRAG) * 64 + GF_WPB * Q::ROWS) * sizeof(float);
-  if (hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(gine_quad_fwd_kernel<CIN, CHID, COUT, NT, NET, ED>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
-    return (int)err;
+  CGVP_SET_DYN_LDS_ONCE((gine_quad_fwd_kernel<CIN, CHID, COUT, NT, NET, ED>), lds);
   hipLaunchKernelGGL((gine_quad_fwd_kernel<CIN, CHID, COUT, NT, NET, ED>), dim3(G), dim3(GF_TPB), lds, st, a);
   return 0;
 }
@@ -677,9 +675,7 @@ int launch(GineQArgs& a, int cap, int* rows, int* row_len, hipStream_t st) {
   int64_t wgs = (tiles + GQ_WPB - 1) / GQ_WPB;
   const int G = (int)(wgs < 1 ? 1 : (wgs > cap ? cap : wgs));
   const size_t lds = (size_t)Q::LDS_FLOATS * sizeof(float);
-  if (hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(gine_quad_bwd_kernel<CIN, CHID, COUT, NT, NET, ED>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
-    return (int)err;
+  CGVP_SET_DYN_LDS_ONCE((gine_quad_bwd_kernel<CIN, CHID, COUT, NT, NET, ED>), lds);
   hipLaunchKernelGGL((gine_quad_bwd_kernel<CIN, CHID, COUT, NT, NET, ED>), dim3(G), dim3(GQ_TPB), lds, st, a);
   *rows = G;
   *row_len = Q::L_SIZE;

@@ -18,6 +18,23 @@ struct QuadOffsets {
 #endif
 constexpr int kBwdMaxGrid = CGVP_BWD_MAX_GRID;    // persistent workgroups of the backward kernels (one per CU) = slab rows per stage
 
+// hipFuncAttributeMaxDynamicSharedMemorySize of a kernel, set ONCE per kernel and device instead of before every launch
+// (hipFuncSetAttribute is a host call of tens of microseconds; a backward pass made 13 of them).  One static flag word per
+// expansion site, one bit per device: idempotent, benign process state (the attribute itself is process state of the runtime).
+#include <atomic>
+#define CGVP_SET_DYN_LDS_ONCE(FN, BYTES)                                                                                      \
+  do {                                                                                                                        \
+    static std::atomic<uint64_t> cgvp_done_{0};                                                                               \
+    int cgvp_dev_ = 0;                                                                                                        \
+    (void)hipGetDevice(&cgvp_dev_);                                                                                           \
+    const uint64_t cgvp_bit_ = 1ull << (cgvp_dev_ & 63);                                                                      \
+    if (!(cgvp_done_.load(std::memory_order_acquire) & cgvp_bit_)) {                                                          \
+      if (hipError_t cgvp_err_ = hipFuncSetAttribute(reinterpret_cast<const void*>(FN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES))) \
+        return (int)cgvp_err_;                                                                                                \
+      cgvp_done_.fetch_or(cgvp_bit_, std::memory_order_release);                                                              \
+    }                                                                                                                         \
+  } while (0)
+
 namespace quad {
 int offsets(int nt_node, int nt_edge, int num_convs, QuadOffsets* o);
 int prepare(const gvp::EncLayout& L, int num_convs, int packed_bf16, const float* params, float* image, hipStream_t st);

@@ -935,10 +935,10 @@ int reduce_slab(const float* slab, int rows, int stride, int col0, int len, floa
 #define BWD_LAUNCH(KERNEL, G, TPB_, LDS_, ARGS)                                                                               \
   do {                                                                                                                        \
     if (bf16) {                                                                                                               \
-      if (hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL(bf16s)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_))) return (int)err; \
+      CGVP_SET_DYN_LDS_ONCE(KERNEL(bf16s), LDS_);                                                                             \
       hipLaunchKernelGGL((KERNEL(bf16s)), dim3(G), dim3(TPB_), (LDS_), st, ARGS);                                             \
     } else {                                                                                                                  \
-      if (hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL(float)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_))) return (int)err; \
+      CGVP_SET_DYN_LDS_ONCE(KERNEL(float), LDS_);                                                                             \
       hipLaunchKernelGGL((KERNEL(float)), dim3(G), dim3(TPB_), (LDS_), st, ARGS);                                             \
     }                                                                                                                         \
   } while (0)

@@ -760,23 +760,23 @@ int pass_begin(const EncLayout& L, int num_convs, int bf16, const float* params,
 }
 
 template <int NTE, int FUSE, int EMODE, typename ST>
-void conv_launch_e(const ConvQArgs& a, dim3 grid, hipStream_t st) {
+int conv_launch_e(const ConvQArgs& a, dim3 grid, hipStream_t st) {
   const size_t lds = (size_t)(Image<0, NTE>::CV_SIZE + (FUSE == 0 ? 0 : Image<0, 0>::ND_SIZE + (FUSE == 2 ? Image<0, 0>::HD_SIZE : 0)) +
                               WPB * WAVE * ROW) * sizeof(float);
-  if (lds > 64 * 1024)      // a failure here resurfaces as the launch error launch_status() reports
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_quad_kernel<NTE, FUSE, EMODE, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 64 * 1024) CGVP_SET_DYN_LDS_ONCE((conv_quad_kernel<NTE, FUSE, EMODE, ST>), lds);      // once per kernel and device; an error is returned
   hipLaunchKernelGGL((conv_quad_kernel<NTE, FUSE, EMODE, ST>), grid, dim3(TPB), lds, st, a);
+  return 0;
 }
 template <int NTE, int FUSE, typename ST>
-void conv_launch_s(const ConvQArgs& a, dim3 grid, hipStream_t st) {
-  if (a.e_in) conv_launch_e<NTE, FUSE, 2, ST>(a, grid, st);
-  else if (a.e_out) conv_launch_e<NTE, FUSE, 1, ST>(a, grid, st);
-  else conv_launch_e<NTE, FUSE, 0, ST>(a, grid, st);
+int conv_launch_s(const ConvQArgs& a, dim3 grid, hipStream_t st) {
+  if (a.e_in) return conv_launch_e<NTE, FUSE, 2, ST>(a, grid, st);
+  if (a.e_out) return conv_launch_e<NTE, FUSE, 1, ST>(a, grid, st);
+  return conv_launch_e<NTE, FUSE, 0, ST>(a, grid, st);
 }
 template <int NTE, int FUSE>
-void conv_launch(const ConvQArgs& a, dim3 grid, int bf16, hipStream_t st) {
-  if (bf16) conv_launch_s<NTE, FUSE, bf16s>(a, grid, st);
-  else conv_launch_s<NTE, FUSE, float>(a, grid, st);
+int conv_launch(const ConvQArgs& a, dim3 grid, int bf16, hipStream_t st) {
+  if (bf16) return conv_launch_s<NTE, FUSE, bf16s>(a, grid, st);
+  return conv_launch_s<NTE, FUSE, float>(a, grid, st);
 }
 
 // fuse: 0 = conv only (dh required); 1 / 2 = the layer's node update (2: with the output head) in the same launch
@@ -797,11 +797,13 @@ int conv(int nt_edge, const float* img, const float* h, const float* e_s, const 
   if (nt_edge != 0 && nt_edge != 1) return CGVP_ERR_UNSUPPORTED_DIMS;
   if (fuse < 0 || fuse > 2) return CGVP_ERR_BAD_ARG;
   if (nt_edge == 0) {
-    if (fuse == 0) conv_launch<0, 0>(a, grid, bf16, st); else if (fuse == 1) conv_launch<0, 1>(a, grid, bf16, st); else conv_launch<0, 2>(a, grid, bf16, st);
-  } else {
-    if (fuse == 0) conv_launch<1, 0>(a, grid, bf16, st); else if (fuse == 1) conv_launch<1, 1>(a, grid, bf16, st); else conv_launch<1, 2>(a, grid, bf16, st);
+    if (fuse == 0) return conv_launch<0, 0>(a, grid, bf16, st);
+    if (fuse == 1) return conv_launch<0, 1>(a, grid, bf16, st);
+    return conv_launch<0, 2>(a, grid, bf16, st);
   }
-  return 0;
+  if (fuse == 0) return conv_launch<1, 0>(a, grid, bf16, st);
+  if (fuse == 1) return conv_launch<1, 1>(a, grid, bf16, st);
+  return conv_launch<1, 2>(a, grid, bf16, st);
 }
 
 int node_update(const float* img_node, const float* img_head, const float* h, const float* dh, int64_t N,

@@ -339,7 +339,8 @@ int cgvp_gine_fwd_workspace(const cgvp_gine_cfg* cfg, int64_t N, int64_t E, int3
   out->eperm = b.take((E > 0 ? E : 1) * 4);
   out->esrc = b.take((E > 0 ? E : 1) * 4);
   out->edst = b.take((E > 0 ? E : 1) * 4);
-  out->ids_scratch = b.take((E > 0 ? E : 1) * 4);
+  out->saved = b.off;                                    // what the backward reads ends here
+  out->ids_scratch = b.take((E > 0 ? E : 1) * 4);        // CSR build scratch: edge ids in (non-deterministic) arrival order
   out->total = b.off;
   return 0;
 }

@@ -19,7 +19,7 @@ ABI_VERSION = 24
 # sha256 of include/caster_gvp.h with comments, blank space and the CGVP_ABI_VERSION line removed, as
 # `abi_header_digest()` computes it.  tests/test_abi.py fails when the header's declarations change
 # without CGVP_ABI_VERSION, ABI_VERSION and this digest being updated together.
-ABI_HEADER_SHA256 = "446e3bdcdbfc4724f8df3735625f425cb0648e0b48e636c306c72d8b839ac316"
+ABI_HEADER_SHA256 = "d2ab5c9d1fb9551bd81e6e1b421f5e49d6dd7676d25939cfe4d8999c4ae33a63"
 
 
 class HipLibraryError(RuntimeError):
@@ -87,7 +87,7 @@ class GineBatch(C.Structure):
 
 class GineFwdWs(C.Structure):
     _fields_ = [("seed", C.c_int64), ("hidden", C.c_int64 * GINE_MAX_LAYERS)] + [(n, C.c_int64) for n in (
-        "rowptr", "eperm", "esrc", "edst", "ids_scratch", "total")]
+        "rowptr", "eperm", "esrc", "edst", "saved", "ids_scratch", "total")]
 
 
 _P = C.c_void_p

@@ -143,14 +143,16 @@ def lba_fwd_ws_bytes(N, E, num_convs, image_floats, esize, save_state):
             + _up((N + 1) * 4) + 3 * _up(e1 * 4))
 
 
-def gine_fwd_ws_bytes(N, E, widths, save_state):
+def gine_fwd_ws_bytes(N, E, widths, save_state, saved_only=False):
+    """total bytes of a GINE forward workspace; saved_only: the prefix the backward reads (everything but the CSR build's
+    scratch of edge ids in arrival order, which is not a function of the inputs)."""
     L = len(widths) - 1
     e1 = E if E > 0 else 1
     if save_state:
         hidden = sum(_up(N * widths[l + 1] * 4) for l in range(L - 1))
     else:
         hidden = 2 * _up(N * max([1] + list(widths[1:L])) * 4)
-    return _up(16) + hidden + _up((N + 1) * 4) + 4 * _up(e1 * 4)
+    return _up(16) + hidden + _up((N + 1) * 4) + (3 if saved_only else 4) * _up(e1 * 4)
 
 
 def _csr_ptrs(csr):
@@ -456,7 +458,8 @@ def gine_encoder_op(params: List[Tensor], x: Tensor, ntypes: Tensor, eattr: Tens
                                   dropout_p, save_state, torch.zeros)
     if not save_state:
         return out, ws.new_empty(0), []
-    return out, ws, masks
+    # what the op hands on is the part the backward reads: the scratch behind it holds edge ids in arrival order
+    return out, ws[:gine_fwd_ws_bytes(int(x.shape[0]), int(edge_index.shape[1]), widths, True, saved_only=True)], masks
 
 
 def gine_forward(params, x, ntypes, eattr, etypes, edge_index, csr, widths, num_ntypes, num_etypes, slope, dropout_p,
@@ -507,7 +510,7 @@ def _(params, x, ntypes, eattr, etypes, edge_index, csr, widths, num_ntypes, num
         return out, x.new_empty((0,), dtype=torch.uint8), []
     pinned = dropout_p > 0 and nl > 1 and PINNED_MASKS is not None
     masks = [x.new_empty((N, widths[l + 1]) if pinned else (0,), dtype=torch.float32) for l in range(nl - 1)]
-    ws = x.new_empty((gine_fwd_ws_bytes(N, E, widths, True),), dtype=torch.uint8)
+    ws = x.new_empty((gine_fwd_ws_bytes(N, E, widths, True, saved_only=True),), dtype=torch.uint8)
     return out, ws, masks
 
 

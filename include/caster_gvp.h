@@ -502,7 +502,9 @@ typedef struct {
 typedef struct {
   int64_t seed;                                /* uint64[2]                                                            */
   int64_t hidden[CGVP_GINE_MAX_LAYERS];        /* hidden[l]: output of layer l, l < L - 1 ([N][widths[l + 1]] fp32)     */
-  int64_t rowptr, eperm, esrc, edst, ids_scratch;
+  int64_t rowptr, eperm, esrc, edst;
+  int64_t saved;                               /* the backward pass reads bytes [0, saved) only                        */
+  int64_t ids_scratch;                         /* forward-only scratch behind them                                      */
   int64_t total;
 } cgvp_gine_fwd_ws;
 int cgvp_gine_fwd_workspace(const cgvp_gine_cfg* cfg, int64_t num_nodes, int64_t num_edges, int32_t save_state,

@@ -72,7 +72,7 @@ def test_fake_kernels_propagate_shapes_without_a_gpu(protein_params, molecule_pa
         margs = (mparams, f(Na, 41), f(Na, dt=torch.int64), f(Ea, 9), f(Ea, dt=torch.int64), f(2, Ea, dt=torch.int64), [],
                  [52, 16, 64], 11, 5, 0.01)
         out, mws, mk = torch.ops.caster_gvp.gine_encoder(*margs, 0.2, True)
-        assert out.shape == (Na, 64) and mk[0].numel() == 0 and mws.shape == (_c_gine_ws_bytes(Na, Ea, [52, 16, 64], True),)
+        assert out.shape == (Na, 64) and mk[0].numel() == 0 and mws.shape == (_c_gine_ws_bytes(Na, Ea, [52, 16, 64], True, saved_only=True),)
         gflat, gx = torch.ops.caster_gvp.gine_encoder_backward(f(Na, 64), *margs[:7], mws, mk, [52, 16, 64],
                                                                11, 5, 0.01, 0.2, True, 0)
         assert gflat.shape == (7390,) and gx.shape == (Na, 41)
@@ -89,13 +89,13 @@ def _c_lba_ws_bytes(N, E, save, storage=0, nc=2):
     return int(w.total)
 
 
-def _c_gine_ws_bytes(N, E, widths, save):
+def _c_gine_ws_bytes(N, E, widths, save, saved_only=False):
     import ctypes as C
     from gvp_hip import _lib
     cfg = autograd_ops._gine_cfg(widths, 11, 5, 9, 0.01)
     w = _lib.GineFwdWs()
     assert _lib.lib().cgvp_gine_fwd_workspace(C.byref(cfg), N, E, 1 if save else 0, C.byref(w)) == 0
-    return int(w.total)
+    return int(w.saved if saved_only else w.total)
 
 
 def test_python_workspace_formulas_match_the_library():
@@ -113,6 +113,7 @@ def test_python_workspace_formulas_match_the_library():
         for widths in ([52, 64], [52, 16, 64], [52, 16, 16, 16, 64]):
             for save in (True, False):
                 assert autograd_ops.gine_fwd_ws_bytes(N, E, widths, save) == _c_gine_ws_bytes(N, E, widths, save)
+                assert autograd_ops.gine_fwd_ws_bytes(N, E, widths, save, True) == _c_gine_ws_bytes(N, E, widths, save, True)
 
 
 # ------------------------------------------------------------------------------------------------ GPU
