@@ -167,6 +167,12 @@ __global__ void csr_fill_kernel(const int64_t* __restrict__ ei, int64_t N, int64
   int64_t s = ei[e], d = ei[E + e];
   if (s < 0 || s >= N || d < 0 || d >= N) return;
   int32_t pos = atomicAdd(&cursor[d], 1);
+  // pos < E always holds when the counters were zero on entry (the contract).  The guard makes a violated contract a wrong
+  // table instead of a wild write: round 2's recorded GPU fault ("write access to a read-only page" on replay of a captured
+  // step) was exactly this store -- the counters were then zero-filled by a captured hipMemsetAsync, which zeroes only
+  // part of its range from the second graph replay on (tools/memset_capture_probe.py), so counts accumulated over replays
+  // and `pos` ran past the E-element tables.
+  if (pos < 0 || pos >= E) return;
   tmp[pos] = (int32_t)e;
   edst[pos] = (int32_t)d;
 }
@@ -182,11 +188,17 @@ __global__ void csr_rank_kernel(const int64_t* __restrict__ ei, int64_t N, int64
                                 int32_t* __restrict__ esrc, int32_t* __restrict__ cnt) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < counters) cnt[t] = 0;
-  if (t >= rowptr[N]) {
+  if (t >= rowptr[N] || t >= E) {
     if (t < E) { eperm[t] = -1; esrc[t] = 0; edst[t] = 0; }
     return;
   }
-  const int32_t n = edst[t], lo = rowptr[n], hi = rowptr[n + 1], key = tmp[t];
+  // (the range checks below never fire on tables built from zeroed counters; they keep every access inside the
+  // E-element tables whatever the counters held -- see csr_fill_kernel)
+  const int32_t n = edst[t];
+  if (n < 0 || n >= N) return;
+  int32_t lo = rowptr[n], hi = rowptr[n + 1];
+  const int32_t key = tmp[t];
+  if (lo < 0 || hi > E || lo > hi || key < 0 || key >= E) return;
   int32_t rank = 0;
   for (int32_t j = lo; j < hi; ++j) rank += tmp[j] < key ? 1 : 0;
   eperm[lo + rank] = key;

@@ -18,12 +18,31 @@
 
 #include <c10/hip/HIPStream.h>
 
+#include <chrono>
+#include <cstdlib>
+#include <map>
+
 #include "../../include/caster_gvp.h"
 
 namespace {
 
 using torch::autograd::Node;
 using torch::autograd::variable_list;
+
+// opt-in host timing (CGVP_BRIDGE_TIMING=1): wall time per named section, reported by timing_report()
+struct Section { double total = 0; long n = 0; };
+std::map<std::string, Section>& sections() { static std::map<std::string, Section> m; return m; }
+const bool g_time = std::getenv("CGVP_BRIDGE_TIMING") != nullptr;
+struct Tic {
+  const char* name; std::chrono::steady_clock::time_point t0;
+  explicit Tic(const char* n) : name(n) { if (g_time) t0 = std::chrono::steady_clock::now(); }
+  ~Tic() {
+    if (!g_time) return;
+    Section& s = sections()[name];
+    s.total += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    ++s.n;
+  }
+};
 
 struct NotImplemented : public std::runtime_error { using std::runtime_error::runtime_error; };     // -> Python NotImplementedError
 
@@ -114,6 +133,7 @@ struct LbaBackward : public Node {
   bool need_x = false;
 
   variable_list apply(variable_list&& grads) override {
+    Tic tic_all("lba_bwd.apply");
     const size_t np = shapes.size();
     variable_list out(np + 2);
     if (grads.empty() || !grads[0].defined()) return out;
@@ -135,10 +155,14 @@ struct LbaBackward : public Node {
     cgvp_lba_batch b{N, E, (const float*)ptr(x_s), (const float*)ptr(x_v), (const int64_t*)ptr(ntypes),
                      (const float*)ptr(e_s), (const float*)ptr(e_v), (const int64_t*)ptr(etypes), nullptr,
                      t.rowptr, t.eperm, t.esrc, t.edst};
-    check(cgvp_lba_backward_pass(&cfg.dims, &cfg.layout, &b, cfg.mean, (float)dropout_p, (const float*)ptr(masks), ptr(ws),
-                                 (const float*)ptr(g_out), ptr(bws), (float*)ptr(gparams), (float*)ptr(g_x_s),
-                                 (float*)ptr(g_x_v), current_stream(x_s)),
-          "cgvp_lba_backward_pass");
+    {
+      Tic tic_c("lba_bwd.c_call");
+      check(cgvp_lba_backward_pass(&cfg.dims, &cfg.layout, &b, cfg.mean, (float)dropout_p, (const float*)ptr(masks), ptr(ws),
+                                   (const float*)ptr(g_out), ptr(bws), (float*)ptr(gparams), (float*)ptr(g_x_s),
+                                   (float*)ptr(g_x_v), current_stream(x_s)),
+            "cgvp_lba_backward_pass");
+    }
+    Tic tic_v("lba_bwd.views");
     int64_t off = 0;
     for (size_t i = 0; i < np; ++i) {
       if (task_should_compute_output(i)) out[i] = gparams.narrow(0, off, numels[i]).view(shapes[i]);
@@ -200,6 +224,7 @@ std::tuple<at::Tensor, at::Tensor, bool> lba_encoder(std::vector<at::Tensor> par
   cgvp_lba_batch b{N, E, (const float*)ptr(x_s), (const float*)ptr(x_v), (const int64_t*)ptr(ntypes),
                    (const float*)ptr(e_s), (const float*)ptr(e_v), (const int64_t*)ptr(etypes),
                    (const int64_t*)ptr(edge_index), t.rowptr, t.eperm, t.esrc, t.edst};
+  Tic tic_f("lba_fwd.c_call");
   const int rc = cgvp_lba_forward_pass(&cfg.dims, &cfg.layout, (const float*)ptr(flat), &b, cfg.mean,
                                        save_state ? (float)dropout_p : 0.f, draw ? (uint64_t*)ptr(rng_state) : nullptr,
                                        drop ? (const float*)ptr(masks) : nullptr, tables ? nullptr : (int32_t*)ptr(counters),
@@ -268,6 +293,7 @@ struct GineBackward : public Node {
   int max_workgroups = 0;
 
   variable_list apply(variable_list&& grads) override {
+    Tic tic_all("gine_bwd.apply");
     const size_t np = params.size();
     variable_list out(np + 1);
     if (grads.empty() || !grads[0].defined()) return out;
@@ -292,10 +318,13 @@ struct GineBackward : public Node {
                       (const int64_t*)ptr(etypes), nullptr, t.rowptr, t.eperm, t.esrc, t.edst};
     std::vector<const float*> mp;
     for (const at::Tensor& m : masks) mp.push_back((const float*)ptr(m));
-    check(cgvp_gine_backward_pass(&meta.cfg, w.data(), &b, (float)dropout_p, mp.empty() ? nullptr : mp.data(), ptr(ws),
-                                  (const float*)ptr(g_out), ptr(bws), (float*)ptr(gflat), (float*)ptr(g_x), max_workgroups,
-                                  current_stream(x)),
-          "cgvp_gine_backward_pass");
+    {
+      Tic tic_c("gine_bwd.c_call");
+      check(cgvp_gine_backward_pass(&meta.cfg, w.data(), &b, (float)dropout_p, mp.empty() ? nullptr : mp.data(), ptr(ws),
+                                    (const float*)ptr(g_out), ptr(bws), (float*)ptr(gflat), (float*)ptr(g_x), max_workgroups,
+                                    current_stream(x)),
+            "cgvp_gine_backward_pass");
+    }
     int64_t off = 0;
     for (size_t i = 0; i < np; ++i) {
       const int64_t n = params[i].numel();
@@ -389,4 +418,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("lba_encoder", &lba_encoder, "VectorProteinGNN_LBAModel.forward (protein_gnn.py:361-388) with autograd");
   m.def("gine_encoder", &gine_encoder, "HomoMoleculeGNN_GINE.forward (molecule_gnn.py:254-268) with autograd");
   m.def("abi_version", []() { return cgvp_abi_version(); });
+  m.def("timing_report", []() {
+    std::string r;
+    for (auto& kv : sections())
+      r += kv.first + ": " + std::to_string(kv.second.total / (kv.second.n ? kv.second.n : 1)) + " us x " + std::to_string(kv.second.n) + "\n";
+    return r;
+  }, "CGVP_BRIDGE_TIMING=1: average host microseconds per instrumented section");
 }

@@ -48,3 +48,13 @@ def test_cpp_bridge_loads_and_matches_the_abi():
     assert b is not None, "build it: bash caster-dta_amd/csrc/build_bridge.sh"
     assert b.abi_version() == _lib.ABI_VERSION
     assert callable(b.lba_encoder) and callable(b.gine_encoder)
+
+
+def test_library_never_calls_hipmemset():
+    """Captured into a HIP graph, hipMemsetAsync re-zeroes only part of its range from the second replay on (ROCm 7.2 on
+    this pool; tools/memset_capture_probe.py): the library zero-fills with its own kernel and must not
+    import any hipMemset* symbol."""
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "hipLaunchKernel" in syms or "hipModuleLaunchKernel" in syms or "__hipPushCallConfiguration" in syms
+    assert "emset" not in syms, [l for l in syms.splitlines() if "emset" in l]

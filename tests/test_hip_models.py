@@ -324,7 +324,7 @@ def test_captured_step_survives_regrow_reseed_and_frees_with_dropout_on(pretrain
     model.load_state_dict(pretrained, strict=True)
     model = model.to(DEV).train()
     p, m = ds.pair_batch(64, 0)                                   # davis_b64: 19,200 residues, ~57k edges
-    big_p, big_m = ds.pair_batch(80, 1, length=330)               # more nodes than the counters were sized for
+    big_p, big_m = ds.pair_batch(130, 1, length=320)              # 41,600 residues: more than the counters were sized for (2 x 19,264)
     pd, md = _to(ds.to_torch(p)), _to(ds.to_torch(m))
     bpd, bmd = _to(ds.to_torch(big_p)), _to(ds.to_torch(big_m))
     pp = [q for q in model.protein_gnn.parameters() if q.numel()]

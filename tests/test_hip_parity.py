@@ -254,3 +254,46 @@ def test_feature_table_wire_format(protein_params):
     assert torch.equal(out, ref)                              # same kernels, same per-edge arithmetic, same order
     for a, b in zip(g_out, g_ref):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9
+
+
+def test_csr_build_with_dirty_counters_stays_inside_its_tables():
+    """The CSR build's contract is "counters zero on entry".  Round 2's recorded GPU fault was what a violated contract
+    did then: un-zeroed counters (a captured hipMemsetAsync that re-zeroed only part of them on graph replays) sent
+    csr_fill's stores past the E-element tables.  The kernels now bound every access by E / N: with counters full of
+    garbage the tables are wrong, but nothing outside them is touched (sentinel guards on both sides of every table)
+    and the counters come back zeroed; the next build on clean counters is correct again."""
+    import ctypes as C
+    from gvp_hip import _lib
+    gb = ds.protein_batch(3, 5, lengths=[40, 77, 25])
+    ei = torch.from_numpy(gb.edge_index).to(DEV)
+    N, E = gb.num_nodes, gb.num_edges
+    G = 4096                                                     # guard ints around every table
+    arena = torch.full((5 * (E + 2 * G) + N + 1 + 2 * G,), -7, dtype=torch.int32, device=DEV)
+    tabs, off = [], 0
+    for n in (N + 1, E, E, E, E):
+        tabs.append(arena[off + G:off + G + n])
+        off += n + 2 * G
+    rowptr, eperm, esrc, edst, ids = tabs
+    L = _lib.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    counters = torch.zeros((N + 1 + 63) // 64 * 64, dtype=torch.int32, device=DEV)
+    for dirty in (1000, 2 ** 30, -5):
+        counters.fill_(dirty)
+        before = arena.clone()
+        for t in tabs:
+            t.fill_(-7)
+        before = arena.clone()
+        rc = L.cgvp_csr_from_coo(P(ei), N, E, P(rowptr), P(eperm), P(esrc), P(edst), P(counters), 1, P(ids), st)
+        torch.cuda.synchronize()
+        assert rc == 0
+        mask = torch.ones_like(arena, dtype=torch.bool)
+        for t in tabs:
+            lo = (t.data_ptr() - arena.data_ptr()) // 4
+            mask[lo:lo + t.numel()] = False
+        assert torch.equal(arena[mask], before[mask]), dirty        # every guard int untouched
+        assert int(counters.abs().max()) == 0                       # and the contract is restored for the next call
+    rc = L.cgvp_csr_from_coo(P(ei), N, E, P(rowptr), P(eperm), P(esrc), P(edst), P(counters), 1, P(ids), st)
+    torch.cuda.synchronize()
+    order = np.lexsort((np.arange(E), gb.edge_index[1]))           # stable by target, then edge id
+    assert np.array_equal(eperm.cpu().numpy(), order)

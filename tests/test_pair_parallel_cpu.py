@@ -133,3 +133,50 @@ def test_pair_parallel_world2_matches_single_process(pretrained, shards, pass_co
     k = "protein_gnn.params.gvp_to_scalar/ws/bias"
     assert np.abs(res[0][1][k] - ref[k]).max() > 1e-3 * np.abs(ref[k]).max()
     assert np.abs(res[0][1][k] + res[1][1][k] - ref[k]).max() <= 2e-4 * np.abs(ref[k]).max() + 1e-7
+
+
+@pytest.mark.timeout(420)
+def test_pair_parallel_world4_with_edge_balanced_ragged_shards(pretrained):
+    """world_size 4 over gloo, shards chosen by `shard_pairs_by_edges` (the reference's edge-balanced sampler,
+    dataset/dual_dataset.py:476-516, turned into per-rank sharding): ranks hold 2-4 pairs each; the gathered predictions
+    and every reduced gradient equal the single-process run over the same 11 pairs."""
+    import sys
+    for p in (PKG, REPO):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from gvp_hip.ops import shard_pairs_by_edges
+    lengths = [61, 24, 35, 48, 19, 55, 30, 27, 44, 22, 38]
+    edge_counts = [3 * n for n in lengths]                       # ~3 edges per residue at 4 A: what the sampler balances
+    parts = shard_pairs_by_edges(edge_counts, 4)
+    assert sorted(i for p in parts for i in p) == list(range(len(lengths))) and all(parts)
+    assert len({len(p) for p in parts}) > 1                      # ragged
+    loads = [sum(edge_counts[i] for i in p) for p in parts]
+    assert max(loads) <= sum(edge_counts) / 4 + max(edge_counts)
+    shards = [[lengths[i] for i in p] for p in parts]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, pretrained, shards, True, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        r = q.get(timeout=360)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    model = _build(pretrained)
+    outs = []
+    for rank, lens in enumerate(shards):
+        pd, md = _batches(lens, 100 + rank)
+        y = model(pd, md)[0]
+        y.square().sum().backward()
+        outs.append(y.detach().numpy())
+    full, ref = np.concatenate(outs), _grads(model)
+    for rank in range(4):
+        assert res[rank][0].shape == (len(lengths), 1)
+        assert np.allclose(res[rank][0], full, rtol=1e-5, atol=1e-6)
+        for k in GRAD_KEYS:
+            scale = np.abs(ref[k]).max()
+            assert np.abs(res[rank][2][k] - ref[k]).max() <= 2e-4 * scale + 1e-7, (k, rank)

@@ -40,3 +40,7 @@ torch.cuda.synchronize()
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(30)
 print(s.getvalue()[:7000])
+
+from gvp_hip import _lib
+if _lib.bridge() is not None and os.environ.get("CGVP_BRIDGE_TIMING"):
+    print(_lib.bridge().timing_report())
