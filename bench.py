@@ -59,7 +59,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="davis_b64", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="BASELINE.json configuration (1-based as DESIGN.md counts them): 2 = Davis batch 64 (default, "
+                         "davis_b64 f32), 3 = KIBA 32 pairs per GPU (kiba_b32 f32), 4 = long-graph stress (long_graph_x64), "
+                         "5 = BindingDB-scale CASTER-DTA(4,4) in bf16 (bindingdb_b32_44 --dtype bf16); --workload / --dtype override")
     ap.add_argument("--mode", default="fwdbwd", choices=["fwd", "fwdbwd"],
                     help="fwdbwd (default, BASELINE config 2): training step of both encoders (dropout on, forward + "
                          "backward incl. all weight gradients); fwd: inference forward only (eval mode)")
@@ -88,7 +92,7 @@ def parse():
                     help="diagnostic: workgroup cap of the GINE backward (0 = library default of 16)")
     ap.add_argument("--only", default=None, choices=["protein", "drug"],
                     help="diagnostic: time one encoder alone (the reported metric needs both; never the default)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
                     help="activation storage of the protein encoder (bf16 = BASELINE config 5: bf16 storage / fp32 "
                          "accumulate; gradients and weights stay fp32; the drug encoder stays fp32 storage)")
     ap.add_argument("--epoch", default="nominal", choices=["off", "nominal", "real"],
@@ -99,7 +103,11 @@ def parse():
     ap.add_argument("--epoch-steps", type=int, default=329, help="batches in the epoch leg (Davis: 21,039 train pairs / 64)")
     ap.add_argument("--cpu-runs", type=int, default=20, help="timed CPU-baseline runs per thread count (median)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (0 = choose for ~10-30 s)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    wl, dt = {2: ("davis_b64", "f32"), 3: ("kiba_b32", "f32"), 4: ("long_graph_x64", "f32"), 5: ("bindingdb_b32_44", "bf16")}[args.config]
+    args.workload = args.workload or wl
+    args.dtype = args.dtype or dt
+    return args
 
 
 def kernel_source_digest():
@@ -309,10 +317,16 @@ def main():
                 flat = torch.cat([g.reshape(-1) for g in out]).cpu()
                 dist.all_reduce(flat)
             return
-        dist.all_gather_into_tensor(pair_all, pair_local)
+        # the two collectives are independent: the gather runs on the side stream while the gradient bucket is packed and
+        # reduced on the main one (each is ~12 us of launch latency at these payloads; back to back they cost 24)
+        main_s = torch.cuda.current_stream()
+        side.wait_stream(main_s)
+        with torch.cuda.stream(side):
+            dist.all_gather_into_tensor(pair_all, pair_local)
         if train:
             torch.cat([g.reshape(-1) for g in out], out=grad_bucket)
             dist.all_reduce(grad_bucket)
+        main_s.wait_stream(side)
 
     with torch.set_grad_enabled(train):
         out = step()
@@ -455,6 +469,7 @@ def main():
                        "scope": args.scope, "untimed_warmup_steps": max(args.warmup, MIN_WARMUP), "torch_compile": bool(args.compile and args.scope == "joint"), "autocast": args.autocast if args.scope == "joint" else None, "train_mode": bool(dropout_on), "dropout_p": 0.2 if dropout_on else 0.0,
                        "csr_build_in_step": ("collate" if args.collate_csr else not args.cache_csr),
                        "hip_graph": graph is not None, "kernels": ops.VARIANT, "parallelism": par,
+                       "baseline_config": args.config, "rccl_ranks": (dist.get_world_size() if (dist is not None and not rehearsal) else 0),
                        "timed_region": ("replays of ONE captured step on one batch (CSR build, dropout draw and weight-image build "
                                         "inside every replay)" if graph is not None else "eager steps on one batch"),
                        "epoch": epoch},

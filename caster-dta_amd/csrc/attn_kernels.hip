@@ -103,17 +103,28 @@ __global__ __launch_bounds__(TPB) void attn_fwd_kernel(Args a) {
   if (qv) qs = *reinterpret_cast<const f4*>(P.q + qr * E + col + 4 * g) * a.scale;
   f4 acc = {0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, l = 0.f;
-  for (int64_t kb = k0; kb < k_end; kb += TILE) {
-    // S^T tile: lane (m = key, g) supplies K[key][4g..4g+3]; k-slot (s, g) <-> dim 4g + s on both operands
+  // The key-tile loop is a dependent chain (loads -> 4 MFMAs -> exp -> 4 MFMAs) and a pair's atoms attend to ~19 residue
+  // tiles: the NEXT tile's K / V rows are loaded while the current one is computed (one global-load latency per wave
+  // instead of one per key tile).
+  //   S^T tile: lane (m = key, g) supplies K[key][4g..4g+3]; k-slot (s, g) <-> dim 4g + s on both operands
+  //   V^T operand: lane (m = d, g), slot r <-> key kb + 4g + r
+  auto load_tile = [&](int64_t kb, f4& kk, float (&va)[4]) {
     const int64_t kr = kb + n;
-    f4 kk = {0.f, 0.f, 0.f, 0.f};
+    kk = f4{0.f, 0.f, 0.f, 0.f};
     if (kr < k_end) kk = *reinterpret_cast<const f4*>(P.k + kr * E + col + 4 * g);
-    float va[4];                                            // V^T operand: lane (m = d, g), slot r <-> key kb + 4g + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t key = kb + 4 * g + r;
       va[r] = key < k_end ? P.v[key * E + col + n] : 0.f;
     }
+  };
+  f4 kk_n;
+  float va_n[4];
+  load_tile(k0, kk_n, va_n);
+  for (int64_t kb = k0; kb < k_end; kb += TILE) {
+    const f4 kk = kk_n;
+    const float va[4] = {va_n[0], va_n[1], va_n[2], va_n[3]};
+    load_tile(kb + TILE, kk_n, va_n);                       // past the end: all-zero tile, never used
     f4 st = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4; ++s) st = mfma(kk[s], qs[s], st);
@@ -171,19 +182,29 @@ __global__ __launch_bounds__(TPB) void attn_bwd_dq_kernel(Args a) {
   dl = quad_sum(dl);
   if (qv && g == 0) P.delta[qr * a.H + h] = dl;
   f4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t kb = k0; kb < k_end; kb += TILE) {
+  // next key tile prefetched while the current one is computed (see attn_fwd_kernel)
+  //   ka: K^T operand for d Qs: lane (m = d, g), slot r <-> key kb + 4g + r
+  auto load_tile = [&](int64_t kb, f4& kk, f4& vv, float (&ka)[4]) {
     const int64_t kr = kb + n;
-    f4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+    kk = f4{0.f, 0.f, 0.f, 0.f};
+    vv = f4{0.f, 0.f, 0.f, 0.f};
     if (kr < k_end) {
       kk = *reinterpret_cast<const f4*>(P.k + kr * E + col + 4 * g);
       vv = *reinterpret_cast<const f4*>(P.v + kr * E + col + 4 * g);
     }
-    float ka[4];                                            // K^T operand for d Qs: lane (m = d, g), slot r <-> key kb + 4g + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t key = kb + 4 * g + r;
       ka[r] = key < k_end ? P.k[key * E + col + n] : 0.f;
     }
+  };
+  f4 kk_n, vv_n;
+  float ka_n[4];
+  load_tile(k0, kk_n, vv_n, ka_n);
+  for (int64_t kb = k0; kb < k_end; kb += TILE) {
+    const f4 kk = kk_n, vv = vv_n;
+    const float ka[4] = {ka_n[0], ka_n[1], ka_n[2], ka_n[3]};
+    load_tile(kb + TILE, kk_n, vv_n, ka_n);
     f4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4; ++s) { st = mfma(kk[s], qs[s], st); dp = mfma(vv[s], go[s], dp); }
@@ -225,23 +246,33 @@ __global__ __launch_bounds__(TPB) void attn_bwd_dkv_kernel(Args a) {
     vv = *reinterpret_cast<const f4*>(P.v + kr * E + col + 4 * g);
   }
   f4 accv = {0.f, 0.f, 0.f, 0.f}, acck = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t qb = q0; qb < q_end; qb += TILE) {
+  // next query tile prefetched while the current one is computed (an atom-key tile loops over ~19 residue tiles)
+  struct QT { f4 qa, ga; float lse[4], dl[4], qt[4], gt[4]; };
+  auto load_tile = [&](int64_t qb, QT& T) {
     const int64_t qm = qb + n;                              // this lane's row as the M index of the two score products
-    f4 qa = {0.f, 0.f, 0.f, 0.f}, ga = {0.f, 0.f, 0.f, 0.f};
+    T.qa = f4{0.f, 0.f, 0.f, 0.f};
+    T.ga = f4{0.f, 0.f, 0.f, 0.f};
     if (qm < q_end) {
-      qa = *reinterpret_cast<const f4*>(P.q + qm * E + col + 4 * g) * a.scale;
-      ga = *reinterpret_cast<const f4*>(P.g_out + qm * E + col + 4 * g);
+      T.qa = *reinterpret_cast<const f4*>(P.q + qm * E + col + 4 * g) * a.scale;
+      T.ga = *reinterpret_cast<const f4*>(P.g_out + qm * E + col + 4 * g);
     }
-    float lse[4], dl[4], qt[4], gt[4];                      // per k-slot r <-> query qb + 4g + r
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < 4; ++r) {                           // per k-slot r <-> query qb + 4g + r
       const int64_t q = qb + 4 * g + r;
       const bool ok = q < q_end;
-      lse[r] = ok ? P.lse[q * a.H + h] : 0.f;
-      dl[r] = ok ? P.delta[q * a.H + h] : 0.f;
-      qt[r] = ok ? P.q[q * E + col + n] * a.scale : 0.f;    // Qs^T operand: lane (m = d, g)
-      gt[r] = ok ? P.g_out[q * E + col + n] : 0.f;          // dO^T operand
+      T.lse[r] = ok ? P.lse[q * a.H + h] : 0.f;
+      T.dl[r] = ok ? P.delta[q * a.H + h] : 0.f;
+      T.qt[r] = ok ? P.q[q * E + col + n] * a.scale : 0.f;  // Qs^T operand: lane (m = d, g)
+      T.gt[r] = ok ? P.g_out[q * E + col + n] : 0.f;        // dO^T operand
     }
+  };
+  QT nxt;
+  load_tile(q0, nxt);
+  for (int64_t qb = q0; qb < q_end; qb += TILE) {
+    const QT cur = nxt;
+    load_tile(qb + TILE, nxt);
+    const f4 qa = cur.qa, ga = cur.ga;
+    const float (&lse)[4] = cur.lse, (&dl)[4] = cur.dl, (&qt)[4] = cur.qt, (&gt)[4] = cur.gt;
     f4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int x = 0; x < 4; ++x) { s = mfma(qa[x], kk[x], s); dp = mfma(ga[x], vv[x], dp); }

@@ -125,7 +125,7 @@ struct LbaBackward : public Node {
   LbaCfg cfg;
   at::Tensor x_s, x_v, ntypes, e_s, e_v, etypes, ws, masks;
   std::vector<at::Tensor> csr;
-  std::vector<std::vector<int64_t>> shapes;
+  std::vector<std::vector<int64_t>> shapes, strides;
   std::vector<int64_t> numels;
   at::ScalarType x_dtype;
   int64_t N = 0, E = 0;
@@ -164,8 +164,8 @@ struct LbaBackward : public Node {
     }
     Tic tic_v("lba_bwd.views");
     int64_t off = 0;
-    for (size_t i = 0; i < np; ++i) {
-      if (task_should_compute_output(i)) out[i] = gparams.narrow(0, off, numels[i]).view(shapes[i]);
+    for (size_t i = 0; i < np; ++i) {      // one view op per parameter (as_strided), not narrow + view
+      if (task_should_compute_output(i)) out[i] = gparams.as_strided(shapes[i], strides[i], off);
       off += numels[i];
     }
     if (need_x) {
@@ -249,7 +249,12 @@ std::tuple<at::Tensor, at::Tensor, bool> lba_encoder(std::vector<at::Tensor> par
     node->N = N; node->E = E; node->dropout_p = drop ? dropout_p : 0.0; node->need_x = need_x;
     node->x_dtype = x_s_in.scalar_type();
     node->shapes.reserve(params.size());
-    for (const at::Tensor& p : params) { node->shapes.push_back(p.sizes().vec()); node->numels.push_back(p.numel()); }
+    node->strides.reserve(params.size());
+    for (const at::Tensor& p : params) {
+      node->shapes.push_back(p.sizes().vec());
+      { auto st = c10::contiguous_strides(p.sizes()); node->strides.emplace_back(st.begin(), st.end()); }
+      node->numels.push_back(p.numel());
+    }
     torch::autograd::set_history(out, node);
   }
   return {out, ws, zero_copy};
@@ -328,7 +333,7 @@ struct GineBackward : public Node {
     int64_t off = 0;
     for (size_t i = 0; i < np; ++i) {
       const int64_t n = params[i].numel();
-      if (task_should_compute_output(i)) out[i] = gflat.narrow(0, off, n).view(params[i].sizes());
+      if (task_should_compute_output(i)) out[i] = gflat.as_strided(params[i].sizes(), c10::contiguous_strides(params[i].sizes()), off);
       off += n;
     }
     if (need_x) out[np] = g_x;

@@ -19,7 +19,7 @@ ABI_VERSION = 24
 # sha256 of include/caster_gvp.h with comments, blank space and the CGVP_ABI_VERSION line removed, as
 # `abi_header_digest()` computes it.  tests/test_abi.py fails when the header's declarations change
 # without CGVP_ABI_VERSION, ABI_VERSION and this digest being updated together.
-ABI_HEADER_SHA256 = "d2ab5c9d1fb9551bd81e6e1b421f5e49d6dd7676d25939cfe4d8999c4ae33a63"
+ABI_HEADER_SHA256 = "8146ebf7cfb39ae8170102f5dcb4366aa0b91cdb3e5038c0b321b86f623a30c8"
 
 
 class HipLibraryError(RuntimeError):
@@ -143,6 +143,8 @@ _SIGNATURES = {
     "cgvp_gine_bwd_workspace_bytes": (C.c_int64, [C.POINTER(GineCfg), _I64, _I64]),
     "cgvp_gine_backward_pass": (C.c_int, [C.POINTER(GineCfg), C.POINTER(GineW), C.POINTER(GineBatch), C.c_float, _P, _P,
                                           _P, _P, _P, _P, _I32, _P]),
+    "cgvp_linear_wgrad_workspace_floats": (C.c_int64, [_I64, _I32, _I32]),
+    "cgvp_linear_wgrad": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P, _P]),
     "cgvp_debug_kernel_timing": (C.c_int, [_I32]),
     "cgvp_debug_kernel_times": (C.c_int, [_P, _P, _I32]),
     "cgvp_gine_bwd_workspace_floats": (C.c_int64, []),

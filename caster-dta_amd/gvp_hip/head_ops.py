@@ -1,0 +1,75 @@
+"""Row-wise nn.Linear layers of the joint head with hand-written weight-gradient kernels.
+
+The head applies Linear layers to every residue / atom row of the batch (joint_gnn.py:188-198 residue / atom stacks,
+:376-389 attention projections and feed-forward).  Forward and input gradient are ordinary GEMMs (library calls); the
+WEIGHT and BIAS gradients reduce over all rows into a 128..384 x 64..256 output, a shape the library serves badly
+(44-60 us per layer at 19,200 rows, plus a column-sum kernel per bias; twelve layers per step).  `fast_linear` routes
+exactly those through ``caster_gvp::linear_wgrad`` (csrc/linear_kernels.hip: rows split over the chip, fp32 MFMA,
+fixed-order reduce) and is `F.linear` everywhere else (small row counts, other dtypes, shapes the kernel is not
+compiled for, no gradient wanted).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from .ops import _f32, _ptr, _stream
+
+MIN_ROWS = 1024          # below this the library GEMM is latency-bound either way
+
+
+@torch.library.custom_op("caster_gvp::linear_wgrad", mutates_args=(), device_types="cuda")
+def linear_wgrad_op(x: Tensor, gy: Tensor) -> Tensor:
+    """x [R, I], gy [R, O] -> flat [O * I + O]: d weight ([O, I] row-major) followed by d bias."""
+    L = _lib.lib()
+    x, gy = _f32(x, "x"), _f32(gy, "grad_output")
+    R, I, O = int(x.shape[0]), int(x.shape[1]), int(gy.shape[1])
+    if gy.shape[0] != R:
+        raise ValueError("x and grad_output hold different numbers of rows")
+    n = int(L.cgvp_linear_wgrad_workspace_floats(R, I, O))
+    if n < 0:
+        _lib.check(n, "cgvp_linear_wgrad_workspace_floats")
+    ws = torch.empty(max(n, 1), dtype=torch.float32, device=x.device)
+    out = torch.empty(O * I + O, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(L.cgvp_linear_wgrad(_ptr(x), _ptr(gy), R, I, O, _ptr(ws), _ptr(out), _stream()), "cgvp_linear_wgrad")
+    return out
+
+
+@linear_wgrad_op.register_fake
+def _(x, gy):
+    I, O = x.shape[1], gy.shape[1]
+    return x.new_empty((O * I + O,), dtype=torch.float32)
+
+
+def supported(x, weight, bias):
+    O, I = weight.shape
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and bias is not None and I % 16 == 0 and 16 <= I <= 256 and O % 64 == 0 and x.shape[0] >= MIN_ROWS
+            and torch.is_grad_enabled() and weight.requires_grad and not torch.is_autocast_enabled("cuda"))
+
+
+class _FastLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        O, I = weight.shape
+        flat = torch.ops.caster_gvp.linear_wgrad(x, gy)
+        return gx, flat[:O * I].view(O, I), flat[O * I:]
+
+
+def fast_linear(x, weight, bias):
+    """F.linear(x, weight, bias) whose weight / bias gradients come from the split-row kernel when the shape qualifies."""
+    if supported(x, weight, bias):
+        return _FastLinear.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)

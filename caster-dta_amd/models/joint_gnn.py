@@ -201,8 +201,9 @@ class JointGNN(nn.Module):
         return as_dict(protein_graph), as_dict(molecule_graph)
 
     def _stack(self, t, lins, norms):
+        from gvp_hip.head_ops import fast_linear      # F.linear; weight gradients of the per-row layers by the split-row kernel
         for lin, norm in zip(lins, norms):
-            t = self.dropout(self.activation(norm(lin(t))))
+            t = self.dropout(self.activation(norm(fast_linear(t, lin.weight, lin.bias))))
         return t
 
     def _pool(self, dense, mask):
@@ -372,16 +373,24 @@ class CrossAttentionModule(nn.Module):
     @staticmethod
     def _qkv(mha, x_q, x_kv):
         """nn.MultiheadAttention's input projections on compact rows (three library GEMMs, contiguous outputs)."""
+        from gvp_hip.head_ops import fast_linear
         E = mha.embed_dim
         b = mha.in_proj_bias
+        if mha._qkv_same_embed_dim and b is not None:
+            # K and V read the same rows and their weights are adjacent in in_proj_weight: ONE [*, 2E] GEMM, split by
+            # column views (what the attention kernel takes: rows of stride 2E would need a copy, so the halves are
+            # made contiguous -- still two launches fewer per direction, forward and backward)
+            W = mha.in_proj_weight
+            q = fast_linear(x_q, W[:E], b[:E])
+            kv = fast_linear(x_kv, W[E:], b[E:])
+            return q, kv[:, :E].contiguous(), kv[:, E:].contiguous()
         bq, bk, bv = (b[:E], b[E:2 * E], b[2 * E:]) if b is not None else (None, None, None)
         if mha._qkv_same_embed_dim:
             W = mha.in_proj_weight
             wq, wk, wv = W[:E], W[E:2 * E], W[2 * E:]
         else:
             wq, wk, wv = mha.q_proj_weight, mha.k_proj_weight, mha.v_proj_weight
-        lin = nn.functional.linear
-        return lin(x_q, wq, bq), lin(x_kv, wk, bk), lin(x_kv, wv, bv)
+        return fast_linear(x_q, wq, bq), fast_linear(x_kv, wk, bk), fast_linear(x_kv, wv, bv)
 
     def forward_varlen(self, embed_1, embed_2, ptr1, ptr2, need_weights=False):
         """`forward` on compact rows: embed_1 [N1, D] with graph offsets ptr1, embed_2 [N2, D] with ptr2; every
@@ -394,7 +403,9 @@ class CrossAttentionModule(nn.Module):
         q2, k2, v2 = self._qkv(self.embed2_to_1, n2, n1)
         heads = self.embed1_to_2.num_heads
         o1, o2, lse1, lse2 = torch.ops.caster_gvp.cross_attention(q1, k1, v1, q2, k2, v2, ptr1, ptr2, heads)
-        a1, a2 = self.embed1_to_2.out_proj(o1), self.embed2_to_1.out_proj(o2)
+        from gvp_hip.head_ops import fast_linear
+        a1 = fast_linear(o1, self.embed1_to_2.out_proj.weight, self.embed1_to_2.out_proj.bias)
+        a2 = fast_linear(o2, self.embed2_to_1.out_proj.weight, self.embed2_to_1.out_proj.bias)
         weights = None
         if need_weights:
             l1 = int((ptr1[1:] - ptr1[:-1]).max()) if ptr1.numel() > 1 else 0      # inference only: host sync
@@ -403,10 +414,12 @@ class CrossAttentionModule(nn.Module):
                                                                          q2.detach(), k2.detach(), lse2.detach(),
                                                                          ptr1, ptr2, heads, l1, l2))
         if self.include_residual_stream:
+            def ff(seq, t):          # nn.Sequential(Linear, ReLU, Dropout, Linear) with the row-wise Linear layers on fast_linear
+                return fast_linear(seq[2](seq[1](fast_linear(t, seq[0].weight, seq[0].bias))), seq[3].weight, seq[3].bias)
             embed_1 = embed_1 + self.ff_dropout(a1)
-            embed_1 = embed_1 + self.ff_dropout(self.ff1(self.ff_norm1(embed_1)))
+            embed_1 = embed_1 + self.ff_dropout(ff(self.ff1, self.ff_norm1(embed_1)))
             embed_2 = embed_2 + self.ff_dropout(a2)
-            embed_2 = embed_2 + self.ff_dropout(self.ff2(self.ff_norm2(embed_2)))
+            embed_2 = embed_2 + self.ff_dropout(ff(self.ff2, self.ff_norm2(embed_2)))
         else:
             embed_1, embed_2 = a1, a2
         return embed_1, embed_2, weights

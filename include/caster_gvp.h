@@ -522,6 +522,18 @@ int cgvp_gine_backward_pass(const cgvp_gine_cfg* cfg, const cgvp_gine_w* w, cons
                             float dropout_p, const float* const* masks, const void* fwd_workspace, const float* g_out,
                             void* bwd_workspace, float* grad_flat, float* g_x, int32_t max_workgroups, void* stream);
 
+/* ------------------------------------------------------------ ROW-WISE LINEAR LAYERS OF THE HEAD: weight gradients
+ * The joint head applies nn.Linear layers to every residue / atom row (joint_gnn.py:188-198, :376-389).  Their weight and
+ * bias gradients reduce over ALL rows of the batch into a tiny output:
+ *     out[o * I + i] = sum_r gy[r][o] x[r][i]   (o < O, i < I)        out[O * I + o] = sum_r gy[r][o]
+ * x [R][I], gy [R][O] fp32 row-major; out [O * I + O] (every element stored); workspace of
+ * cgvp_linear_wgrad_workspace_floats(R, I, O) floats (per-split partial sums; < 0 = unsupported shape).
+ * I a multiple of 16 up to 256, O a multiple of 64.  Two launches (split-row MFMA kernel, fixed-order reduce):
+ * deterministic, exact fp32. */
+int64_t cgvp_linear_wgrad_workspace_floats(int64_t num_rows, int32_t in_features, int32_t out_features);
+int cgvp_linear_wgrad(const float* x, const float* gy, int64_t num_rows, int32_t in_features, int32_t out_features,
+                      float* workspace, float* out, void* stream);
+
 /* ------------------------------------------------------------ DIAGNOSTICS
  * The ONE piece of process-global state in the library, off by default, not thread-safe; bench.py's roofline leg uses
  * it to time the dominant kernel in situ: while enabled, the whole-pass entry points bracket every conv-layer launch

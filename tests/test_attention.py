@@ -115,10 +115,17 @@ def test_module_varlen_equals_dense_mha():
 
 
 @pytest.mark.gpu
-def test_joint_model_all_gradients_vs_oracle(pretrained):
+@pytest.mark.parametrize("wgrad_kernel", [False, True])
+def test_joint_model_all_gradients_vs_oracle(pretrained, wgrad_kernel, monkeypatch):
     """Encoders (HIP) + varlen head vs the oracle's dense formulation: prediction and the gradient of EVERY one of the
-    764,396 parameters on a ragged batch."""
+    764,396 parameters on a ragged batch.  wgrad_kernel: the head's per-row Linear layers take their weight / bias
+    gradients from caster_gvp::linear_wgrad (what a training batch's row counts select; forced here at 332 rows)."""
+    from gvp_hip import head_ops
     from models.joint_gnn import JointGNN
+    monkeypatch.setattr(head_ops, "MIN_ROWS", 1 if wgrad_kernel else 1 << 40)
+    calls = []
+    real = head_ops._FastLinear.apply
+    monkeypatch.setattr(head_ops._FastLinear, "apply", staticmethod(lambda *a: (calls.append(1), real(*a))[1]))
     kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))
     model = JointGNN(protein_gnn_kwargs=kw["protein_gnn_kwargs"], molecule_gnn_kwargs=kw["molecule_gnn_kwargs"],
                      **kw["joint_gnn_kwargs"])
@@ -147,7 +154,46 @@ def test_joint_model_all_gradients_vs_oracle(pretrained):
         assert err <= 5e-4 * float(want.abs().max()) + 2e-6 * scale, (name, err, float(want.abs().max()))
         n += 1
     assert n >= 100
+    assert (len(calls) >= 12) == wgrad_kernel            # 2 stacks + 2 x (q, kv, out, ff0, ff1)
     model.train()
     model.attention_weights = "auto"
     _, none = model(dp, dm)
     assert none is None                                  # training: the weights are not materialised
+
+
+
+@pytest.mark.parametrize("R,I,O", [(19200, 128, 384), (2560, 64, 128), (5003, 256, 128), (1031, 128, 256), (7, 128, 128),
+                                   (0, 64, 128), (40000, 128, 128)])
+def test_linear_wgrad_kernel_matches_torch(R, I, O):
+    """caster_gvp::linear_wgrad (split-row MFMA kernel + fixed-order reduce) vs the matmuls autograd would run, in fp64:
+    rows that are no multiple of the 64-row LDS chunk or of the 4-row k-step, one chunk, no rows; run-to-run bitwise."""
+    from gvp_hip import head_ops  # noqa: F401
+    gen = torch.Generator(device=DEV).manual_seed(R + I + O)
+    x = torch.randn(R, I, device=DEV, generator=gen)
+    gy = torch.randn(R, O, device=DEV, generator=gen)
+    out = torch.ops.caster_gvp.linear_wgrad(x, gy)
+    gw, gb = out[:O * I].view(O, I), out[O * I:]
+    want_w = (gy.double().t() @ x.double())
+    want_b = gy.double().sum(0)
+    scale = max(1.0, float(want_w.abs().max()))
+    assert float((gw.double() - want_w).abs().max()) <= 2e-6 * scale * max(1, R) ** 0.5
+    assert float((gb.double() - want_b).abs().max()) <= 2e-6 * max(1.0, float(want_b.abs().max())) * max(1, R) ** 0.5
+    assert torch.equal(out, torch.ops.caster_gvp.linear_wgrad(x, gy))
+    torch.library.opcheck(torch.ops.caster_gvp.linear_wgrad.default, (x[:300], gy[:300])) if R >= 300 else None
+
+
+def test_fast_linear_is_f_linear_with_the_same_gradients():
+    from gvp_hip import head_ops
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(4099, 128, device=DEV, generator=gen, requires_grad=True)
+    lin = torch.nn.Linear(128, 256).to(DEV)
+    r = torch.randn(4099, 256, device=DEV, generator=gen)
+    assert head_ops.supported(x, lin.weight, lin.bias)
+    y = head_ops.fast_linear(x, lin.weight, lin.bias)
+    gx, gw, gb = torch.autograd.grad(y, [x, lin.weight, lin.bias], r)
+    y0 = torch.nn.functional.linear(x, lin.weight, lin.bias)
+    hx, hw, hb = torch.autograd.grad(y0, [x, lin.weight, lin.bias], r)
+    assert torch.equal(y, y0) and torch.equal(gx, hx)
+    assert rel_err(gw, hw) < 1e-5 and rel_err(gb, hb) < 1e-5
+    assert not head_ops.supported(x[:100], lin.weight, lin.bias)            # few rows: the library GEMM
+    assert not head_ops.supported(x, torch.nn.Linear(128, 100).to(DEV).weight, lin.bias)
