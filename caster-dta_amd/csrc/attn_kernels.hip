@@ -82,14 +82,21 @@ __device__ __forceinline__ bool locate(const int64_t* __restrict__ ptr, int B, i
   return false;
 }
 
+// The problem a wave works on, BY VALUE and selected with a wave-uniform index: `const Prob& P = a.p[pi]` with an index the
+// compiler cannot prove uniform turned every P.k / P.v / ... inside the loops into a vector load of the pointer from the
+// kernel-argument segment followed by s_waitcnt vmcnt(0) -- five dependent load pairs per key tile, 70-83 us per launch
+// for 6 us of matrix work (profiles/r03/kernel_stats_davis_b64_joint_before.csv).
+__device__ __forceinline__ Prob pick(const Args& a, int pi) { return pi ? a.p[1] : a.p[0]; }
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 // ------------------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(TPB) void attn_fwd_kernel(Args a) {
   const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
-  int64_t u = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+  int64_t u = (int64_t)blockIdx.x * WPB + wave_id();
   int pi = 0;
   if (u >= (int64_t)a.p[0].units_q * a.H) { u -= (int64_t)a.p[0].units_q * a.H; pi = 1; }
   if (pi >= a.nprob) return;
-  const Prob& P = a.p[pi];
+  const Prob P = pick(a, pi);
   if (u >= (int64_t)P.units_q * a.H) return;
   const int h = (int)(u % a.H), t = (int)(u / a.H);
   int b;
@@ -108,19 +115,23 @@ __global__ __launch_bounds__(TPB) void attn_fwd_kernel(Args a) {
   // instead of one per key tile).
   //   S^T tile: lane (m = key, g) supplies K[key][4g..4g+3]; k-slot (s, g) <-> dim 4g + s on both operands
   //   V^T operand: lane (m = d, g), slot r <-> key kb + 4g + r
+  // (loads are UNCONDITIONAL on rows clamped to the pair's last key and zeroed afterwards: with loads under lane masks
+  // the compiler cannot count what is outstanding and waits for vmcnt(0), i.e. for the prefetch it has just issued)
+  const int64_t k_last = k_end - 1;
   auto load_tile = [&](int64_t kb, f4& kk, float (&va)[4]) {
     const int64_t kr = kb + n;
-    kk = f4{0.f, 0.f, 0.f, 0.f};
-    if (kr < k_end) kk = *reinterpret_cast<const f4*>(P.k + kr * E + col + 4 * g);
+    kk = *reinterpret_cast<const f4*>(P.k + (kr < k_end ? kr : k_last) * E + col + 4 * g);
+    if (kr >= k_end) kk = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t key = kb + 4 * g + r;
-      va[r] = key < k_end ? P.v[key * E + col + n] : 0.f;
+      const float x = P.v[(key < k_end ? key : k_last) * E + col + n];
+      va[r] = key < k_end ? x : 0.f;
     }
   };
-  f4 kk_n;
-  float va_n[4];
-  load_tile(k0, kk_n, va_n);
+  f4 kk_n = {0.f, 0.f, 0.f, 0.f};
+  float va_n[4] = {0.f, 0.f, 0.f, 0.f};
+  if (k0 < k_end) load_tile(k0, kk_n, va_n);
   for (int64_t kb = k0; kb < k_end; kb += TILE) {
     const f4 kk = kk_n;
     const float va[4] = {va_n[0], va_n[1], va_n[2], va_n[3]};
@@ -156,11 +167,11 @@ __global__ __launch_bounds__(TPB) void attn_fwd_kernel(Args a) {
 // Same orientation as the forward.  Also writes delta[q][h] = sum_d dO[q][d] O[q][d] for the d K / d V kernel.
 __global__ __launch_bounds__(TPB) void attn_bwd_dq_kernel(Args a) {
   const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
-  int64_t u = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+  int64_t u = (int64_t)blockIdx.x * WPB + wave_id();
   int pi = 0;
   if (u >= (int64_t)a.p[0].units_q * a.H) { u -= (int64_t)a.p[0].units_q * a.H; pi = 1; }
   if (pi >= a.nprob) return;
-  const Prob& P = a.p[pi];
+  const Prob P = pick(a, pi);
   if (u >= (int64_t)P.units_q * a.H) return;
   const int h = (int)(u % a.H), t = (int)(u / a.H);
   int b;
@@ -184,23 +195,22 @@ __global__ __launch_bounds__(TPB) void attn_bwd_dq_kernel(Args a) {
   f4 acc = {0.f, 0.f, 0.f, 0.f};
   // next key tile prefetched while the current one is computed (see attn_fwd_kernel)
   //   ka: K^T operand for d Qs: lane (m = d, g), slot r <-> key kb + 4g + r
+  const int64_t k_last = k_end - 1;
   auto load_tile = [&](int64_t kb, f4& kk, f4& vv, float (&ka)[4]) {
-    const int64_t kr = kb + n;
-    kk = f4{0.f, 0.f, 0.f, 0.f};
-    vv = f4{0.f, 0.f, 0.f, 0.f};
-    if (kr < k_end) {
-      kk = *reinterpret_cast<const f4*>(P.k + kr * E + col + 4 * g);
-      vv = *reinterpret_cast<const f4*>(P.v + kr * E + col + 4 * g);
-    }
+    const int64_t kr = kb + n, krc = kr < k_end ? kr : k_last;
+    kk = *reinterpret_cast<const f4*>(P.k + krc * E + col + 4 * g);
+    vv = *reinterpret_cast<const f4*>(P.v + krc * E + col + 4 * g);
+    if (kr >= k_end) { kk = f4{0.f, 0.f, 0.f, 0.f}; vv = f4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t key = kb + 4 * g + r;
-      ka[r] = key < k_end ? P.k[key * E + col + n] : 0.f;
+      const float x = P.k[(key < k_end ? key : k_last) * E + col + n];
+      ka[r] = key < k_end ? x : 0.f;
     }
   };
-  f4 kk_n, vv_n;
-  float ka_n[4];
-  load_tile(k0, kk_n, vv_n, ka_n);
+  f4 kk_n = {0.f, 0.f, 0.f, 0.f}, vv_n = {0.f, 0.f, 0.f, 0.f};
+  float ka_n[4] = {0.f, 0.f, 0.f, 0.f};
+  if (k0 < k_end) load_tile(k0, kk_n, vv_n, ka_n);
   for (int64_t kb = k0; kb < k_end; kb += TILE) {
     const f4 kk = kk_n, vv = vv_n;
     const float ka[4] = {ka_n[0], ka_n[1], ka_n[2], ka_n[3]};
@@ -226,11 +236,11 @@ __global__ __launch_bounds__(TPB) void attn_bwd_dq_kernel(Args a) {
 //   dK[key][d]  = D[m = d][n = key] += sum_q Qs[q][d] dS[q][key]
 __global__ __launch_bounds__(TPB) void attn_bwd_dkv_kernel(Args a) {
   const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
-  int64_t u = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+  int64_t u = (int64_t)blockIdx.x * WPB + wave_id();
   int pi = 0;
   if (u >= (int64_t)a.p[0].units_k * a.H) { u -= (int64_t)a.p[0].units_k * a.H; pi = 1; }
   if (pi >= a.nprob) return;
-  const Prob& P = a.p[pi];
+  const Prob P = pick(a, pi);
   if (u >= (int64_t)P.units_k * a.H) return;
   const int h = (int)(u % a.H), t = (int)(u / a.H);
   int b;
@@ -248,26 +258,25 @@ __global__ __launch_bounds__(TPB) void attn_bwd_dkv_kernel(Args a) {
   f4 accv = {0.f, 0.f, 0.f, 0.f}, acck = {0.f, 0.f, 0.f, 0.f};
   // next query tile prefetched while the current one is computed (an atom-key tile loops over ~19 residue tiles)
   struct QT { f4 qa, ga; float lse[4], dl[4], qt[4], gt[4]; };
+  const int64_t q_last = q_end - 1;
   auto load_tile = [&](int64_t qb, QT& T) {
-    const int64_t qm = qb + n;                              // this lane's row as the M index of the two score products
-    T.qa = f4{0.f, 0.f, 0.f, 0.f};
-    T.ga = f4{0.f, 0.f, 0.f, 0.f};
-    if (qm < q_end) {
-      T.qa = *reinterpret_cast<const f4*>(P.q + qm * E + col + 4 * g) * a.scale;
-      T.ga = *reinterpret_cast<const f4*>(P.g_out + qm * E + col + 4 * g);
-    }
+    const int64_t qm = qb + n, qmc = qm < q_end ? qm : q_last;     // this lane's row as the M index of the two score products
+    T.qa = *reinterpret_cast<const f4*>(P.q + qmc * E + col + 4 * g) * a.scale;
+    T.ga = *reinterpret_cast<const f4*>(P.g_out + qmc * E + col + 4 * g);
+    if (qm >= q_end) { T.qa = f4{0.f, 0.f, 0.f, 0.f}; T.ga = f4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {                           // per k-slot r <-> query qb + 4g + r
-      const int64_t q = qb + 4 * g + r;
+      const int64_t q = qb + 4 * g + r, qc = q < q_end ? q : q_last;
       const bool ok = q < q_end;
-      T.lse[r] = ok ? P.lse[q * a.H + h] : 0.f;
-      T.dl[r] = ok ? P.delta[q * a.H + h] : 0.f;
-      T.qt[r] = ok ? P.q[q * E + col + n] * a.scale : 0.f;  // Qs^T operand: lane (m = d, g)
-      T.gt[r] = ok ? P.g_out[q * E + col + n] : 0.f;        // dO^T operand
+      const float x0 = P.lse[qc * a.H + h], x1 = P.delta[qc * a.H + h], x2 = P.q[qc * E + col + n], x3 = P.g_out[qc * E + col + n];
+      T.lse[r] = ok ? x0 : 0.f;
+      T.dl[r] = ok ? x1 : 0.f;
+      T.qt[r] = ok ? x2 * a.scale : 0.f;                    // Qs^T operand: lane (m = d, g)
+      T.gt[r] = ok ? x3 : 0.f;                              // dO^T operand
     }
   };
-  QT nxt;
-  load_tile(q0, nxt);
+  QT nxt = {};
+  if (q0 < q_end) load_tile(q0, nxt);
   for (int64_t qb = q0; qb < q_end; qb += TILE) {
     const QT cur = nxt;
     load_tile(qb + TILE, nxt);
@@ -296,11 +305,11 @@ __global__ __launch_bounds__(TPB) void attn_bwd_dkv_kernel(Args a) {
 // (inference/evaluation.py:43-66 slices it per pair); one wave per 16-query tile, all heads.
 __global__ __launch_bounds__(TPB) void attn_weights_kernel(Args a) {
   const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
-  int64_t t = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+  int64_t t = (int64_t)blockIdx.x * WPB + wave_id();
   int pi = 0;
   if (t >= a.p[0].units_q) { t -= a.p[0].units_q; pi = 1; }
   if (pi >= a.nprob) return;
-  const Prob& P = a.p[pi];
+  const Prob P = pick(a, pi);
   if (t >= P.units_q || !P.w) return;
   int b;
   int64_t q0, q_end;

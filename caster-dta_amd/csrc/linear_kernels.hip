@@ -26,7 +26,7 @@ namespace {
 typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int WAVE = 64, WPB = 8, TPB = WAVE * WPB, KC = 64, OG = 64;      // rows per LDS chunk; output rows per workgroup
 constexpr int MAX_NT = 17;                                                  // I <= 256: 16 column tiles + the bias tile
-constexpr int MAX_SPLITS = 64;
+constexpr int MAX_SPLITS = 128;
 
 struct WgArgs {
   const float* x; const float* gy; int64_t R; int I, O; int rows_per_split; float* slab; int slab_stride;
@@ -46,23 +46,48 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& a, float* lds) {
   f4 acc[NTW];
 #pragma unroll
   for (int t = 0; t < NTW; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+  // Register-staged double buffering: the NEXT 64-row chunk's global loads are issued before the current chunk's MFMAs
+  // and land in LDS after them (one exposed load latency per workgroup instead of one per chunk).
   const int i4 = I / 4;
-  for (int64_t rc = r_lo; rc < r_hi; rc += KC) {
+  constexpr int XV = KC * (256 / 4) / TPB, YV = KC * (OG / 4) / TPB;       // float4 per thread: X (I <= 256), dY
+  f4 xr[XV], yr[YV];
+  auto fetch = [&](int64_t rc) {
     const int rows = (int)(r_hi - rc < KC ? r_hi - rc : KC);
-    __syncthreads();                    // the previous chunk's reads are done
-    for (int q = tid; q < KC * i4; q += TPB) {             // X chunk, float4 loads, zero rows past the end
+#pragma unroll
+    for (int k = 0; k < XV; ++k) {
+      const int q = tid + k * TPB;
       const int r = q / i4, c = (q - r * i4) * 4;
-      f4 v = {0.f, 0.f, 0.f, 0.f};
-      if (r < rows) v = *reinterpret_cast<const f4*>(a.x + (rc + r) * I + c);
-      *reinterpret_cast<f4*>(xs + r * ldx + c) = v;
+      xr[k] = f4{0.f, 0.f, 0.f, 0.f};
+      if (q < KC * i4 && r < rows) xr[k] = *reinterpret_cast<const f4*>(a.x + (rc + r) * I + c);
     }
-    for (int q = tid; q < KC * (OG / 4); q += TPB) {       // this workgroup's 64 columns of dY
+#pragma unroll
+    for (int k = 0; k < YV; ++k) {
+      const int q = tid + k * TPB;
       const int r = q / (OG / 4), c = (q - r * (OG / 4)) * 4;
-      f4 v = {0.f, 0.f, 0.f, 0.f};
-      if (r < rows) v = *reinterpret_cast<const f4*>(a.gy + (rc + r) * a.O + o0 + c);
-      *reinterpret_cast<f4*>(ys + r * ldy + c) = v;
+      yr[k] = f4{0.f, 0.f, 0.f, 0.f};
+      if (r < rows) yr[k] = *reinterpret_cast<const f4*>(a.gy + (rc + r) * a.O + o0 + c);
     }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int k = 0; k < XV; ++k) {
+      const int q = tid + k * TPB;
+      const int r = q / i4, c = (q - r * i4) * 4;
+      if (q < KC * i4) *reinterpret_cast<f4*>(xs + r * ldx + c) = xr[k];
+    }
+#pragma unroll
+    for (int k = 0; k < YV; ++k) {
+      const int q = tid + k * TPB;
+      const int r = q / (OG / 4), c = (q - r * (OG / 4)) * 4;
+      *reinterpret_cast<f4*>(ys + r * ldy + c) = yr[k];
+    }
+  };
+  if (r_lo < r_hi) fetch(r_lo);
+  for (int64_t rc = r_lo; rc < r_hi; rc += KC) {
+    __syncthreads();                    // the previous chunk's operand reads are done
+    stash();
     __syncthreads();
+    if (rc + KC < r_hi) fetch(rc + KC);
 #pragma unroll 4
     for (int kk = 0; kk < KC / 4; ++kk) {
       const float av = ys[(4 * kk + g) * ldy + 16 * mt + n];                 // A[m = o][k = row]

@@ -162,6 +162,7 @@ def test_joint_model_all_gradients_vs_oracle(pretrained, wgrad_kernel, monkeypat
 
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("R,I,O", [(19200, 128, 384), (2560, 64, 128), (5003, 256, 128), (1031, 128, 256), (7, 128, 128),
                                    (0, 64, 128), (40000, 128, 128)])
 def test_linear_wgrad_kernel_matches_torch(R, I, O):
@@ -182,6 +183,7 @@ def test_linear_wgrad_kernel_matches_torch(R, I, O):
     torch.library.opcheck(torch.ops.caster_gvp.linear_wgrad.default, (x[:300], gy[:300])) if R >= 300 else None
 
 
+@pytest.mark.gpu
 def test_fast_linear_is_f_linear_with_the_same_gradients():
     from gvp_hip import head_ops
     gen = torch.Generator(device=DEV).manual_seed(3)
