@@ -105,9 +105,56 @@ void gine_bwd_layout(const cgvp_gine_cfg* c, int64_t N, GineBwdWs* w) {
   w->total = b.off;
 }
 
+// ------------------------------------------------------------------ batch staging (cgvp_stage_buffers)
+struct StageTable { cgvp_stage_item it[CGVP_MAX_STAGE]; };
+__global__ __launch_bounds__(256) void stage_kernel(StageTable t) {
+  const cgvp_stage_item it = t.it[blockIdx.y];
+  const int64_t words = it.capacity_bytes >> 2, copy = it.copy_bytes >> 2;
+  uint32_t* __restrict__ d = static_cast<uint32_t*>(it.dst);
+  const uint32_t* __restrict__ s = static_cast<const uint32_t*>(it.src);
+  const bool vec = !(((uintptr_t)d | (uintptr_t)s) & 15);
+  if (vec) {                                           // 16-byte body, word tail
+    const int64_t c4 = copy >> 2, w4 = words >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < w4; i += (int64_t)gridDim.x * 256) {
+      uint4 v = make_uint4(it.fill_word, it.fill_word, it.fill_word, it.fill_word);
+      if (i < c4) v = reinterpret_cast<const uint4*>(s)[i];
+      else if (i == c4 && (copy & 3)) {
+        const int64_t b = i << 2;
+        v.x = b < copy ? s[b] : it.fill_word; v.y = b + 1 < copy ? s[b + 1] : it.fill_word;
+        v.z = b + 2 < copy ? s[b + 2] : it.fill_word; v.w = it.fill_word;
+      }
+      reinterpret_cast<uint4*>(d)[i] = v;
+    }
+    for (int64_t i = (w4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (int64_t)gridDim.x * 256)
+      d[i] = i < copy ? s[i] : it.fill_word;
+    return;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (int64_t)gridDim.x * 256)
+    d[i] = i < copy ? s[i] : it.fill_word;
+}
+
 }  // namespace
 
 extern "C" {
+
+int cgvp_stage_buffers(const cgvp_stage_item* items, int32_t n, void* stream) {
+  if (n < 0 || n > CGVP_MAX_STAGE || (n > 0 && !items)) return CGVP_ERR_BAD_ARG;
+  if (n == 0) return 0;
+  StageTable t;
+  int64_t most = 0;
+  for (int i = 0; i < n; ++i) {
+    const cgvp_stage_item& it = items[i];
+    if (it.copy_bytes < 0 || it.capacity_bytes < it.copy_bytes || (it.copy_bytes & 3) || (it.capacity_bytes & 3)) return CGVP_ERR_BAD_ARG;
+    if ((it.capacity_bytes > 0 && !it.dst) || (it.copy_bytes > 0 && !it.src)) return CGVP_ERR_BAD_ARG;
+    if (((uintptr_t)it.dst & 3) || ((uintptr_t)it.src & 3)) return CGVP_ERR_BAD_ARG;
+    t.it[i] = it;
+    most = it.capacity_bytes > most ? it.capacity_bytes : most;
+  }
+  int64_t blocks = (most / 16 + 255) / 256;            // one uint4 per thread on the largest item; smaller items finish early
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(stage_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, (hipStream_t)stream, t);
+  return launch_status();
+}
 
 // ===================================================================================== protein encoder
 int cgvp_lba_fwd_workspace(const cgvp_dims* dims, const cgvp_layout* layout, int64_t N, int64_t E, int32_t save_state,

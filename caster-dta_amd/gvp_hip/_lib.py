@@ -19,7 +19,7 @@ ABI_VERSION = 24
 # sha256 of include/caster_gvp.h with comments, blank space and the CGVP_ABI_VERSION line removed, as
 # `abi_header_digest()` computes it.  tests/test_abi.py fails when the header's declarations change
 # without CGVP_ABI_VERSION, ABI_VERSION and this digest being updated together.
-ABI_HEADER_SHA256 = "8146ebf7cfb39ae8170102f5dcb4366aa0b91cdb3e5038c0b321b86f623a30c8"
+ABI_HEADER_SHA256 = "62c0a18dc02a672c99a06b379776544e7d0a1517a1befe0a5c4e117249932053"
 
 
 class HipLibraryError(RuntimeError):
@@ -58,6 +58,15 @@ class AttnProblem(C.Structure):
 
 class GineW(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("eps", "we", "be", "w0", "b0", "w1", "b1")]
+
+
+MAX_STAGE = 24           # CGVP_MAX_STAGE
+
+
+class StageItem(C.Structure):
+    """cgvp_stage_item: one copy-and-pad of cgvp_stage_buffers."""
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("copy_bytes", C.c_int64), ("capacity_bytes", C.c_int64),
+                ("fill_word", C.c_uint32)]
 
 
 class LbaBatch(C.Structure):
@@ -145,6 +154,7 @@ _SIGNATURES = {
                                           _P, _P, _P, _P, _I32, _P]),
     "cgvp_linear_wgrad_workspace_floats": (C.c_int64, [_I64, _I32, _I32]),
     "cgvp_linear_wgrad": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P, _P]),
+    "cgvp_stage_buffers": (C.c_int, [C.POINTER(StageItem), _I32, _P]),
     "cgvp_debug_kernel_timing": (C.c_int, [_I32]),
     "cgvp_debug_kernel_times": (C.c_int, [_P, _P, _I32]),
     "cgvp_gine_bwd_workspace_floats": (C.c_int64, []),

@@ -1,0 +1,148 @@
+"""Shape-bucketed HIP-graph replay of an encoder training step for loops that feed a DIFFERENT batch every step.
+
+The reference's loop (train_model.py:548-587) draws a new batch -- new N, E, edge_index -- every step.  Launched
+eagerly, a step of both encoders costs ~0.6 ms of host time (PyTorch's autograd engine alone spends ~0.3 ms on the 74
+parameter leaves) for ~0.25 ms of device work.  A captured step replays in one host call, but a HIP graph freezes its
+shapes.  `GraphedEncoderStep` keeps one captured step per SHAPE BUCKET:
+
+  * sizes (residues, protein edges, atoms, drug edges) are rounded up to the next multiple of 1/8 of their power of two
+    (at most 12.5 % padding), a bucket = the four rounded sizes;
+  * each bucket owns static input buffers; a step copies the batch into them with ONE launch (cgvp_stage_buffers) and
+    replays the bucket's graph;
+  * padding is inert by construction: padded residues / atoms are isolated nodes (their upstream gradient rows are zero,
+    and every backward stage is linear in its upstream gradient), padded edges carry endpoint -1 and are dropped by the
+    CSR build inside the captured step (tests/test_hip_random_graphs.py covers out-of-range endpoints); dropout is keyed
+    by (seed, offset, layer, row, channel), so the real rows draw the same factors as in an unpadded eager step.
+
+The outputs (embeddings of the real rows, every weight gradient) are the graph's static tensors: consume them (optimizer
+step, all-reduce) before the next `run` of the same bucket.  Opt-in: the nn.Module API is untouched.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib, ops
+
+
+def bucket_size(n):
+    """n rounded up to a multiple of 2^(floor(log2 n) - 3): at most 12.5 % larger, 8 buckets per octave."""
+    n = int(n)
+    if n <= 64:
+        return 64
+    q = 1 << max(n.bit_length() - 4, 0)
+    return (n + q - 1) // q * q
+
+
+class _Bucket:
+    def __init__(self, owner, key, pdata, mdata, sdt):
+        N, E, Na, Ea = key
+        dev = owner.device
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
+        ni = pdata["x"][0].shape[1], pdata["x"][1].shape[1], pdata["eattr"][0].shape[1], pdata["eattr"][1].shape[1]
+        self.p = dict(x=(z(N, ni[0], dt=sdt), z(N, ni[1], 3, dt=sdt)), edge_index=torch.full((2, E), -1, dtype=torch.int64, device=dev),
+                      ntypes=z(N, dt=torch.int64), etypes=z(E, dt=torch.int64),
+                      eattr=(z(E, ni[2], dt=sdt), z(E, ni[3], 3, dt=sdt)))
+        self.m = dict(x=z(Na, mdata["x"].shape[1]), edge_index=torch.full((2, Ea), -1, dtype=torch.int64, device=dev),
+                      ntypes=z(Na, dt=torch.int64), etypes=z(Ea, dt=torch.int64), eattr=z(Ea, mdata["eattr"].shape[1]))
+        self.g_res, self.g_atm = z(N, owner.out_res, dt=sdt), z(Na, owner.out_atm)
+        self.graph, self.out = None, None
+        self.steps = 0
+
+
+class GraphedEncoderStep:
+    """step = forward of both encoders + backward with every weight gradient, protein chain on the launch stream, drug
+    chain on a side stream (what bench.py times).  `run(pdata, mdata, g_res, g_atm)` -> (residues [N, 64],
+    atoms [Na, 64], protein grads, drug grads) -- views of static tensors of the batch's bucket."""
+
+    def __init__(self, protein_gnn, molecule_gnn, train=True, quantum=bucket_size):
+        self.prot, self.mol = protein_gnn, molecule_gnn
+        self.pp = [p for p in protein_gnn.parameters() if p.numel()]
+        self.mp = [p for p in molecule_gnn.parameters() if p.numel()]
+        self.device = self.pp[0].device
+        self.out_res = protein_gnn.out_channels[0] if isinstance(protein_gnn.out_channels, (tuple, list)) else protein_gnn.out_channels
+        self.out_atm = molecule_gnn.out_channels
+        self.train, self.quantum = train, quantum
+        self.buckets = {}
+        self.stream = torch.cuda.Stream(device=self.device)          # capture + replay stream (its CSR counters persist)
+        self.side = torch.cuda.Stream(device=self.device)
+        self.pool = None
+
+    def _step(self, b):
+        main_s = torch.cuda.current_stream()
+        self.side.wait_stream(main_s)
+        res = self.prot(**b.p)
+        with torch.cuda.stream(self.side):
+            atm = self.mol(**b.m)
+        if not self.train:
+            main_s.wait_stream(self.side)
+            return res, atm, (), ()
+        gp = torch.autograd.grad([res], self.pp, [b.g_res])
+        with torch.cuda.stream(self.side):
+            gd = torch.autograd.grad([atm], self.mp, [b.g_atm])
+        main_s.wait_stream(self.side)
+        return res, atm, gp, gd
+
+    def _stage(self, b, pdata, mdata, g_res, g_atm):
+        pairs = [(b.p["x"][0], pdata["x"][0]), (b.p["x"][1], pdata["x"][1]), (b.p["ntypes"], pdata["ntypes"]),
+                 (b.p["etypes"], pdata["etypes"]), (b.p["eattr"][0], pdata["eattr"][0]), (b.p["eattr"][1], pdata["eattr"][1]),
+                 (b.m["x"], mdata["x"]), (b.m["ntypes"], mdata["ntypes"]), (b.m["etypes"], mdata["etypes"]),
+                 (b.m["eattr"], mdata["eattr"])]
+        if self.train:
+            pairs += [(b.g_res, g_res), (b.g_atm, g_atm)]
+        items = (_lib.StageItem * _lib.MAX_STAGE)()
+        keep, k = [], 0
+        for dst, src in pairs:
+            if src.dtype != dst.dtype or not src.is_contiguous():
+                src = src.to(dst.dtype).contiguous()
+                keep.append(src)
+            items[k] = _lib.StageItem(dst.data_ptr(), src.data_ptr() if src.numel() else 0, src.numel() * src.element_size(),
+                                      dst.numel() * dst.element_size(), 0)
+            k += 1
+        for dst, src in ((b.p["edge_index"], pdata["edge_index"]), (b.m["edge_index"], mdata["edge_index"])):
+            src = src.contiguous()
+            keep.append(src)
+            E, Ecap = src.shape[1], dst.shape[1]
+            for row in range(2):                                      # each row of [2, E] lands in its row of [2, Ecap], tail = -1
+                items[k] = _lib.StageItem(dst[row].data_ptr(), src[row].data_ptr() if E else 0, E * 8, Ecap * 8, 0xFFFFFFFF)
+                k += 1
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().cgvp_stage_buffers(items, k, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       "cgvp_stage_buffers")
+        return keep
+
+    def run(self, pdata, mdata, g_res=None, g_atm=None):
+        N, E = pdata["x"][0].shape[0], pdata["edge_index"].shape[1]
+        Na, Ea = mdata["x"].shape[0], mdata["edge_index"].shape[1]
+        key = (self.quantum(N), self.quantum(E), self.quantum(Na), self.quantum(Ea))
+        sdt = torch.bfloat16 if pdata["x"][0].dtype == torch.bfloat16 else torch.float32
+        b = self.buckets.get((key, sdt))
+        caller = torch.cuda.current_stream()
+        self.stream.wait_stream(caller)
+        with torch.cuda.stream(self.stream), torch.set_grad_enabled(self.train):
+            if b is None:
+                b = self.buckets[(key, sdt)] = _Bucket(self, key, pdata, mdata, sdt)
+            keep = self._stage(b, pdata, mdata, g_res, g_atm)
+            if b.graph is None:
+                old = ops.CSR_CACHE_ENABLED
+                ops.CSR_CACHE_ENABLED = False                # the captured step rebuilds its CSR tables from the staged edge_index
+                try:
+                    for _ in range(2):                       # warm-up on the capture stream (generator state, counters exist)
+                        self._step(b)
+                    torch.cuda.current_stream().synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self.stream, pool=self.pool):
+                        b.out = self._step(b)
+                    if self.pool is None:
+                        self.pool = g.pool()                 # every bucket's graph shares one memory pool
+                    b.graph = g
+                finally:
+                    ops.CSR_CACHE_ENABLED = old
+            b.graph.replay()
+            b.steps += 1
+        caller.wait_stream(self.stream)
+        for t in keep:
+            t.record_stream(self.stream)
+        res, atm, gp, gd = b.out
+        return res[:N], atm[:Na], gp, gd

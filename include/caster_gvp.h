@@ -534,6 +534,21 @@ int64_t cgvp_linear_wgrad_workspace_floats(int64_t num_rows, int32_t in_features
 int cgvp_linear_wgrad(const float* x, const float* gy, int64_t num_rows, int32_t in_features, int32_t out_features,
                       float* workspace, float* out, void* stream);
 
+/* ------------------------------------------------------------ BATCH STAGING (shape-bucketed HIP-graph replay)
+ * A training loop that replays a captured step on a DIFFERENT batch every step (train_model.py:548-587 feeds new N, E
+ * each step) keeps static input buffers per shape bucket and copies the batch into them.  This does every copy of a
+ * step in ONE launch: item k copies `copy_bytes` from src to dst and fills the rest of dst's `capacity_bytes` with the
+ * 32-bit pattern `fill_word` (0xFFFFFFFF = index -1 for the padded tail of edge_index: the CSR build drops such edges;
+ * 0 for features and upstream gradients: padded nodes are isolated and receive no gradient).  All sizes are multiples
+ * of 4, pointers 4-byte aligned; src may be NULL when copy_bytes == 0.  Up to CGVP_MAX_STAGE items per call. */
+#define CGVP_MAX_STAGE 24
+typedef struct {
+  void* dst; const void* src;
+  int64_t copy_bytes, capacity_bytes;
+  uint32_t fill_word;
+} cgvp_stage_item;
+int cgvp_stage_buffers(const cgvp_stage_item* items, int32_t num_items, void* stream);
+
 /* ------------------------------------------------------------ DIAGNOSTICS
  * The ONE piece of process-global state in the library, off by default, not thread-safe; bench.py's roofline leg uses
  * it to time the dominant kernel in situ: while enabled, the whole-pass entry points bracket every conv-layer launch

@@ -401,3 +401,43 @@ def test_captured_step_survives_regrow_reseed_and_frees_with_dropout_on(pretrain
             assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 2e-6 * scale
     finally:
         ops.CSR_CACHE_ENABLED = old
+
+
+def test_bucketed_graph_replay_equals_eager_on_changing_batches(pretrained):
+    """gvp_hip.graphed.GraphedEncoderStep: a different batch every step (other proteins, other N / E), replayed from one
+    captured step per shape bucket with the batch staged into padded static buffers (padded residues / atoms isolated,
+    padded edges with endpoint -1).  Embeddings of the real rows and every weight gradient equal the eager step on the
+    unpadded batch; batches of different sizes share a bucket when their rounded sizes agree."""
+    from gvp_hip.graphed import GraphedEncoderStep, bucket_size
+    from models.joint_gnn import JointGNN
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))
+    kw["protein_gnn_kwargs"] = dict(kw["protein_gnn_kwargs"], dropout_rate=0.0)
+    kw["molecule_gnn_kwargs"] = dict(kw["molecule_gnn_kwargs"], dropout_rate=0.0)
+    model = JointGNN(protein_gnn_kwargs=kw["protein_gnn_kwargs"], molecule_gnn_kwargs=kw["molecule_gnn_kwargs"],
+                     **kw["joint_gnn_kwargs"])
+    model.load_state_dict(pretrained, strict=True)
+    model = model.to(DEV).train()
+    runner = GraphedEncoderStep(model.protein_gnn, model.molecule_gnn)
+    pp, mp = runner.pp, runner.mp
+    cases = [(3, [40, 75, 33, 120, 64, 51]), (4, [41, 74, 33, 121, 64, 50]), (5, [300, 280]), (6, [39, 76, 33, 119, 65, 51]),
+             (7, [17])]
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    seen = set()
+    for seed, lengths in cases:
+        p, m = ds.pair_batch(len(lengths), seed, lengths=lengths)
+        pd, md = _to(ds.to_torch(p)), _to(ds.to_torch(m))
+        pd.pop("batch"), md.pop("batch")
+        g_res = torch.randn(p.num_nodes, 64, device=DEV, generator=gen)
+        g_atm = torch.randn(m.num_nodes, 64, device=DEV, generator=gen)
+        res, atm, gp, gd = runner.run(pd, md, g_res, g_atm)
+        got = [t.clone() for t in (res, atm) + tuple(gp) + tuple(gd)]
+        seen.add((bucket_size(p.num_nodes), bucket_size(p.num_edges), bucket_size(m.num_nodes), bucket_size(m.num_edges)))
+        e_res = model.protein_gnn(**pd)
+        e_atm = model.molecule_gnn(**md)
+        want = [e_res.detach(), e_atm.detach()] + list(torch.autograd.grad([e_res, e_atm], pp + mp, [g_res, g_atm]))
+        assert got[0].shape == want[0].shape and got[1].shape == want[1].shape
+        assert rel_err(got[0], want[0]) < 1e-6 and rel_err(got[1], want[1]) < 1e-6
+        scale = max(float(w.abs().max()) for w in want[2:])
+        for a, b in zip(got[2:], want[2:]):
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 2e-6 * scale, (seed, tuple(a.shape))
+    assert len(runner.buckets) == len(seen) < len(cases)               # cases 1, 2 and 4 share a bucket
