@@ -11,9 +11,9 @@ mkdir -p "$OUT" profiles/$RND
 export TMPDIR=/tmp
 python bench.py --workload $WL "$@" > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 bench.py --workload $WL --no-cpu-baseline --steps 100 "$@" > $OUT/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- python3 bench.py --workload $WL --no-cpu-baseline --no-graph --steps 10 --warmup 2 "$@" > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o run -- python3 bench.py --workload $WL --no-cpu-baseline --no-graph --steps 10 --warmup 2 "$@" > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 bench.py --workload $WL --no-cpu-baseline --epoch off --steps 100 "$@" > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- python3 bench.py --workload $WL --no-cpu-baseline --epoch off --no-graph --steps 10 --warmup 2 "$@" > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o run -- python3 bench.py --workload $WL --no-cpu-baseline --epoch off --no-graph --steps 10 --warmup 2 "$@" > $OUT/write.log 2>&1
 python tools/pmc_summarise.py $OUT/fetch $OUT/write $OUT/pmc_traffic_${TAG}.json "$TAG fwd+bwd train mode, eager" > $OUT/pmc.txt
 find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_${TAG}.csv
 python tools/step_trace.py $OUT/stats > $OUT/step_trace_${TAG}.txt 2>/dev/null || true

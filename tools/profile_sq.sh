@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16"; do
   i=$((i + 1))
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -o run -- python3 bench.py --workload $WL --no-cpu-baseline --no-graph --steps 6 --warmup 2 "$@" > $OUT/p$i.log 2>&1 || echo "pass $i ($grp) failed"
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -o run -- python3 bench.py --workload $WL --no-cpu-baseline --epoch off --no-graph --steps 6 --warmup 2 "$@" > $OUT/p$i.log 2>&1 || echo "pass $i ($grp) failed"
 done
 python tools/pmc_sq_summarise.py $OUT/pmc_sq_stalls_${TAG}.json $OUT/p* | grep -E "conv_bwd|conv_quad|node_bwd|edge_bwd"
 rm -rf $OUT/p[0-9]
