@@ -205,86 +205,6 @@ __global__ void csr_rank_kernel(const int64_t* __restrict__ ei, int64_t N, int64
   esrc[lo + rank] = (int32_t)ei[key];
 }
 
-// The whole build in ONE launch of ONE workgroup, for graphs whose per-target counters fit the LDS (the drug graphs of a
-// batch: ~2.5k atoms, ~8k bonds).  Same phases as the four kernels above -- count, exclusive scan, fill in arrival
-// order, rank by edge id -- separated by workgroup barriers instead of kernel boundaries; same tables, bit for bit
-// (the rank makes the order independent of the arrival order).  Why: the drug chain of a training step runs on a side
-// stream beside CU-filling protein kernels, and every one of its tiny launches waited 4-30 us for a dispatch slot
-// (profiles/r03/step_trace_davis_b64_before_csr_small.txt: count .. rank spread over 55 us for 15 us of work).
-constexpr int CSR_SMALL_MAX_N = 8192, CSR_SMALL_TPB = 1024;
-__global__ __launch_bounds__(CSR_SMALL_TPB) void csr_small_kernel(const int64_t* __restrict__ ei, int N, int E,
-                                                                int32_t* __restrict__ rowptr, int32_t* __restrict__ eperm,
-                                                                int32_t* __restrict__ esrc, int32_t* __restrict__ edst,
-                                                                int32_t* __restrict__ tmp, unsigned long long* rng_state,
-                                                                unsigned long long* rng_out) {
-  __shared__ int32_t cnt[CSR_SMALL_MAX_N + 1];        // counts -> cursors
-  __shared__ int32_t rp[CSR_SMALL_MAX_N + 1];         // row pointers
-  __shared__ int32_t part[CSR_SMALL_TPB / 64 * 2];
-  const int t = threadIdx.x;
-  if (rng_state && t == 0) {
-    const unsigned long long off = rng_state[1] + 1;
-    rng_state[1] = off;
-    rng_out[0] = rng_state[0];
-    rng_out[1] = off;
-  }
-  for (int i = t; i <= N; i += CSR_SMALL_TPB) cnt[i] = 0;
-  __syncthreads();
-  for (int e = t; e < E; e += CSR_SMALL_TPB) {
-    const int64_t s = ei[e], d = ei[(int64_t)E + e];
-    if (s >= 0 && s < N && d >= 0 && d < N) atomicAdd(&cnt[d], 1);
-  }
-  __syncthreads();
-  // exclusive scan of cnt[0 .. N): per-thread chunks, wave shuffles, the 16 wave totals through LDS
-  const int chunk = (N + CSR_SMALL_TPB - 1) / CSR_SMALL_TPB;
-  const int lo = t * chunk < N ? t * chunk : N, hi = lo + chunk < N ? lo + chunk : N;
-  int32_t sum = 0;
-  for (int i = lo; i < hi; ++i) sum += cnt[i];
-  int32_t inc = sum;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int32_t u = __shfl_up(inc, off);
-    if ((t & 63) >= off) inc += u;
-  }
-  if ((t & 63) == 63) part[t >> 6] = inc;
-  __syncthreads();
-  if (t < 16) {
-    int32_t w = part[t];
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) {
-      const int32_t u = __shfl_up(w, off, 16);
-      if (t >= off) w += u;
-    }
-    part[16 + t] = w;
-  }
-  __syncthreads();
-  int32_t run = ((t >> 6) > 0 ? part[16 + (t >> 6) - 1] : 0) + inc - sum;
-  for (int i = lo; i < hi; ++i) { const int32_t c = cnt[i]; rp[i] = run; cnt[i] = run; run += c; }
-  if (t == CSR_SMALL_TPB - 1) rp[N] = part[31];
-  __syncthreads();
-  const int total = rp[N];
-  for (int i = t; i <= N; i += CSR_SMALL_TPB) rowptr[i] = rp[i];
-  for (int e = t; e < E; e += CSR_SMALL_TPB) {        // fill in arrival order (cursors in LDS)
-    const int64_t s = ei[e], d = ei[(int64_t)E + e];
-    if (s < 0 || s >= N || d < 0 || d >= N) continue;
-    const int32_t pos = atomicAdd(&cnt[(int)d], 1);
-    if (pos < 0 || pos >= E) continue;
-    tmp[pos] = e;
-    edst[pos] = (int32_t)d;
-  }
-  __syncthreads();                                    // one workgroup = one CU: its global stores are visible to its own loads
-  for (int p = t; p < E; p += CSR_SMALL_TPB) {        // rank every position's edge id inside its segment
-    if (p >= total) { eperm[p] = -1; esrc[p] = 0; edst[p] = 0; continue; }
-    const int32_t n = edst[p];
-    if (n < 0 || n >= N) continue;
-    const int32_t a = rp[n], b = rp[n + 1], key = tmp[p];
-    if (a < 0 || b > E || a > b || key < 0 || key >= E) continue;
-    int32_t rank = 0;
-    for (int32_t j = a; j < b; ++j) rank += tmp[j] < key ? 1 : 0;
-    eperm[a + rank] = key;
-    esrc[a + rank] = (int32_t)ei[key];
-  }
-}
-
 // Batch CSR by CONCATENATION of per-graph CSRs (a dataset's few hundred unique
 // graphs are sorted once; a batch is their blocks shifted by node / edge offsets).  One workgroup
 // per batch slot; `sel[b]` is the slot's graph in the store, whose tables hold LOCAL indices.
@@ -713,13 +633,6 @@ int csr_build(const int64_t* edge_index, int64_t N, int64_t E, int32_t* rowptr, 
   if (N >= (int64_t)1 << 31 || E >= (int64_t)1 << 31) return CGVP_ERR_BAD_ARG;
   if ((uintptr_t)work & 15) return CGVP_ERR_BAD_ARG;
   hipStream_t s = stream;
-  if (N <= CSR_SMALL_MAX_N && E <= 8 * CSR_SMALL_MAX_N && work_is_zero != 2) {
-    // small graph: the whole build in one launch of one workgroup; the persistent counters are not touched (a caller
-    // that said work_is_zero = 0 asked for a fill it no longer needs)
-    hipLaunchKernelGGL(csr_small_kernel, dim3(1), dim3(CSR_SMALL_TPB), 0, s, edge_index, (int)N, (int)E, rowptr, eperm, esrc, edst,
-                       ids_scratch, rng_state, rng_out);
-    return launch_status();
-  }
   const int64_t counters = (N + 1 + 63) / 64 * 64;
   if (work_is_zero == 0) {
     zero_words(work, (size_t)counters, s);
