@@ -88,6 +88,8 @@ def parse():
                          "computes in half precision; the encoder ops' autocast rule keeps them in fp32)")
     ap.add_argument("--compile-graph", action="store_true",
                     help="with --compile: additionally capture the compiled step into a HIP graph (experiment)")
+    ap.add_argument("--drug-priority", type=int, default=0,
+                    help="diagnostic: priority of the drug encoder's side stream (-1 = high)")
     ap.add_argument("--gine-bwd-wgs", type=int, default=0,
                     help="diagnostic: workgroup cap of the GINE backward (0 = library default of 16)")
     ap.add_argument("--only", default=None, choices=["protein", "drug"],
@@ -208,7 +210,7 @@ def main():
     jp = dict(pdata, ptr=torch.as_tensor(pb.ptr).to(dev))
     jm = dict(mdata, ptr=torch.as_tensor(mb.ptr).to(dev))
     ops.CSR_CACHE_ENABLED = bool(args.cache_csr or args.collate_csr)
-    side = torch.cuda.Stream(device=dev)
+    side = torch.cuda.Stream(device=dev, priority=args.drug_priority)
     collate = None
     if args.collate_csr:
         # wire format of SURVEY 8 f-2: every unique graph's CSR is sorted ONCE (outside the timed region, as a
