@@ -696,6 +696,7 @@ int gine_bwd(int cin, int chid, int cout, int nt, int net, int ed, const float* 
               w->w1, w->b1, slope, mask, rng, g_out, g_x, slab};
   // compiled for the layer shapes of HomoMoleculeGNN_GINE in CASTER-DTA (molecule_gnn.py:240-250)
   if (cin == 52 && chid == 16 && cout == 16 && nt == 11 && net == 5 && ed == 9) return launch<52, 16, 16, 11, 5, 9>(a, cap, rows, row_len, st);
+  if (cin == 52 && chid == 16 && cout == 16 && nt == 0 && net == 5 && ed == 9) return launch<52, 16, 16, 0, 5, 9>(a, cap, rows, row_len, st);   // nn.Embedding atom types (11-wide), materialised by the host
   if (cin == 16 && chid == 64 && cout == 64 && nt == 0 && net == 5 && ed == 9) return launch<16, 64, 64, 0, 5, 9>(a, cap, rows, row_len, st);
   if (cin == 16 && chid == 16 && cout == 16 && nt == 0 && net == 5 && ed == 9) return launch<16, 16, 16, 0, 5, 9>(a, cap, rows, row_len, st);   // middle layers of deeper stacks
   return CGVP_ERR_UNSUPPORTED_DIMS;
@@ -710,6 +711,7 @@ int gine_fwd(int cin, int chid, int cout, int nt, int net, int ed, const float* 
   GineFArgs a{x, ntypes, eattr, etypes, rowptr, eperm, esrc, edst, N, w->eps, w->we, w->be, w->w0, w->b0,
               w->w1, w->b1, slope, mask, rng, out};
   if (cin == 52 && chid == 16 && cout == 16 && nt == 11 && net == 5 && ed == 9) return launch_fwd<52, 16, 16, 11, 5, 9>(a, st);
+  if (cin == 52 && chid == 16 && cout == 16 && nt == 0 && net == 5 && ed == 9) return launch_fwd<52, 16, 16, 0, 5, 9>(a, st);
   if (cin == 16 && chid == 64 && cout == 64 && nt == 0 && net == 5 && ed == 9) return launch_fwd<16, 64, 64, 0, 5, 9>(a, st);
   if (cin == 16 && chid == 16 && cout == 16 && nt == 0 && net == 5 && ed == 9) return launch_fwd<16, 16, 16, 0, 5, 9>(a, st);
   return 1;

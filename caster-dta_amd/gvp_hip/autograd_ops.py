@@ -596,9 +596,10 @@ torch.library.register_autocast("caster_gvp::gine_encoder", "cuda", torch.float3
 
 
 def gine_params(model):
+    emb = None if model._onehot_etypes else model.etype_embedding
     params = []
     for conv in model.conv_list:
-        kw = conv.kernel_weights()
+        kw = conv.kernel_weights(emb)
         params += [kw[k] for k in _GINE_KEYS]
     return params
 
@@ -620,7 +621,8 @@ def gine_encoder(model, x, ntypes, eattr, etypes, edge_index, slope, train_dropo
             else:
                 draw = True
         with torch.cuda.device(dev):
-            out, ws = br.gine_encoder(gine_params(model), x, ntypes, eattr, etypes, edge_index, csr, widths, model.num_ntypes,
+            out, ws = br.gine_encoder(gine_params(model), x, ntypes, eattr, etypes, edge_index, csr, widths,
+                                      model.num_ntypes if model._onehot_ntypes else 0,
                                       model.num_etypes, float(slope), p, save_state, masks,
                                       rng_state("gine", dev) if draw else None, None if csr else ops.csr_counters(dev, N),
                                       0, GINE_BWD_WORKGROUPS)
@@ -629,5 +631,5 @@ def gine_encoder(model, x, ntypes, eattr, etypes, edge_index, slope, train_dropo
         return out
     out, _, _ = torch.ops.caster_gvp.gine_encoder(
         gine_params(model), x, ntypes, eattr, etypes, edge_index, _memo_tables(edge_index, x.shape[0]), list(model._widths),
-        model.num_ntypes, model.num_etypes, float(slope), p, save_state)
+        model.num_ntypes if model._onehot_ntypes else 0, model.num_etypes, float(slope), p, save_state)
     return out

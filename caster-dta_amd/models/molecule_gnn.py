@@ -120,10 +120,17 @@ class GINEConv(nn.Module):
     def __repr__(self):
         return f"GINEConv(nn={self.nn})"
 
-    def kernel_weights(self):
+    def kernel_weights(self, etype_embedding=None):
+        """The seven tensors of the layer as the kernels take them.  `etype_embedding` (an nn.Embedding, when the model
+        encodes bond types that way, molecule_gnn.py:118-122): the edge Linear sees [emb(type) | features]; its embedding
+        part is linear in the table, so an EQUIVALENT one-hot weight [W[:, :D] @ table^T | W[:, D:]] is built here (one
+        tiny matmul + cat, differentiable: autograd carries the kernels' gradient back to `lin.weight` and the table)."""
         l0, l1 = self.nn.lins
-        return dict(eps=self.eps, we=self.lin.weight, be=self.lin.bias, w0=l0.weight, b0=l0.bias,
-                    w1=l1.weight, b1=l1.bias)
+        we = self.lin.weight
+        if etype_embedding is not None:
+            d = etype_embedding.embedding_dim
+            we = torch.cat([we[:, :d] @ etype_embedding.weight.t(), we[:, d:]], dim=1)
+        return dict(eps=self.eps, we=we, be=self.lin.bias, w0=l0.weight, b0=l0.bias, w1=l1.weight, b1=l1.bias)
 
 
 class HomoMoleculeGNN_GINE(BaseMoleculeGNN):
@@ -131,8 +138,10 @@ class HomoMoleculeGNN_GINE(BaseMoleculeGNN):
 
     def __init__(self, act_first=False, gin_norm=None, gin_norm_kwargs=None, gin_trainable_eps=True, **kwargs):
         super().__init__(**kwargs)
-        if act_first or gin_norm is not None:
-            raise NotImplementedError("act_first / gin_norm are not compiled into the fused GINE kernel")
+        if gin_norm is not None:
+            raise NotImplementedError("gin_norm is not compiled into the fused GINE kernel (the reference trains with "
+                                      "gin_norm=None, train_model.py:300-312)")
+        # act_first only reorders activation and normalisation inside PyG's MLP: without a norm it changes nothing
         if self.aggr not in ("sum", "add"):
             raise NotImplementedError("the fused GINE kernel implements aggr='sum'")
         self.act_first = act_first
@@ -155,8 +164,14 @@ class HomoMoleculeGNN_GINE(BaseMoleculeGNN):
         if slope is None:
             raise NotImplementedError(f"activation {self.activation} is not compiled into the fused GINE kernel "
                                       "(ReLU / LeakyReLU / none are)")
-        if not (self._onehot_ntypes and self._onehot_etypes):
-            raise NotImplementedError("nn.Embedding type encoders are not compiled into the fused GINE kernel")
+        if not self._onehot_ntypes:
+            # nn.Embedding atom types (molecule_gnn.py:112-116): the embedding row sits UNDER the message ReLU and the
+            # (1 + eps) residual, so it cannot be folded into a weight; it is materialised (one gather + cat) and the
+            # first layer runs as a plain [Na, D + F] layer.  The kernels are compiled for D + F = 52.
+            if self.ntype_emb_dim + self.in_channels != 52:
+                raise NotImplementedError("nn.Embedding atom types: the fused GINE kernel is compiled for ntype_emb_dim + "
+                                          f"in_channels = 52, got {self.ntype_emb_dim} + {self.in_channels}")
+            x = torch.cat([self.ntype_embedding(ntypes).to(x.dtype), x], dim=-1)
         if eattr is None:
             raise NotImplementedError("the GINE encoder needs edge features (eattr)")
         if not x.is_cuda:

@@ -288,10 +288,14 @@ def gine_conv(P, pfx, x, edge_index, edge_attr, act="leaky_relu"):
 def molecule_gine_forward(P, x, edge_index, ntypes, etypes, eattr, num_ntypes=11, num_etypes=5,
                           num_convs=2, act="leaky_relu", pfx="", return_stages=False, masks=None):
     """molecule_gnn.py:254-268 (HomoMoleculeGNN_GINE.forward), eval mode; `masks` (one [N, width] tensor of
-    dropout factors per layer but the last, or None) supplies the training-mode dropout of :262 explicitly."""
+    dropout factors per layer but the last, or None) supplies the training-mode dropout of :262 explicitly.
+    Type encoders (:112-122): nn.Embedding tables when P holds `ntype_embedding.weight` / `etype_embedding.weight`,
+    one-hot otherwise."""
     dt = x.dtype
-    x = torch.cat([F.one_hot(ntypes, num_ntypes).to(dt), x], -1)                # :127-140
-    eattr = torch.cat([F.one_hot(etypes, num_etypes).to(dt), eattr], -1)
+    nt = P[pfx + "ntype_embedding.weight"][ntypes] if pfx + "ntype_embedding.weight" in P else F.one_hot(ntypes, num_ntypes).to(dt)
+    et = P[pfx + "etype_embedding.weight"][etypes] if pfx + "etype_embedding.weight" in P else F.one_hot(etypes, num_etypes).to(dt)
+    x = torch.cat([nt, x], -1)                                                  # :127-140
+    eattr = torch.cat([et, eattr], -1)
     stages = {}
     for l in range(num_convs):
         x = _act(act)(gine_conv(P, f"{pfx}conv_list.{l}.", x, edge_index, eattr, act))

@@ -162,3 +162,47 @@ def test_c5_pair_full_size_bf16_protein_fp32_drug():
     assert rel_err(torch.cat(outs), out) < 1e-6
     for gf, gs in zip(g_full, gsum):
         assert rel_err(gf, gs) < 2e-4
+
+
+@pytest.mark.parametrize("nt_emb,et_emb", [(11, 3), (None, 4), (11, None)])
+def test_gine_with_embedding_type_encoders(nt_emb, et_emb):
+    """nn.Embedding type encoders on the drug side (molecule_gnn.py:112-122).  Bond types: the embedding is folded into an
+    equivalent one-hot edge weight (exact).  Atom types: the embedding row is materialised in front of the atom features
+    (it sits under the message ReLU, so it cannot be folded) and the first layer runs as a plain 52-wide layer.  Forward
+    and every gradient incl. both embedding tables against the oracle."""
+    from models.molecule_gnn import SelectableMoleculeModelWrapper
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))["molecule_gnn_kwargs"]
+    torch.manual_seed(7)
+    model = SelectableMoleculeModelWrapper(**dict(kw, ntype_emb_dim=nt_emb, etype_emb_dim=et_emb)).to(DEV).eval()
+    keys = set(model.gnn_model.state_dict())
+    assert ("ntype_embedding.weight" in keys) == (nt_emb is not None) and ("etype_embedding.weight" in keys) == (et_emb is not None)
+    d = ds.to_torch(ds.drug_batch(9, 5))
+    dd = _to(d)
+    gx = dd["x"].clone().requires_grad_()
+    out = model(gx, dd["edge_index"], dd["ntypes"], dd["etypes"], eattr=dd["eattr"])
+    r = torch.randn(out.shape, generator=torch.Generator().manual_seed(1))
+    (out * r.to(DEV)).sum().backward()
+    P = _oracle_params(model)
+    xr = d["x"].clone().requires_grad_()
+    ref = O.molecule_gine_forward(P, xr, d["edge_index"], d["ntypes"], d["etypes"], d["eattr"], num_convs=2)
+    assert rel_err(out, ref) < 2e-5
+    (ref * r).sum().backward()
+    n = 0
+    for name, p in model.gnn_model.named_parameters():
+        assert p.grad is not None, name
+        assert rel_err(p.grad, P[name].grad) < 2e-4, name
+        n += 1
+    assert n == 14 + (nt_emb is not None) + (et_emb is not None)
+    assert rel_err(gx.grad, xr.grad) < 2e-4
+
+
+def test_gine_unsupported_options_say_so():
+    from models.molecule_gnn import SelectableMoleculeModelWrapper
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))["molecule_gnn_kwargs"]
+    SelectableMoleculeModelWrapper(**dict(kw, act_first=True))                  # no norm: act_first changes nothing
+    with pytest.raises(NotImplementedError):
+        SelectableMoleculeModelWrapper(**dict(kw, gin_norm="batch_norm"))
+    m = SelectableMoleculeModelWrapper(**dict(kw, ntype_emb_dim=8)).to(DEV)
+    d = _to(ds.to_torch(ds.drug_batch(2, 1)))
+    with pytest.raises(NotImplementedError):
+        m(d["x"], d["edge_index"], d["ntypes"], d["etypes"], eattr=d["eattr"])
