@@ -520,6 +520,10 @@ __global__ __launch_bounds__(CB_TPB, CB_WPB / 4) void conv_bwd_kernel(ConvBArgs 
 
       STAMP(3);
       // ---- backward through the three message GVPs
+      // Lanes past the wave's last edge carry d_ms = d_mv = 0 (initialised above, loaded only `if (active)`), and every
+      // gradient below is linear in them: their dY operands of the weight-gradient outer products are exactly zero, so
+      // the per-operand `active ? x : 0` selects of weight_grads are compiled out here (~60 v_cndmask per tile).
+      constexpr bool kAllActive = true;
       float d_b[4], d_bv[3][1];
       {
         f4 d_so[1] = {d_ms};
@@ -527,7 +531,7 @@ __global__ __launch_bounds__(CB_TPB, CB_WPB / 4) void conv_bwd_kernel(ConvBArgs 
         QMsg2::Grads gr;
         QMsg2::template backward<Io<ST>::BF>(imgT + IM::TC_M2, lane, c2[0], d_so, d_vo, d_b, d_bv, gr);
         STAMP(10);
-        QMsg2::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::M2, first, lane, 0, active, b2[0], bv2[0], c2[0], gr, CB_TSCR);
+        QMsg2::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::M2, first, lane, 0, kAllActive, b2[0], bv2[0], c2[0], gr, CB_TSCR);
       }
       {
         f4 d_so[1] = {f4{d_b[0], d_b[1], d_b[2], d_b[3]}};
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(CB_TPB, CB_WPB / 4) void conv_bwd_kernel(ConvBArgs 
         STAMP(11);
         QMsg1::template backward<Io<ST>::BF>(imgT + IM::TC_M1, lane, c1[0], d_so, d_vo, d_b, d_bv, gr);
         STAMP(12);
-        QMsg1::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::M1, first, lane, 0, active, b1[0], bv1[0], c1[0], gr, CB_TSCR);
+        QMsg1::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::M1, first, lane, 0, kAllActive, b1[0], bv1[0], c1[0], gr, CB_TSCR);
       }
       float d_b0[16], d_bv0[3][3];
       {
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(CB_TPB, CB_WPB / 4) void conv_bwd_kernel(ConvBArgs 
         STAMP(13);
         QMsg0::template backward<Io<ST>::BF>(imgT + IM::TC_M0, lane, c0[0], d_so, d_vo, d_b0, d_bv0, gr);
         STAMP(14);
-        QMsg0::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::M0, first, lane, 0, active, b0[0], bv0[0], c0[0], gr, CB_TSCR);
+        QMsg0::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::M0, first, lane, 0, kAllActive, b0[0], bv0[0], c0[0], gr, CB_TSCR);
       }
       STAMP(4);
       // ---- d(edge embedding) of this layer -> g_e (plain stores, sorted-edge order)
