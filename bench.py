@@ -146,7 +146,7 @@ def committed_traffic(workload, kernel, dtype="f32"):
     gfx950 correction applied: tools/pmc_summarise.py).  Only reported when the file was measured on the SAME
     kernel sources and workload; otherwise null (a stale number is worse than none)."""
     tag = workload if dtype == "f32" else f"{workload}_{dtype}"
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(REPO, "profiles", rnd, f"pmc_traffic_{tag}.json")
         if not os.path.exists(path) and workload == "davis_b64":
             path = os.path.join(REPO, "profiles", rnd, "pmc_traffic.json")
