@@ -32,7 +32,7 @@ Pinning status
   no reference test or golden vector covers them): restated from PyG's
   published definitions -- PARITY UNPINNED at that boundary; pinned only
   structurally by the shapes / key names / parameter counts in
-  ``pretrained_model_downstream/`` (see ``tests/test_state_dict_contract.py``).
+  ``pretrained_model_downstream/`` (see ``tests/test_dropin_boundary.py``).
 """
 from __future__ import annotations
 
