@@ -7,6 +7,10 @@
 #include "gvp_math.h"
 #include "gvp_rng.h"
 
+// Tile policy index the launchers in namespace quad take (their `bf16` parameter): activation storage type x layer kind
+// (cgvp_dims.storage / cgvp_dims.layer_kind; gvp_quad.h LayerKind).  bf16 storage exists for CASTER-DTA's layers only.
+constexpr int POLICY_F32 = 0, POLICY_BF16 = 1, POLICY_GVPDEF = 2, POLICY_LINEAR = 3;
+
 // Float offsets of the per-kernel slices inside the fragment image.
 struct QuadOffsets {
   int emb, conv0, node0, layer_stride, head, total;

@@ -28,9 +28,21 @@ inline int check_dims(const cgvp_dims* d) {
       d->edge_hidden_s != ES || d->edge_hidden_v != EV || d->out_s != OUT)
     return CGVP_ERR_UNSUPPORTED_DIMS;
   if (d->storage != CGVP_F32 && d->storage != CGVP_BF16) return CGVP_ERR_UNSUPPORTED_DIMS;
+  if (d->layer_kind < CGVP_LAYER_GATED || d->layer_kind > CGVP_LAYER_LINEAR) return CGVP_ERR_UNSUPPORTED_DIMS;
+  if (d->layer_kind != CGVP_LAYER_GATED && d->storage != CGVP_F32) return CGVP_ERR_UNSUPPORTED_DIMS;
   return 0;
 }
-inline int is_bf16(const cgvp_dims* d) { return d->storage == CGVP_BF16 ? 1 : 0; }
+// entry points that exist for CASTER-DTA's gated layers only (embeddings, head, fused layer, whole passes)
+inline int check_dims_gated(const cgvp_dims* d) {
+  if (int rc = check_dims(d)) return rc;
+  return d->layer_kind == CGVP_LAYER_GATED ? 0 : CGVP_ERR_UNSUPPORTED_DIMS;
+}
+// tile policy index of the MFMA launchers (gvp_internal.h): storage type for the gated kind, else the layer kind
+inline int policy_of(const cgvp_dims* d) {
+  if (d->layer_kind == CGVP_LAYER_GVPDEF) return POLICY_GVPDEF;
+  if (d->layer_kind == CGVP_LAYER_LINEAR) return POLICY_LINEAR;
+  return d->storage == CGVP_BF16 ? POLICY_BF16 : POLICY_F32;
+}
 
 inline EncLayout cvt(const cgvp_layout& l) {
   EncLayout L;
@@ -692,7 +704,7 @@ int cgvp_lba_prepare(const cgvp_dims* dims, const cgvp_layout* layout, const flo
   if (int rc = check_dims(dims)) return rc;
   if (!layout || !params || !image) return CGVP_ERR_BAD_ARG;
   // bf16 storage: the fragments of every GEMM with K > 4 are packed as bf16 for v_mfma_f32_16x16x16_bf16 (gvp_quad.h)
-  if (int rc = quad::prepare(cvt(*layout), num_convs_of(*layout), is_bf16(dims) ? 1 : 0, params, image, (hipStream_t)stream)) return rc;
+  if (int rc = quad::prepare(cvt(*layout), num_convs_of(*layout), policy_of(dims) == POLICY_BF16 ? 1 : 0, params, image, (hipStream_t)stream)) return rc;
   return launch_status();
 }
 
@@ -700,7 +712,7 @@ int cgvp_lba_pass_begin(const cgvp_dims* dims, const cgvp_layout* layout, const 
                         const float* x_s, const float* x_v, const int64_t* ntypes, int64_t N, float* h,
                         uint64_t* rng_state, uint64_t* rng_out, const int64_t* edge_index, int64_t E,
                         int32_t* csr_counters, void* stream) {
-  if (int rc = check_dims(dims)) return rc;
+  if (int rc = check_dims_gated(dims)) return rc;
   if (N < 0 || E < 0 || !layout || !params || !image || (layout->nt_node > 0 && N > 0 && !ntypes)) return CGVP_ERR_BAD_ARG;
   if ((rng_state != nullptr) != (rng_out != nullptr)) return CGVP_ERR_BAD_ARG;
   if (((uintptr_t)rng_state & 7) || ((uintptr_t)rng_out & 7) || ((uintptr_t)h & 15) || ((uintptr_t)image & 15)) return CGVP_ERR_BAD_ARG;
@@ -709,7 +721,7 @@ int cgvp_lba_pass_begin(const cgvp_dims* dims, const cgvp_layout* layout, const 
   if (N >= (int64_t)1 << 31 || E >= (int64_t)1 << 31) return CGVP_ERR_BAD_ARG;
   if (N == 0 && rng_state)           // no embedding block exists to do the hand-off
     if (int rc = cgvp_rng_next(rng_state, rng_out, stream)) return rc;
-  if (int rc = quad::pass_begin(cvt(*layout), num_convs_of(*layout), is_bf16(dims), params, image, x_s, x_v, ntypes, N, h,
+  if (int rc = quad::pass_begin(cvt(*layout), num_convs_of(*layout), policy_of(dims), params, image, x_s, x_v, ntypes, N, h,
                                 reinterpret_cast<unsigned long long*>(rng_state), reinterpret_cast<unsigned long long*>(rng_out),
                                 edge_index, E, csr_counters, (hipStream_t)stream)) return rc;
   return launch_status();
@@ -718,7 +730,7 @@ int cgvp_lba_pass_begin(const cgvp_dims* dims, const cgvp_layout* layout, const 
 int cgvp_node_embed_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* params,
                         const float* image, const float* x_s, const float* x_v, const int64_t* ntypes,
                         int64_t N, float* h, uint64_t* rng_state, uint64_t* rng_out, void* stream) {
-  if (int rc = check_dims(dims)) return rc;
+  if (int rc = check_dims_gated(dims)) return rc;
   if (N < 0 || !layout || !params || (layout->nt_node > 0 && N > 0 && !ntypes)) return CGVP_ERR_BAD_ARG;
   if ((rng_state != nullptr) != (rng_out != nullptr) || (rng_state && !image)) return CGVP_ERR_BAD_ARG;
   if (((uintptr_t)rng_state & 7) || ((uintptr_t)rng_out & 7)) return CGVP_ERR_BAD_ARG;
@@ -730,10 +742,10 @@ int cgvp_node_embed_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
     if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
     if (int rc = quad::node_embed(layout->nt_node, image + o.emb, x_s, x_v, ntypes, N, h,
                                   reinterpret_cast<unsigned long long*>(rng_state),
-                                  reinterpret_cast<unsigned long long*>(rng_out), is_bf16(dims), (hipStream_t)stream)) return rc;
+                                  reinterpret_cast<unsigned long long*>(rng_out), policy_of(dims), (hipStream_t)stream)) return rc;
     return launch_status();
   }
-  if (is_bf16(dims)) return CGVP_ERR_UNSUPPORTED_DIMS;      // bf16 storage is a feature of the MFMA kernels
+  if (policy_of(dims)) return CGVP_ERR_UNSUPPORTED_DIMS;      // bf16 storage is a feature of the MFMA kernels
   NodeEmbedArgs a{params, cvt(*layout), x_s, x_v, ntypes, N, h};
   const dim3 grid((unsigned)((N + WAVE - 1) / WAVE));
   hipStream_t st = (hipStream_t)stream;
@@ -766,11 +778,11 @@ int cgvp_conv_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float*
     if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
     if (int rc = quad::conv(layout->nt_edge, image + o.conv0 + layer * o.layer_stride, h, e_s, e_v, etypes, rowptr,
                             eperm, esrc, edst, N, E, aggr_mean ? 1 : 0, dh, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
-                            nullptr, gvp::RngArgs{nullptr, 0.f, 0}, e_in, e_in ? nullptr : e_out, is_bf16(dims),
+                            nullptr, gvp::RngArgs{nullptr, 0.f, 0}, e_in, e_in ? nullptr : e_out, policy_of(dims),
                             (hipStream_t)stream)) return rc;
     return launch_status();
   }
-  if (is_bf16(dims)) return CGVP_ERR_UNSUPPORTED_DIMS;
+  if (policy_of(dims)) return CGVP_ERR_UNSUPPORTED_DIMS;
   // target nodes per workgroup: aim at ~48 of the 64 edge lanes per chunk
   int64_t deg = (E + N - 1) / N;
   if (deg < 1) deg = 1;
@@ -794,7 +806,7 @@ int cgvp_conv_layer_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
                         int64_t N, int64_t E, int32_t aggr_mean, const float* mask0, const float* mask1,
                         const cgvp_rng* rng, int32_t with_head, const float* e_in, float* e_out, float* dh,
                         float* h_out, float* out, void* stream) {
-  if (int rc = check_dims(dims)) return rc;
+  if (int rc = check_dims_gated(dims)) return rc;
   if (int rc = check_rng(rng)) return rc;
   if (N < 0 || E < 0 || !layout || !image) return CGVP_ERR_BAD_ARG;
   if (layer < 0 || layer >= num_convs_of(*layout)) return CGVP_ERR_BAD_ARG;
@@ -809,7 +821,7 @@ int cgvp_conv_layer_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
   if (int rc = quad::conv(layout->nt_edge, image + o.conv0 + layer * o.layer_stride, h, e_s, e_v, etypes, rowptr, eperm,
                           esrc, edst, N, E, aggr_mean ? 1 : 0, dh, with_head ? 2 : 1,
                           image + o.node0 + layer * o.layer_stride, image + o.head, h_out, out, mask0, mask1,
-                          rng_args(rng, 2 * layer), e_in, e_in ? nullptr : e_out, is_bf16(dims), (hipStream_t)stream)) return rc;
+                          rng_args(rng, 2 * layer), e_in, e_in ? nullptr : e_out, policy_of(dims), (hipStream_t)stream)) return rc;
   return launch_status();
 }
 
@@ -828,10 +840,10 @@ int cgvp_node_update_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const
     if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
     if (int rc = quad::node_update(image + o.node0 + layer * o.layer_stride, image + o.head, h, dh, N,
                                    with_head ? 1 : 0, h_out, out, nullptr, nullptr, gvp::RngArgs{nullptr, 0.f, 0},
-                                   is_bf16(dims), (hipStream_t)stream)) return rc;
+                                   policy_of(dims), (hipStream_t)stream)) return rc;
     return launch_status();
   }
-  if (is_bf16(dims)) return CGVP_ERR_UNSUPPORTED_DIMS;
+  if (policy_of(dims)) return CGVP_ERR_UNSUPPORTED_DIMS;
   NodeUpdateArgs a{params, cvt(*layout), layer, h, dh, N, h_out, out};
   dim3 grid((unsigned)((N + WAVE - 1) / WAVE));
   if (with_head) hipLaunchKernelGGL(node_update_kernel<true>, grid, dim3(WAVE), 0, (hipStream_t)stream, a);
@@ -855,7 +867,7 @@ int cgvp_node_update_fwd_train(const cgvp_dims* dims, const cgvp_layout* layout,
   if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
   if (int rc = quad::node_update(image + o.node0 + layer * o.layer_stride, image + o.head, h, dh, N,
                                  with_head ? 1 : 0, h_out, out, mask0, mask1, rng_args(rng, 2 * layer),
-                                 is_bf16(dims), (hipStream_t)stream)) return rc;
+                                 policy_of(dims), (hipStream_t)stream)) return rc;
   return launch_status();
 }
 
@@ -883,6 +895,7 @@ int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const
   if (layer < 0 || layer >= nc) return CGVP_ERR_BAD_ARG;
   if (N == 0) return 0;
   if (!h || !dh || !g_dh || (with_head && (!g_out || !h_out))) return CGVP_ERR_BAD_ARG;
+  if (with_head && dims->layer_kind != CGVP_LAYER_GATED) return CGVP_ERR_UNSUPPORTED_DIMS;     // the head is CASTER-DTA's
   const void* al[] = {h, dh, mask0, mask1, h_out, g_out, g_up0, g_up1, g_up2, g_dh, g_h, zero_out};
   for (const void* q : al) if ((uintptr_t)q & 15) return CGVP_ERR_BAD_ARG;
   QuadOffsets o;
@@ -893,12 +906,12 @@ int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const
   float* head_slab = workspace + (size_t)kBwdMaxGrid * nd;
   if (with_head) {
     // the head's d h_out lands in g_dh and is consumed in place as the node stage's upstream
-    if (int rc = quad::head_bwd(image + o.head, image + o.headT, h_out, g_out, N, g_dh, head_slab, &hgrid, is_bf16(dims), st)) return rc;
+    if (int rc = quad::head_bwd(image + o.head, image + o.headT, h_out, g_out, N, g_dh, head_slab, &hgrid, policy_of(dims), st)) return rc;
     g_up0 = g_dh; g_up1 = nullptr; g_up2 = nullptr;
   }
   if (int rc = quad::node_update_bwd(image + o.node0 + layer * o.layer_stride, image + o.nodeT0 + layer * o.layerT_stride,
                                      h, dh, mask0, mask1, rng_args(rng, 2 * layer), g_up0, g_up1, g_up2, N, g_dh, g_h, zero_out,
-                                     workspace, &grid, is_bf16(dims), st)) return rc;
+                                     workspace, &grid, policy_of(dims), st)) return rc;
   const int node_len = conv_ff1() + LFf1::size(0) - conv_ln0();          // norm.0 .. end of ff_func.1
   cgvp_segment sg[2] = {{workspace, grid, nd, 0, node_len, layout->conv0 + layer * layout->conv_stride + conv_ln0()},
                         {head_slab, hgrid, hd, 0, layout->total - layout->ln_out, layout->ln_out}};
@@ -932,7 +945,7 @@ int cgvp_conv_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float*
   }
   if (int rc = quad::conv_bwd(layout->nt_edge, image + o.conv0 + layer * o.layer_stride,
                               image + o.convT0 + layer * o.layerT_stride, h, e_emb, rowptr, esrc, edst, N, E,
-                              aggr_mean ? 1 : 0, g_dh, g_src, g_dst, g_e, workspace, &grid, is_bf16(dims), st)) return rc;
+                              aggr_mean ? 1 : 0, g_dh, g_src, g_dst, g_e, workspace, &grid, policy_of(dims), st)) return rc;
   cgvp_segment sg[1] = {{workspace, grid, ct, 0, conv_ln0(), layout->conv0 + layer * layout->conv_stride}};
   if (segs && nsegs) { segs[0] = sg[0]; *nsegs = 1; }
   else quad::reduce_segments(sg, 1, grad_params, st);
@@ -943,7 +956,7 @@ int cgvp_edge_embed_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
                         const float* e_v, const int64_t* etypes, const int32_t* eperm, int64_t E,
                         const float* const* g_e, int32_t num_g, float* grad_params, float* workspace,
                         cgvp_segment* segs, int32_t* nsegs, void* stream) {
-  if (int rc = check_dims(dims)) return rc;
+  if (int rc = check_dims_gated(dims)) return rc;
   if (E < 0 || !layout || !image || !grad_params || !workspace || !g_e || num_g < 1) return CGVP_ERR_BAD_ARG;
   if (segs && nsegs) *nsegs = 0;
   if (E == 0) return 0;
@@ -958,7 +971,7 @@ int cgvp_edge_embed_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
   hipStream_t st = (hipStream_t)stream;
   // gvp_edge's fragments are the head of every conv slice (identical in all layers): layer 0's is used
   if (int rc = quad::edge_embed_bwd(layout->nt_edge, image + o.conv0, image + o.convT0, e_s, e_v, etypes, eperm, E, g_e,
-                                    num_g, workspace, &grid, is_bf16(dims), st)) return rc;
+                                    num_g, workspace, &grid, policy_of(dims), st)) return rc;
   cgvp_segment sg[1] = {{workspace, grid, ce, 0, layout->conv0 - layout->edge_gvp, layout->edge_gvp}};
   if (segs && nsegs) { segs[0] = sg[0]; *nsegs = 1; }
   else quad::reduce_segments(sg, 1, grad_params, st);
@@ -969,7 +982,7 @@ int cgvp_node_embed_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
                         const float* x_v, const int64_t* ntypes, int64_t N, const float* g_up0,
                         const float* g_up1, const float* g_up2, float* g_x_s, float* g_x_v, float* grad_params,
                         float* workspace, cgvp_segment* segs, int32_t* nsegs, void* stream) {
-  if (int rc = check_dims(dims)) return rc;
+  if (int rc = check_dims_gated(dims)) return rc;
   if (N < 0 || !layout || !image || !grad_params || !workspace) return CGVP_ERR_BAD_ARG;
   if (N == 0) return 0;
   if (!x_s || !x_v || (layout->nt_node > 0 && !ntypes) || ((g_x_s == nullptr) != (g_x_v == nullptr))) return CGVP_ERR_BAD_ARG;
@@ -981,7 +994,7 @@ int cgvp_node_embed_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
   if (int rc = quad::bwd_block_sizes(layout->nt_node, layout->nt_edge, &emb, &ce, &ct, &nd, &hd)) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (int rc = quad::node_embed_bwd(layout->nt_node, image + o.emb, image + o.embT, x_s, x_v, ntypes, N, g_up0, g_up1,
-                                    g_up2, g_x_s, g_x_v, workspace, &grid, is_bf16(dims), st)) return rc;
+                                    g_up2, g_x_s, g_x_v, workspace, &grid, policy_of(dims), st)) return rc;
   cgvp_segment sg[1] = {{workspace, grid, emb, 0, layout->edge_gvp - layout->node_gvp, layout->node_gvp}};
   if (segs && nsegs) { segs[0] = sg[0]; *nsegs = 1; }
   else quad::reduce_segments(sg, 1, grad_params, st);

@@ -57,6 +57,11 @@ template <> struct Io<float> {
   static __device__ __forceinline__ float rt(float v) { return v; }
   static __device__ __forceinline__ f4 rt4(f4 v) { return v; }
 };
+// Tile policies: ST names the storage element type of the activation buffers AND the kind of GVPConvLayer the
+// kernel computes (LayerKind<ST> below).  float / bf16s: CASTER-DTA's layers (relu, vector gate); the two below are
+// fp32 storage with the reference's other two layer kinds (a11 of the survey: CPD-style and PocketMiner-style stacks).
+struct f32_gvpdef {};   // activations (relu, sigmoid), vector_gate=False: the gvp_layers.py defaults
+struct f32_linear {};   // activations (None, None), vector_gate=False
 template <> struct Io<bf16s> {
   static constexpr bool BF = true;
   static __device__ __forceinline__ float widen(uint32_t hi16) { return __uint_as_float(hi16); }
@@ -78,6 +83,9 @@ template <> struct Io<bf16s> {
   static __device__ __forceinline__ float rt(float v) { return widen((uint32_t)narrow(v) << 16); }
   static __device__ __forceinline__ f4 rt4(f4 v) { return f4{rt(v[0]), rt(v[1]), rt(v[2]), rt(v[3])}; }
 };
+
+template <> struct Io<f32_gvpdef> : Io<float> {};
+template <> struct Io<f32_linear> : Io<float> {};
 
 // One run of k-slots of a GEMM: which source column of W feeds slot (step s, group g).
 template <int KIND, int BASE, int WIDTH>
@@ -464,7 +472,12 @@ __device__ __forceinline__ void flush_slots(float* dst, bool first, int LD, cons
 //   SSegs: k-slots of the scalar inputs, columns relative to the ws row (after
 //          the NT type columns are skipped by BASE offsets chosen by the caller)
 //   VSegs: k-slots of the vector-channel inputs (columns of wh)
-template <int NT, int SI, int VI, int SO, int VO, int H, bool RELU_, class SSegs, class VSegs>
+//   VM   : what scales the vector outputs (gvp_layers.py:155-166): VM_GATE  v * sigmoid(wsv(s))       vector_gate=True
+//                                                                 VM_NORM  v * sigmoid(|v|)          vector_act=sigmoid
+//                                                                 VM_NONE  v                         vector_act=None
+//          (the wsv slots of the image / gradient block stay in place for every VM: zero, and zero gradient)
+constexpr int VM_GATE = 0, VM_NORM = 1, VM_NONE = 2;
+template <int NT, int SI, int VI, int SO, int VO, int H, bool RELU_, class SSegs, class VSegs, int VM = VM_GATE>
 struct GvpQ {
   static_assert(SO % 16 == 0, "scalar outputs are whole tiles");
   static constexpr bool RELU = RELU_;
@@ -555,22 +568,24 @@ struct GvpQ {
       for (int j = 0; j < TN; ++j) c[j].sp[t] = acc[j];
     }
     if (VO > 0) {
-      float bsp[TN][4 * OT];
-      f4 gate[TN];
+      if (VM == VM_GATE) {
+        float bsp[TN][4 * OT];
+        f4 gate[TN];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
+        for (int j = 0; j < TN; ++j) {
 #pragma unroll
-        for (int t = 0; t < OT; ++t)
+          for (int t = 0; t < OT; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) bsp[j][4 * t + r] = c[j].sp[t][r];
+            for (int r = 0; r < 4; ++r) bsp[j][4 * t + r] = c[j].sp[t][r];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gate[j][r] = img[V_BSV + ((4 * r + g) & 15)];
+          for (int r = 0; r < 4; ++r) gate[j][r] = img[V_BSV + ((4 * r + g) & 15)];
+        }
+        apply<GWsv, TN, BF>(img + F_WSV * 64, 0, bsp, gate, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c[j].sg[r] = gvp::f_sigmoid(gate[j][r]);
       }
-      apply<GWsv, TN, BF>(img + F_WSV * 64, 0, bsp, gate, lane);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) c[j].sg[r] = gvp::f_sigmoid(gate[j][r]);
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
         float bh[TN][HR];
@@ -583,12 +598,21 @@ struct GvpQ {
         }
         apply<GWv, TN, BF>(img + F_WV * 64, 0, bh, acc, lane);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          c[j].vp[p] = acc[j];
-#pragma unroll
-          for (int r = 0; r < VOR; ++r) vo[j][p][r] = acc[j][r] * c[j].sg[r];
-        }
+        for (int j = 0; j < TN; ++j) c[j].vp[p] = acc[j];
       }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < VOR; ++r) {
+          if (VM == VM_NORM) {          // sigmoid of the clamped norm of the un-scaled output (gvp_layers.py:164-166)
+            const float n2 = c[j].vp[0][r] * c[j].vp[0][r] + c[j].vp[1][r] * c[j].vp[1][r] + c[j].vp[2][r] * c[j].vp[2][r];
+            c[j].sg[r] = gvp::f_sigmoid(gvp::f_sqrt(gvp::f_max(n2, gvp::kNormEps)));
+          } else if (VM == VM_NONE) {
+            c[j].sg[r] = 1.0f;
+          }
+#pragma unroll
+          for (int p = 0; p < 3; ++p) vo[j][p][r] = c[j].vp[p][r] * c[j].sg[r];
+        }
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -645,16 +669,24 @@ struct GvpQ {
         float dsg = 0.f;
 #pragma unroll
         for (int p = 0; p < 3; ++p) { dsg = fmaf(d_vo[p][r], c.vp[p][r], dsg); gr.dvp[p][r] = d_vo[p][r] * sg; }
-        gr.dgate[r] = dsg * sg * (1.0f - sg);
+        if (VM == VM_GATE) gr.dgate[r] = dsg * sg * (1.0f - sg);
+        if (VM == VM_NORM) {            // vo = vp sigmoid(n), n = sqrt(max(|vp|^2, eps)): no gradient through n below the clamp
+          const float n2 = c.vp[0][r] * c.vp[0][r] + c.vp[1][r] * c.vp[1][r] + c.vp[2][r] * c.vp[2][r];
+          const float k = n2 > gvp::kNormEps ? dsg * sg * (1.0f - sg) * gvp::f_rsqrt(n2) : 0.f;
+#pragma unroll
+          for (int p = 0; p < 3; ++p) gr.dvp[p][r] = fmaf(k, c.vp[p][r], gr.dvp[p][r]);
+        }
       }
-      float bg[1][TWsv::NSTEPS];
+      if (VM == VM_GATE) {
+        float bg[1][TWsv::NSTEPS];
 #pragma unroll
-      for (int r = 0; r < TWsv::NSTEPS; ++r) bg[0][r] = gr.dgate[r];
+        for (int r = 0; r < TWsv::NSTEPS; ++r) bg[0][r] = gr.dgate[r];
 #pragma unroll
-      for (int t = 0; t < OT; ++t) {
-        f4 acc[1] = {gr.dsp[t]};
-        apply<TWsv, 1, BF>(imgT + FT_WSV * 64, t, bg, acc, lane);
-        gr.dsp[t] = acc[0];
+        for (int t = 0; t < OT; ++t) {
+          f4 acc[1] = {gr.dsp[t]};
+          apply<TWsv, 1, BF>(imgT + FT_WSV * 64, t, bg, acc, lane);
+          gr.dsp[t] = acc[0];
+        }
       }
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
@@ -960,6 +992,25 @@ using QMsg1 = GvpQ<0, NS, NV, NS, NV, NV, true, Segs<Seg<P1, 0, NS>>, Segs<Seg<P
 using QMsg2 = GvpQ<0, NS, NV, NS, NV, NV, false, Segs<Seg<P1, 0, NS>>, Segs<Seg<P2, 0, NV>>>;
 using QFf0 = GvpQ<0, NS, NV, FS, FV, FV, true, Segs<Seg<P1, 0, NS>>, Segs<Seg<P2, 0, NV>>>;
 using QFf1 = GvpQ<0, FS, FV, NS, NV, FV, false, Segs<Seg<P1, 0, FS>>, Segs<Seg<P2, 0, FV>>>;
+
+// The same five GVPs of a GVPConvLayer for the tile policy ST (Io<ST>, LayerKind<ST>): image slices, arena blocks and
+// gradient blocks have the SAME size and layout for every kind, only the tile arithmetic differs.
+//   message_func.{0,1} / ff_func.0 : `activations`, `vector_gate` of the layer (gvp_layers.py:271-288, :355-366)
+//   message_func.2 / ff_func.1     : activations (None, None), same vector_gate
+template <typename ST> struct LayerKind { static constexpr bool RELU = true; static constexpr int VM = VM_GATE, VM_LAST = VM_GATE; };
+template <> struct LayerKind<f32_gvpdef> { static constexpr bool RELU = true; static constexpr int VM = VM_NORM, VM_LAST = VM_NONE; };
+template <> struct LayerKind<f32_linear> { static constexpr bool RELU = false; static constexpr int VM = VM_NONE, VM_LAST = VM_NONE; };
+template <typename ST>
+using Msg0 = GvpQ<0, MS, MV, NS, NV, MV, LayerKind<ST>::RELU, Segs<Seg<P1, 0, MS>>,
+                  Segs<Seg<P2, 0, NV>, Seg<P2, NV + EV, NV>, Seg<P2, NV, EV>>, LayerKind<ST>::VM>;
+template <typename ST>
+using Msg1 = GvpQ<0, NS, NV, NS, NV, NV, LayerKind<ST>::RELU, Segs<Seg<P1, 0, NS>>, Segs<Seg<P2, 0, NV>>, LayerKind<ST>::VM>;
+template <typename ST>
+using Msg2 = GvpQ<0, NS, NV, NS, NV, NV, false, Segs<Seg<P1, 0, NS>>, Segs<Seg<P2, 0, NV>>, LayerKind<ST>::VM_LAST>;
+template <typename ST>
+using Ff0 = GvpQ<0, NS, NV, FS, FV, FV, LayerKind<ST>::RELU, Segs<Seg<P1, 0, NS>>, Segs<Seg<P2, 0, NV>>, LayerKind<ST>::VM>;
+template <typename ST>
+using Ff1 = GvpQ<0, FS, FV, NS, NV, FV, false, Segs<Seg<P1, 0, FS>>, Segs<Seg<P2, 0, FV>>, LayerKind<ST>::VM_LAST>;
 using QHead = GvpQ<0, NS, NV, OUT, 0, NV, true, Segs<Seg<P1, 0, NS>>, Segs<Seg<P2, 0, NV>>>;
 
 // Image = what the kernels copy to LDS, one slice per kernel:

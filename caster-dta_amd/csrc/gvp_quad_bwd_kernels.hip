@@ -224,20 +224,20 @@ __global__ __launch_bounds__(BW_TPB, 2) void node_bwd_kernel(NodeBArgs a) {
     f4 hs[1][4], s2[1][1];
     float hv[1][3][2], v2[1][3][1];
     float bs0[1][4], bv0[1][3][1], bs1[1][16], bv1[1][3][2];
-    QFf0::Cache c0[1];
-    QFf1::Cache c1[1];
+    typename Ff0<ST>::Cache c0[1];
+    typename Ff1<ST>::Cache c1[1];
 #pragma unroll
     for (int r = 0; r < 4; ++r) bs0[0][r] = y[0][r];
 #pragma unroll
     for (int p = 0; p < 3; ++p) bv0[0][p][0] = yv[p][0];
-    QFf0::template forward<1, Io<ST>::BF>(f_node + IM::ND_FF0, lane, zt, bs0, bv0, hs, hv, c0);
+    Ff0<ST>::template forward<1, Io<ST>::BF>(f_node + IM::ND_FF0, lane, zt, bs0, bv0, hs, hv, c0);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) bs1[0][4 * t + r] = hs[0][t][r];
 #pragma unroll
     for (int p = 0; p < 3; ++p) { bv1[0][p][0] = hv[0][p][0]; bv1[0][p][1] = hv[0][p][1]; }
-    QFf1::template forward<1, Io<ST>::BF>(f_node + IM::ND_FF1, lane, zt, bs1, bv1, s2, v2, c1);
+    Ff1<ST>::template forward<1, Io<ST>::BF>(f_node + IM::ND_FF1, lane, zt, bs1, bv1, s2, v2, c1);
     f4 z[1] = {y[0] + s2[0][0] * m1s};
     float zv[3][1];
 #pragma unroll
@@ -255,22 +255,22 @@ __global__ __launch_bounds__(BW_TPB, 2) void node_bwd_kernel(NodeBArgs a) {
     {
       f4 d_so[1] = {gs[0] * m1s};
       float d_vo[3][1] = {{gv[0][0] * m1v}, {gv[1][0] * m1v}, {gv[2][0] * m1v}};
-      QFf1::Grads gr1;
+      typename Ff1<ST>::Grads gr1;
       STAMP(4);
-      QFf1::template backward<Io<ST>::BF>(t_node + IM::TN_FF1, lane, c1[0], d_so, d_vo, d_hs, d_hv, gr1);
+      Ff1<ST>::template backward<Io<ST>::BF>(t_node + IM::TN_FF1, lane, c1[0], d_so, d_vo, d_hs, d_hv, gr1);
       STAMP(5);
-      QFf1::template weight_grads<AccPriv, Io<ST>::BF>(gblk + NB_FF1, first, lane, 0, active, bs1[0], bv1[0], c1[0], gr1, tscr);
+      Ff1<ST>::template weight_grads<AccPriv, Io<ST>::BF>(gblk + NB_FF1, first, lane, 0, active, bs1[0], bv1[0], c1[0], gr1, tscr);
     }
     {
       f4 d_so[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) d_so[t] = f4{d_hs[4 * t], d_hs[4 * t + 1], d_hs[4 * t + 2], d_hs[4 * t + 3]};
       float d_ys[4], d_yv[3][1];
-      QFf0::Grads gr0;
+      typename Ff0<ST>::Grads gr0;
       STAMP(6);
-      QFf0::template backward<Io<ST>::BF>(t_node + IM::TN_FF0, lane, c0[0], d_so, d_hv, d_ys, d_yv, gr0);
+      Ff0<ST>::template backward<Io<ST>::BF>(t_node + IM::TN_FF0, lane, c0[0], d_so, d_hv, d_ys, d_yv, gr0);
       STAMP(7);
-      QFf0::template weight_grads<AccPriv, Io<ST>::BF>(gblk + NB_FF0, first, lane, 0, active, bs0[0], bv0[0], c0[0], gr0, tscr);
+      Ff0<ST>::template weight_grads<AccPriv, Io<ST>::BF>(gblk + NB_FF0, first, lane, 0, active, bs0[0], bv0[0], c0[0], gr0, tscr);
 #pragma unroll
       for (int r = 0; r < 4; ++r) gs[0][r] += d_ys[r];
 #pragma unroll
@@ -503,20 +503,20 @@ __global__ __launch_bounds__(CB_TPB, CB_WPB / 4) void conv_bwd_kernel(ConvBArgs 
       for (int d = 0; d < 3; ++d) { bv0[0][d][0] = vj[d]; bv0[0][d][1] = vi[d]; bv0[0][d][2] = ev[d]; }
       f4 s1[1][1], s2[1][1], s3[1][1];
       float v1[1][3][1], v2[1][3][1], v3[1][3][1];
-      QMsg0::Cache c0[1];
-      QMsg1::Cache c1[1];
-      QMsg2::Cache c2[1];
-      QMsg0::template forward<1, Io<ST>::BF>(img + IM::CV_M0, lane, zt, b0, bv0, s1, v1, c0);
+      typename Msg0<ST>::Cache c0[1];
+      typename Msg1<ST>::Cache c1[1];
+      typename Msg2<ST>::Cache c2[1];
+      Msg0<ST>::template forward<1, Io<ST>::BF>(img + IM::CV_M0, lane, zt, b0, bv0, s1, v1, c0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) b1[0][r] = s1[0][0][r];
 #pragma unroll
       for (int d = 0; d < 3; ++d) bv1[0][d][0] = v1[0][d][0];
-      QMsg1::template forward<1, Io<ST>::BF>(img + IM::CV_M1, lane, zt, b1, bv1, s2, v2, c1);
+      Msg1<ST>::template forward<1, Io<ST>::BF>(img + IM::CV_M1, lane, zt, b1, bv1, s2, v2, c1);
 #pragma unroll
       for (int r = 0; r < 4; ++r) b2[0][r] = s2[0][0][r];
 #pragma unroll
       for (int d = 0; d < 3; ++d) bv2[0][d][0] = v2[0][d][0];
-      QMsg2::template forward<1, Io<ST>::BF>(img + IM::CV_M2, lane, zt, b2, bv2, s3, v3, c2);
+      Msg2<ST>::template forward<1, Io<ST>::BF>(img + IM::CV_M2, lane, zt, b2, bv2, s3, v3, c2);
 
       STAMP(3);
       // ---- backward through the three message GVPs
@@ -528,29 +528,29 @@ __global__ __launch_bounds__(CB_TPB, CB_WPB / 4) void conv_bwd_kernel(ConvBArgs 
       {
         f4 d_so[1] = {d_ms};
         float d_vo[3][1] = {{d_mv[0]}, {d_mv[1]}, {d_mv[2]}};
-        QMsg2::Grads gr;
-        QMsg2::template backward<Io<ST>::BF>(imgT + IM::TC_M2, lane, c2[0], d_so, d_vo, d_b, d_bv, gr);
+        typename Msg2<ST>::Grads gr;
+        Msg2<ST>::template backward<Io<ST>::BF>(imgT + IM::TC_M2, lane, c2[0], d_so, d_vo, d_b, d_bv, gr);
         STAMP(10);
-        QMsg2::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::M2, first, lane, 0, kAllActive, b2[0], bv2[0], c2[0], gr, CB_TSCR);
+        Msg2<ST>::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::M2, first, lane, 0, kAllActive, b2[0], bv2[0], c2[0], gr, CB_TSCR);
       }
       {
         f4 d_so[1] = {f4{d_b[0], d_b[1], d_b[2], d_b[3]}};
         float d_vo[3][1] = {{d_bv[0][0]}, {d_bv[1][0]}, {d_bv[2][0]}};
-        QMsg1::Grads gr;
+        typename Msg1<ST>::Grads gr;
         STAMP(11);
-        QMsg1::template backward<Io<ST>::BF>(imgT + IM::TC_M1, lane, c1[0], d_so, d_vo, d_b, d_bv, gr);
+        Msg1<ST>::template backward<Io<ST>::BF>(imgT + IM::TC_M1, lane, c1[0], d_so, d_vo, d_b, d_bv, gr);
         STAMP(12);
-        QMsg1::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::M1, first, lane, 0, kAllActive, b1[0], bv1[0], c1[0], gr, CB_TSCR);
+        Msg1<ST>::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::M1, first, lane, 0, kAllActive, b1[0], bv1[0], c1[0], gr, CB_TSCR);
       }
       float d_b0[16], d_bv0[3][3];
       {
         f4 d_so[1] = {f4{d_b[0], d_b[1], d_b[2], d_b[3]}};
         float d_vo[3][1] = {{d_bv[0][0]}, {d_bv[1][0]}, {d_bv[2][0]}};
-        QMsg0::Grads gr;
+        typename Msg0<ST>::Grads gr;
         STAMP(13);
-        QMsg0::template backward<Io<ST>::BF>(imgT + IM::TC_M0, lane, c0[0], d_so, d_vo, d_b0, d_bv0, gr);
+        Msg0<ST>::template backward<Io<ST>::BF>(imgT + IM::TC_M0, lane, c0[0], d_so, d_vo, d_b0, d_bv0, gr);
         STAMP(14);
-        QMsg0::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::M0, first, lane, 0, kAllActive, b0[0], bv0[0], c0[0], gr, CB_TSCR);
+        Msg0<ST>::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::M0, first, lane, 0, kAllActive, b0[0], bv0[0], c0[0], gr, CB_TSCR);
       }
       STAMP(4);
       // ---- d(edge embedding) of this layer -> g_e (plain stores, sorted-edge order)
@@ -947,6 +947,20 @@ int reduce_slab(const float* slab, int rows, int stride, int col0, int len, floa
     }                                                                                                                         \
   } while (0)
 
+// the same for the two kernels that exist for every layer kind (`bf16` = tile policy index, gvp_internal.h)
+#define BWD_LAUNCH_KIND(KERNEL, G, TPB_, LDS_, ARGS)                                                                          \
+  do {                                                                                                                        \
+    if (bf16 == POLICY_GVPDEF) {                                                                                              \
+      CGVP_SET_DYN_LDS_ONCE(KERNEL(f32_gvpdef), LDS_);                                                                        \
+      hipLaunchKernelGGL((KERNEL(f32_gvpdef)), dim3(G), dim3(TPB_), (LDS_), st, ARGS);                                        \
+    } else if (bf16 == POLICY_LINEAR) {                                                                                       \
+      CGVP_SET_DYN_LDS_ONCE(KERNEL(f32_linear), LDS_);                                                                        \
+      hipLaunchKernelGGL((KERNEL(f32_linear)), dim3(G), dim3(TPB_), (LDS_), st, ARGS);                                        \
+    } else {                                                                                                                  \
+      BWD_LAUNCH(KERNEL, G, TPB_, LDS_, ARGS);                                                                                \
+    }                                                                                                                         \
+  } while (0)
+
 int node_update_bwd(const float* img_node, const float* imgT_node, const float* h, const float* dh,
                     const float* mask0, const float* mask1, gvp::RngArgs rng, const float* g_up0, const float* g_up1,
                     const float* g_up2, int64_t N, float* g_dh, float* g_h, float* zero_rows, float* slab, int* grid,
@@ -956,7 +970,7 @@ int node_update_bwd(const float* img_node, const float* imgT_node, const float* 
   *grid = G;
   const size_t lds = (size_t)node_bwd_lds_floats() * sizeof(float);
 #define K_(ST) node_bwd_kernel<ST>
-  BWD_LAUNCH(K_, G, BW_TPB, lds, a);
+  BWD_LAUNCH_KIND(K_, G, BW_TPB, lds, a);
 #undef K_
   return 0;
 }
@@ -981,6 +995,11 @@ int conv_bwd_impl(ConvBArgs& a, int* grid, int bf16, hipStream_t st) {
   *grid = G;
   const size_t lds = (size_t)conv_bwd_lds_floats<NTE>() * sizeof(float);
 #define K_(ST) conv_bwd_kernel<NTE, ST>
+  if (bf16 >= POLICY_GVPDEF) {
+    if constexpr (NTE == 0) BWD_LAUNCH_KIND(K_, G, CB_TPB, lds, a);
+    else return CGVP_ERR_UNSUPPORTED_DIMS;
+    return 0;
+  }
   BWD_LAUNCH(K_, G, CB_TPB, lds, a);
 #undef K_
   return 0;

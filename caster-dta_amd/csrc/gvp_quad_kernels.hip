@@ -295,8 +295,8 @@ __device__ __forceinline__ void node_tile(const float* nd, const float* hd, int 
       for (int r = 0; r < 4; ++r) bs[0][r] = s[0][r];
 #pragma unroll
       for (int p = 0; p < 3; ++p) bv[0][p][0] = v[p][0];
-      QFf0::Cache c[1];
-      QFf0::template forward<1, Io<ST>::BF>(nd + IM::ND_FF0, lane, zt, bs, bv, hs, hv, c);
+      typename Ff0<ST>::Cache c[1];
+      Ff0<ST>::template forward<1, Io<ST>::BF>(nd + IM::ND_FF0, lane, zt, bs, bv, hs, hv, c);
     }
     {
       float bs[1][16], bv[1][3][2];
@@ -306,8 +306,8 @@ __device__ __forceinline__ void node_tile(const float* nd, const float* hd, int 
         for (int r = 0; r < 4; ++r) bs[0][4 * t + r] = hs[0][t][r];
 #pragma unroll
       for (int p = 0; p < 3; ++p) { bv[0][p][0] = hv[0][p][0]; bv[0][p][1] = hv[0][p][1]; }
-      QFf1::Cache c[1];
-      QFf1::template forward<1, Io<ST>::BF>(nd + IM::ND_FF1, lane, zt, bs, bv, s2, v2, c);
+      typename Ff1<ST>::Cache c[1];
+      Ff1<ST>::template forward<1, Io<ST>::BF>(nd + IM::ND_FF1, lane, zt, bs, bv, s2, v2, c);
     }
     s[0] += s2[0][0] * m1s;
 #pragma unroll
@@ -529,8 +529,8 @@ __device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, i
 #pragma unroll
       for (int d = 0; d < 3; ++d) { bv[j][d][0] = vj[j][d]; bv[j][d][1] = vi[j][d]; bv[j][d][2] = e_v[j][d][0]; }
     }
-    QMsg0::Cache c[CTN];
-    QMsg0::template forward<CTN, Io<ST>::BF>(img + IM::CV_M0, lane, zero_t, bs, bv, s1, v1, c);
+    typename Msg0<ST>::Cache c[CTN];
+    Msg0<ST>::template forward<CTN, Io<ST>::BF>(img + IM::CV_M0, lane, zero_t, bs, bv, s1, v1, c);
   }
   {
     float bs[CTN][4], bv[CTN][3][1];
@@ -541,8 +541,8 @@ __device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, i
 #pragma unroll
       for (int d = 0; d < 3; ++d) bv[j][d][0] = v1[j][d][0];
     }
-    QMsg1::Cache c[CTN];
-    QMsg1::template forward<CTN, Io<ST>::BF>(img + IM::CV_M1, lane, zero_t, bs, bv, s2, v2, c);
+    typename Msg1<ST>::Cache c[CTN];
+    Msg1<ST>::template forward<CTN, Io<ST>::BF>(img + IM::CV_M1, lane, zero_t, bs, bv, s2, v2, c);
   }
   {
     float bs[CTN][4], bv[CTN][3][1];
@@ -553,8 +553,8 @@ __device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, i
 #pragma unroll
       for (int d = 0; d < 3; ++d) bv[j][d][0] = v2[j][d][0];
     }
-    QMsg2::Cache c[CTN];
-    QMsg2::template forward<CTN, Io<ST>::BF>(img + IM::CV_M2, lane, zero_t, bs, bv, s1, v1, c);
+    typename Msg2<ST>::Cache c[CTN];
+    Msg2<ST>::template forward<CTN, Io<ST>::BF>(img + IM::CV_M2, lane, zero_t, bs, bv, s1, v1, c);
   }
 #pragma unroll
   for (int j = 0; j < CTN; ++j) {
@@ -773,8 +773,17 @@ int conv_launch_s(const ConvQArgs& a, dim3 grid, hipStream_t st) {
   if (a.e_out) return conv_launch_e<NTE, FUSE, 1, ST>(a, grid, st);
   return conv_launch_e<NTE, FUSE, 0, ST>(a, grid, st);
 }
+// `bf16` below is the tile policy index (gvp_internal.h, POLICY_*): 0 float, 1 bf16s, 2 f32_gvpdef, 3 f32_linear
 template <int NTE, int FUSE>
 int conv_launch(const ConvQArgs& a, dim3 grid, int bf16, hipStream_t st) {
+  if (bf16 >= POLICY_GVPDEF) {      // the other layer kinds: stand-alone layers (stored edge embedding, no type columns, two launches)
+    if constexpr (NTE == 0 && FUSE == 0) {
+      if (!a.e_in) return CGVP_ERR_UNSUPPORTED_DIMS;
+      if (bf16 == POLICY_GVPDEF) return conv_launch_e<0, 0, 2, f32_gvpdef>(a, grid, st);
+      return conv_launch_e<0, 0, 2, f32_linear>(a, grid, st);
+    }
+    return CGVP_ERR_UNSUPPORTED_DIMS;
+  }
   if (bf16) return conv_launch_s<NTE, FUSE, bf16s>(a, grid, st);
   return conv_launch_s<NTE, FUSE, float>(a, grid, st);
 }
@@ -811,7 +820,11 @@ int node_update(const float* img_node, const float* img_head, const float* h, co
                 int bf16, hipStream_t st) {
   NodeQArgs a{img_node, img_head, h, dh, N, h_out, out, mask0, mask1, rng};
   const dim3 grid((unsigned)((N + WPB * TILE - 1) / (WPB * TILE)));
-  if (bf16) {
+  if (bf16 >= POLICY_GVPDEF) {
+    if (with_head) return CGVP_ERR_UNSUPPORTED_DIMS;
+    if (bf16 == POLICY_GVPDEF) hipLaunchKernelGGL((node_quad_kernel<false, f32_gvpdef>), grid, dim3(TPB), 0, st, a);
+    else hipLaunchKernelGGL((node_quad_kernel<false, f32_linear>), grid, dim3(TPB), 0, st, a);
+  } else if (bf16) {
     if (with_head) hipLaunchKernelGGL((node_quad_kernel<true, bf16s>), grid, dim3(TPB), 0, st, a);
     else hipLaunchKernelGGL((node_quad_kernel<false, bf16s>), grid, dim3(TPB), 0, st, a);
   } else {

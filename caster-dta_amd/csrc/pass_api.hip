@@ -160,6 +160,7 @@ int cgvp_stage_buffers(const cgvp_stage_item* items, int32_t n, void* stream) {
 int cgvp_lba_fwd_workspace(const cgvp_dims* dims, const cgvp_layout* layout, int64_t N, int64_t E, int32_t save_state,
                            cgvp_lba_fwd_ws* out) {
   if (!dims || !layout || !out || N < 0 || E < 0) return CGVP_ERR_BAD_ARG;
+  if (dims->layer_kind != CGVP_LAYER_GATED) return CGVP_ERR_UNSUPPORTED_DIMS;      // whole passes: CASTER-DTA's encoder only
   const int64_t img = cgvp_lba_image_floats(dims, layout);
   if (img < 0) return (int)img;
   const int nc = num_convs_of(*layout);
@@ -272,6 +273,7 @@ int cgvp_lba_forward_pass(const cgvp_dims* dims, const cgvp_layout* layout, cons
 
 int64_t cgvp_lba_bwd_workspace_bytes(const cgvp_dims* dims, const cgvp_layout* layout, int64_t N, int64_t E) {
   if (!dims || !layout || N < 0 || E < 0) return CGVP_ERR_BAD_ARG;
+  if (dims->layer_kind != CGVP_LAYER_GATED) return CGVP_ERR_UNSUPPORTED_DIMS;
   LbaBwdWs w;
   if (int rc = lba_bwd_layout(dims, layout, N, E, &w)) return rc;
   return w.total;

@@ -78,7 +78,7 @@ LbaCfg make_cfg(const std::vector<int64_t>& c, bool bf16) {
   TORCH_CHECK(c.size() == 13, "cfg must hold 13 integers");
   LbaCfg r;
   r.dims = cgvp_dims{(int32_t)c[0], (int32_t)c[1], (int32_t)c[2], (int32_t)c[3], (int32_t)c[4], (int32_t)c[5],
-                     (int32_t)c[6], (int32_t)c[7], (int32_t)c[8], bf16 ? CGVP_BF16 : CGVP_F32};
+                     (int32_t)c[6], (int32_t)c[7], (int32_t)c[8], bf16 ? CGVP_BF16 : CGVP_F32, CGVP_LAYER_GATED};
   check(cgvp_lba_layout(&r.dims, (int32_t)c[9], (int32_t)c[10], (int32_t)c[11], &r.layout), "cgvp_lba_layout");
   r.nc = (int)c[11];
   r.mean = c[12] != 0;

@@ -15,11 +15,11 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CGVP_LIB_PATH: A/B builds of the same ABI (diagnostics); the default is the in-tree library
 LIB_PATH = os.environ.get("CGVP_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libcaster_gvp.so")
-ABI_VERSION = 24
+ABI_VERSION = 25
 # sha256 of include/caster_gvp.h with comments, blank space and the CGVP_ABI_VERSION line removed, as
 # `abi_header_digest()` computes it.  tests/test_abi.py fails when the header's declarations change
 # without CGVP_ABI_VERSION, ABI_VERSION and this digest being updated together.
-ABI_HEADER_SHA256 = "62c0a18dc02a672c99a06b379776544e7d0a1517a1befe0a5c4e117249932053"
+ABI_HEADER_SHA256 = "71551f848a3c46e7c0400891fd99c3fd0fd62effc80d0f9d0305565e0c6e298d"
 
 
 class HipLibraryError(RuntimeError):
@@ -29,7 +29,7 @@ class HipLibraryError(RuntimeError):
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "node_in_s", "node_in_v", "edge_in_s", "edge_in_v", "hidden_s", "hidden_v",
-        "edge_hidden_s", "edge_hidden_v", "out_s", "storage")]
+        "edge_hidden_s", "edge_hidden_v", "out_s", "storage", "layer_kind")]
 
 
 class Layout(C.Structure):

@@ -14,7 +14,8 @@ from . import _lib
 from ._lib import Dims, GineW, Layout, Rng
 
 CASTER_DIMS = dict(node_in_s=17, node_in_v=3, edge_in_s=32, edge_in_v=1, hidden_s=16, hidden_v=4,
-                   edge_hidden_s=32, edge_hidden_v=1, out_s=64, storage=0)
+                   edge_hidden_s=32, edge_hidden_v=1, out_s=64, storage=0, layer_kind=0)
+LAYER_GATED, LAYER_GVPDEF, LAYER_LINEAR = 0, 1, 2   # cgvp_dims.layer_kind (include/caster_gvp.h, "LAYER KIND")
 F32, BF16 = 0, 1   # cgvp_dims.storage: element type of the activation buffers ("bf16 storage / fp32 accumulate")
 ROW = 28  # merged node row: 16 scalars + 4x3 vector channels
 EROW = 36  # stored edge embedding row (CGVP_EDGE_ROW): 32 scalars + 1x3 vector + pad, sorted-edge order

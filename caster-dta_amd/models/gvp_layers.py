@@ -8,9 +8,15 @@ Where the arithmetic runs
 The hot path never executes the `forward` methods in this file: the protein
 encoder (`models.protein_gnn.VectorProteinGNN_LBAModel`) walks these modules only
 to own their Parameters (as views into one arena) and launches the fused gfx950
-kernels of libcaster_gvp.so.  The `forward` methods below are small tensor-op
-compositions kept so that each module still works when somebody instantiates it
-on its own (other GVP stacks, analysis scripts); they need no torch_geometric.
+kernels of libcaster_gvp.so.
+
+A `GVPConv` / `GVPConvLayer` instantiated on its own (the PocketMiner- and
+CPD-style stacks, analysis scripts) runs on the same tile kernels when it is one
+of the three layer kinds they are compiled for -- node dims (16, 4), edge dims
+(<= 32, 1), 3 message / 2 feed-forward GVPs, (relu, None)+gate, (relu, sigmoid)
+or (None, None) -- and its tensors are fp32 on the GPU (`gvp_hip.conv_layer_ops`).
+Every other case runs the small tensor-op compositions below (no torch_geometric
+needed), which are also what the golden fixtures pin against the reference.
 """
 import functools
 
@@ -190,7 +196,21 @@ class GVPConv(nn.Module):
     def message(self, x_i, x_j, edge_attr):
         return _merge(*self.message_func(tuple_cat(x_j, edge_attr, x_i)))
 
+    def _kernel_kind(self, x, edge_attr):
+        """The layer kind the MI355X kernels compute this conv as (gvp_hip.conv_layer_ops), or None: other widths,
+        other activation combinations, non-CUDA / non-fp32 tensors run the tensor-op composition below."""
+        if not (x[0].is_cuda and x[0].dtype == torch.float32):
+            return None
+        from gvp_hip import conv_layer_ops as K
+        if not K.usable(x[0], x[1], edge_attr[0], edge_attr[1]):
+            return None
+        return K.conv_kind(self)
+
     def forward(self, x, edge_index, edge_attr):
+        kind = self._kernel_kind(x, edge_attr)
+        if kind is not None:
+            from gvp_hip import conv_layer_ops as K
+            return K.tuple_from_rows(K.conv_message(self, kind, x, edge_index, edge_attr))
         agg = _gather_scatter(self.message, x[0], x[1], edge_index, edge_attr, self.aggr)
         return _split(agg, self.vo)
 
@@ -234,6 +254,11 @@ class GVPConvLayer(nn.Module):
             n = dh[0].shape[0]
             cnt = torch.bincount(edge_index[1], minlength=n).clamp(min=1).to(dh[0].dtype).unsqueeze(-1)
             dh = (dh[0] / cnt, dh[1] / cnt.unsqueeze(-1))
+        if node_mask is None and x[0].is_cuda and x[0].dtype == torch.float32:
+            from gvp_hip import conv_layer_ops as K
+            kind = K.node_kind(self) if K.usable(x[0], x[1], dh[0], dh[1]) else None
+            if kind is not None:            # residual + LayerNorm + feed-forward + residual + LayerNorm: one launch
+                return K.node_update(self, kind, x, K.rows_from_tuple(dh))
         full = x
         if node_mask is not None:
             x, dh = tuple_index(x, node_mask), tuple_index(dh, node_mask)

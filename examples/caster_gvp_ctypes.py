@@ -1,4 +1,4 @@
-# models/_caster_gvp.py -- ctypes binding of libcaster_gvp.so (C ABI v24): the protein encoder forward
+# models/_caster_gvp.py -- ctypes binding of libcaster_gvp.so (C ABI v25): the protein encoder forward
 # (VectorProteinGNN_LBAModel.forward, protein_gnn.py:361-388) on the MFMA kernels, nothing but torch + ctypes.
 import ctypes as C
 import torch                                           # import torch first: it provides the HIP runtime
@@ -6,7 +6,7 @@ import torch                                           # import torch first: it 
 
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("node_in_s", "node_in_v", "edge_in_s", "edge_in_v", "hidden_s", "hidden_v",
-                                         "edge_hidden_s", "edge_hidden_v", "out_s", "storage")]
+                                         "edge_hidden_s", "edge_hidden_v", "out_s", "storage", "layer_kind")]
 
 
 class Layout(C.Structure):
@@ -29,9 +29,9 @@ class ProteinEncoder:
         """state_dict: the `protein_gnn.gnn_model.*` slice of a CASTER-DTA checkpoint (keys without that prefix)."""
         self.lib = lib = C.CDLL(lib_path)
         lib.cgvp_lba_image_floats.restype = C.c_int64
-        assert lib.cgvp_abi_version() == 24
+        assert lib.cgvp_abi_version() == 25
         self.num_convs = num_convs
-        self.dims, self.lay = Dims(17, 3, 32, 1, 16, 4, 32, 1, 64, 0), Layout()     # storage 0 = fp32 activations, 1 = bf16
+        self.dims, self.lay = Dims(17, 3, 32, 1, 16, 4, 32, 1, 64, 0, 0), Layout()     # storage 0 = fp32 activations, 1 = bf16
         check(lib.cgvp_lba_layout(C.byref(self.dims), num_ntypes, num_etypes, num_convs, C.byref(self.lay)), "cgvp_lba_layout")
         # params: ONE fp32 tensor with the weights in state_dict order (the zero-size dummy_params are skipped)
         self.params = torch.cat([v.reshape(-1).float() for v in state_dict.values() if v.numel()]).cuda()

@@ -1,4 +1,4 @@
-# models/_caster_gvp_pass.py -- ctypes binding of the WHOLE-PASS entry points of libcaster_gvp.so (C ABI v24): one call
+# models/_caster_gvp_pass.py -- ctypes binding of the WHOLE-PASS entry points of libcaster_gvp.so (C ABI v25): one call
 # runs VectorProteinGNN_LBAModel.forward (protein_gnn.py:361-388), one call its backward -- the production path.
 # Nothing but torch + ctypes; every buffer is the caller's.
 import ctypes as C
@@ -7,7 +7,7 @@ import torch                                           # import torch first: it 
 
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("node_in_s", "node_in_v", "edge_in_s", "edge_in_v", "hidden_s", "hidden_v",
-                                         "edge_hidden_s", "edge_hidden_v", "out_s", "storage")]
+                                         "edge_hidden_s", "edge_hidden_v", "out_s", "storage", "layer_kind")]
 
 
 class Layout(C.Structure):
@@ -40,8 +40,8 @@ class ProteinEncoder:
         self.lib = lib = C.CDLL(lib_path)
         lib.cgvp_lba_bwd_workspace_bytes.restype = C.c_int64
         lib.cgvp_lba_bwd_workspace_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
-        assert lib.cgvp_abi_version() == 24
-        self.dims, self.lay = Dims(17, 3, 32, 1, 16, 4, 32, 1, 64, 0), Layout()
+        assert lib.cgvp_abi_version() == 25
+        self.dims, self.lay = Dims(17, 3, 32, 1, 16, 4, 32, 1, 64, 0, 0), Layout()
         check(lib.cgvp_lba_layout(C.byref(self.dims), num_ntypes, num_etypes, num_convs, C.byref(self.lay)), "cgvp_lba_layout")
         # ONE fp32 arena with the weights in state_dict order (zero-size dummy_params skipped); gradients come back the same way
         self.params = torch.cat([v.reshape(-1).float() for v in state_dict.values() if v.numel()]).cuda()

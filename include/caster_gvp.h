@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 24
+#define CGVP_ABI_VERSION 25
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
@@ -71,7 +71,22 @@ typedef struct {
   int32_t edge_hidden_s, edge_hidden_v; /* 32, 1 */
   int32_t out_s;                    /* 64 */
   int32_t storage;                  /* CGVP_F32 (0) or CGVP_BF16 (1): element type of the ACTIVATION buffers, see below */
+  int32_t layer_kind;               /* CGVP_LAYER_*: which GVPConvLayer the conv / node-update entry points compute      */
 } cgvp_dims;
+/* LAYER KIND.  gvp_layers.GVPConvLayer(activations, vector_gate) (gvp_layers.py:340-366) comes in three forms in the
+ * reference; message_func.{0,1} and ff_func.0 use the layer's arguments, message_func.2 and ff_func.1 always have
+ * activations (None, None) (gvp_layers.py:279-288, :357-366):
+ *   CGVP_LAYER_GATED   (relu, None), vector_gate=True : v * sigmoid(wsv(s))   protein_gnn.py:349-353 (CASTER-DTA / LBA)
+ *   CGVP_LAYER_GVPDEF  (relu, sigmoid), no gate       : v * sigmoid(|v|)      protein_gnn.py:565-573 (CPD encoder/decoder)
+ *   CGVP_LAYER_LINEAR  (None, None), no gate          : v                     protein_gnn.py:468-473 (PocketMiner-style)
+ * The arena / image / gradient-block layout is the SAME for all three (the wsv slots of the two un-gated kinds are
+ * ignored by the forward and receive zero gradient).  Kinds other than GATED are accepted by cgvp_lba_layout /
+ * cgvp_lba_image_floats / cgvp_lba_prepare (layout only), cgvp_conv_fwd (stored edge embedding `e_in`, nt_edge = 0),
+ * cgvp_node_update_fwd[_train] / cgvp_node_update_bwd (without the head), cgvp_conv_bwd, cgvp_bwd_workspace_floats
+ * and cgvp_bwd_reduce -- fp32 storage only; every other entry point returns CGVP_ERR_UNSUPPORTED_DIMS for them. */
+#define CGVP_LAYER_GATED 0
+#define CGVP_LAYER_GVPDEF 1
+#define CGVP_LAYER_LINEAR 2
 /* ACTIVATION STORAGE ("bf16 storage / fp32 accumulate", BASELINE config 5; MFMA kernels only).  With
  * dims->storage == CGVP_BF16 every activation buffer of the protein entry points -- x_s, x_v, e_s, e_v, the node rows
  * h / dh / h_out, the edge-embedding store e_in / e_out / e_emb and the residue embeddings out -- holds bfloat16

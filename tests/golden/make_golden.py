@@ -150,8 +150,9 @@ def lba_fixture(model, m64, gb, r_seed):
 
 def gvp_stacks(Wrapper):
     """The reference's other GVP stacks with seeded default initialisation, eval mode: PocketMiner-style, CPD-style
-    (autoregressive decoder) and the LBA model with nn.Embedding type encoders; inputs, state dicts, outputs and (for
-    the embedding LBA model) reference-autograd gradients."""
+    (autoregressive decoder; twice: the default widths and a decoder edge width the conv kernels are compiled for) and the
+    LBA model with nn.Embedding type encoders; inputs, state dicts, outputs and reference-autograd gradients of every
+    parameter."""
     base = dict(in_channels=(17, 3), edge_dim=(32, 1), num_ntypes=20, num_etypes=1, num_convs=2, hidden_channels=(16, 4),
                 dropout_rate=0.1)
     cases = {
@@ -162,6 +163,10 @@ def gvp_stacks(Wrapper):
                          edge_hidden_channels=(32, 1)),
         "lba_embedding": dict(base, base_conv="lbamodel", ntype_emb_dim=8, etype_emb_dim=4, out_channels=64,
                               edge_hidden_channels=(32, 1), aggr="sum"),
+        # CPD-style stack whose DECODER edge embedding (edge_hidden + one-hot residue type = 12 + 20) has the width
+        # the MI355X conv kernels are compiled for; the encoder's 12 edge scalars run zero-padded
+        "cpdmodel_k": dict(base, base_conv="cpdmodel", ntype_emb_dim=None, etype_emb_dim=None, out_channels=8,
+                           edge_hidden_channels=(12, 1)),
     }
     rng = np.random.default_rng(31)
     gb = ds.collate([ds.protein_graph(L, rng, 4.0, "dist") for L in (28, 41, 17)])
@@ -179,7 +184,7 @@ def gvp_stacks(Wrapper):
         arrays[f"{name}_out"] = np_(out)
         for k, p in model.state_dict().items():
             arrays[f"{name}_w_{k}"] = np_(p)
-        if name == "lba_embedding":
+        if name in ("lba_embedding", "pocketminer", "cpdmodel", "cpdmodel_k"):      # reference-autograd gradients
             r = torch.from_numpy(np.random.default_rng(9).normal(size=tuple(out.shape)).astype(np.float32))
             (out * r).sum().backward()
             arrays[f"{name}_r"] = np_(r)
