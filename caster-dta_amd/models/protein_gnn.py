@@ -228,12 +228,14 @@ class VectorProteinGNN_LBAModel(BaseProteinGNN):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # The reference's two other GVP stacks (protein_gnn.py:392-516 PocketMiner-style, :518-608 CPD-style with an
-# autoregressive decoder).  train_model.py never selects them (it hard-codes 'lbamodel', :276), their channel widths
-# are free constructor arguments (the fused kernels are compiled for the CASTER-DTA widths), and they use the
-# non-gated GVP branches (`vector_gate=False`, sigmoid on vector norms, `vi = 0`): they are provided as compositions of
-# this package's `models.gvp_layers` modules -- plain tensor ops on whatever device the tensors live on, same
-# parameter names / shapes as the reference (strict checkpoint loading), pinned against outputs of the reference's own
-# classes (tests/golden/gvp_stacks.npz).  They are NOT the MI355X fast path.
+# autoregressive decoder).  train_model.py never selects them (it hard-codes 'lbamodel', :276) and their channel widths
+# are free constructor arguments, so they are built from this package's `models.gvp_layers` modules with the
+# reference's parameter names / shapes (strict checkpoint loading).  On MI355X every `GVPConvLayer` in them whose dims
+# are the compiled ones -- node (16, 4), edge (<= 32, 1) -- runs on the tile kernels in its own layer kind (un-gated
+# `(None, None)` for PocketMiner, `(relu, sigmoid)` for CPD; the autoregressive decoder as two masked conv passes),
+# forward and backward (gvp_hip/conv_layer_ops.py); the projection GVPs / LayerNorms around them, and layers at other
+# widths, are tensor ops on whatever device the tensors live on.  Pinned against outputs and gradients of the
+# reference's own classes (tests/golden/gvp_stacks.npz; CPU and GPU tests in tests/test_gvp_stacks.py).
 class VectorProteinGNN_PocketMiner(BaseProteinGNN):
     """Structural projection GVPs -> type embedding cat -> LayerNorm + GVP on nodes and edges -> `num_convs`
     GVPConvLayers (activations (None, None), aggr 'mean', no gate) -> LayerNorm + GVP -> per-residue scalars."""
