@@ -254,11 +254,17 @@ class GVPConvLayer(nn.Module):
             n = dh[0].shape[0]
             cnt = torch.bincount(edge_index[1], minlength=n).clamp(min=1).to(dh[0].dtype).unsqueeze(-1)
             dh = (dh[0] / cnt, dh[1] / cnt.unsqueeze(-1))
-        if node_mask is None and x[0].is_cuda and x[0].dtype == torch.float32:
+        if x[0].is_cuda and x[0].dtype == torch.float32:
             from gvp_hip import conv_layer_ops as K
             kind = K.node_kind(self) if K.usable(x[0], x[1], dh[0], dh[1]) else None
             if kind is not None:            # residual + LayerNorm + feed-forward + residual + LayerNorm: one launch
-                return K.node_update(self, kind, x, K.rows_from_tuple(dh))
+                if node_mask is None:
+                    return K.node_update(self, kind, x, K.rows_from_tuple(dh))
+                # only the masked nodes are updated (gvp_layers.py:403-414): the kernel runs on their rows, the
+                # result is written back into the caller's tensors like the reference does
+                sub = K.node_update(self, kind, tuple_index(x, node_mask), K.rows_from_tuple(tuple_index(dh, node_mask)))
+                x[0][node_mask], x[1][node_mask] = sub[0], sub[1]
+                return x
         full = x
         if node_mask is not None:
             x, dh = tuple_index(x, node_mask), tuple_index(dh, node_mask)

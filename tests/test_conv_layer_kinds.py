@@ -179,8 +179,34 @@ def test_training_mode_dropout_masks(kind):
     assert torch.isfinite(out_t[0]).all() and out_t[1].shape == (n, 4, 3) and not torch.allclose(out_t[0], out_e[0])
 
 
+def test_node_mask_updates_only_the_selected_rows_on_the_kernels(monkeypatch):
+    """`node_mask` (gvp_layers.py:403-414): messages come from every node, only the masked nodes are updated."""
+    from gvp_hip import conv_layer_ops as K
+    layer = _layer("gvpdef", 32).eval()
+    n, e = 210, 1000
+    ei = _graph(n, e, 51)
+    x, ea = _feats(n, (16, 4), 52), _feats(e, (32, 1), 53)
+    mask = (torch.arange(n, device=DEV) % 3) != 1
+    sizes = []
+    node_update = K.node_update
+    monkeypatch.setattr(K, "node_update", lambda *a, **k: (sizes.append(int(a[2][0].shape[0])), node_update(*a, **k))[1])
+    outs = []
+    for enabled in (True, False):
+        K.ENABLED = enabled
+        try:
+            xin = (x[0].clone(), x[1].clone())
+            with torch.no_grad():
+                outs.append(layer(xin, ei, ea, node_mask=mask))
+        finally:
+            K.ENABLED = True
+    assert sizes == [int(mask.sum())]
+    for a, b, orig in zip(outs[0], outs[1], x):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+        assert torch.equal(a[~mask], orig[~mask]) and not torch.allclose(a[mask], orig[mask])
+
+
 def test_cases_outside_the_compiled_set_use_the_composition(monkeypatch):
-    """Other widths / activation mixes / node masks are not silently mis-computed: they never reach the kernels."""
+    """Other widths / activation mixes are not silently mis-computed: they never reach the kernels."""
     import models.gvp_layers as gvp
     from gvp_hip import conv_layer_ops as K
 
