@@ -71,7 +71,7 @@ int conv_bwd(int nt_edge, const float* img, const float* imgT, const float* h, c
 // backward of gvp_edge + LayerNorm from the summed d(edge embedding) of the conv layers (weight gradients only)
 int edge_embed_bwd(int nt_edge, const float* img, const float* imgT, const float* e_s, const float* e_v,
                    const int64_t* etypes, const int32_t* eperm, int64_t E, const float* const* g_e, int n_g,
-                   float* slab, int* grid, int bf16, hipStream_t st);
+                   float* g_e_s, float* g_e_v, float* slab, int* grid, int bf16, hipStream_t st);
 constexpr int kEdgeRow = 36;              // floats per edge of the stored edge embedding: [e_s 32 | e_v 3 | pad]
 int node_embed_bwd(int nt_node, const float* img, const float* imgT, const float* x_s, const float* x_v,
                    const int64_t* ntypes, int64_t N, const float* g_up0, const float* g_up1, const float* g_up2,

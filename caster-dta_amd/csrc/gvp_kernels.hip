@@ -954,10 +954,11 @@ int cgvp_conv_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float*
 
 int cgvp_edge_embed_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image, const float* e_s,
                         const float* e_v, const int64_t* etypes, const int32_t* eperm, int64_t E,
-                        const float* const* g_e, int32_t num_g, float* grad_params, float* workspace,
-                        cgvp_segment* segs, int32_t* nsegs, void* stream) {
+                        const float* const* g_e, int32_t num_g, float* g_e_s, float* g_e_v, float* grad_params,
+                        float* workspace, cgvp_segment* segs, int32_t* nsegs, void* stream) {
   if (int rc = check_dims_gated(dims)) return rc;
   if (E < 0 || !layout || !image || !grad_params || !workspace || !g_e || num_g < 1) return CGVP_ERR_BAD_ARG;
+  if ((g_e_s == nullptr) != (g_e_v == nullptr) || ((uintptr_t)g_e_s & 15)) return CGVP_ERR_BAD_ARG;
   if (segs && nsegs) *nsegs = 0;
   if (E == 0) return 0;
   if (!e_s || !e_v || !eperm || (layout->nt_edge > 0 && !etypes)) return CGVP_ERR_BAD_ARG;
@@ -969,9 +970,13 @@ int cgvp_edge_embed_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
   int emb, ce, ct, nd, hd, grid = 0;
   if (int rc = quad::bwd_block_sizes(layout->nt_node, layout->nt_edge, &emb, &ce, &ct, &nd, &hd)) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (g_e_s) {        // edges the CSR build dropped (endpoint out of range) are in no tile: their rows stay zero
+    quad::zero_words(g_e_s, (size_t)E * EDGE_IN_S, st);
+    quad::zero_words(g_e_v, (size_t)E * EDGE_IN_V * 3, st);
+  }
   // gvp_edge's fragments are the head of every conv slice (identical in all layers): layer 0's is used
   if (int rc = quad::edge_embed_bwd(layout->nt_edge, image + o.conv0, image + o.convT0, e_s, e_v, etypes, eperm, E, g_e,
-                                    num_g, workspace, &grid, policy_of(dims), st)) return rc;
+                                    num_g, g_e_s, g_e_v, workspace, &grid, policy_of(dims), st)) return rc;
   cgvp_segment sg[1] = {{workspace, grid, ce, 0, layout->conv0 - layout->edge_gvp, layout->edge_gvp}};
   if (segs && nsegs) { segs[0] = sg[0]; *nsegs = 1; }
   else quad::reduce_segments(sg, 1, grad_params, st);

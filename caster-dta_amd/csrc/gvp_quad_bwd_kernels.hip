@@ -641,11 +641,12 @@ struct EdgeBArgs {
   const float* img; const float* imgT;
   const float* e_s; const float* e_v; const int64_t* etypes; const int32_t* eperm; int64_t E;
   const float* g_e[EB_MAX_LAYERS]; int n_g; float* slab;
+  float* g_e_s; float* g_e_v;     // optional: d(loss)/d(raw edge features), fp32, ORIGINAL edge order (DX instantiation)
 };
 template <int NTE>
 constexpr int edge_bwd_lds_floats() { return BW_TPB + Image<0, NTE>::CV_M0 + Image<0, NTE>::TC_M0 + BW_WPB * (EdgeBlk<NTE>::SIZE + TSCR_FLOATS); }
 
-template <int NTE, typename ST>
+template <int NTE, typename ST, bool DX = false>
 __global__ __launch_bounds__(BW_TPB, 2) void edge_bwd_kernel(EdgeBArgs a) {
   WALL_STAMP(3);
   typedef Image<0, NTE> IM;
@@ -714,6 +715,15 @@ __global__ __launch_bounds__(BW_TPB, 2) void edge_bwd_kernel(EdgeBArgs a) {
     float d_in[8], d_inv[3][1];
     typename QEdge<NTE>::Grads gr;
     QEdge<NTE>::template backward<Io<ST>::BF>(imgT + IM::TC_EDGE, lane, ce[0], d_es, d_ev, d_in, d_inv, gr);
+    if (DX && active) {               // gradients of the raw features: every valid edge id is written exactly once
+      const int64_t er = (int64_t)eid * EDGE_IN_S;
+      *reinterpret_cast<f4*>(a.g_e_s + er + 4 * g) = f4{d_in[0], d_in[1], d_in[2], d_in[3]};
+      *reinterpret_cast<f4*>(a.g_e_s + er + 16 + 4 * g) = f4{d_in[4], d_in[5], d_in[6], d_in[7]};
+      if (g == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) a.g_e_v[(int64_t)eid * 3 + d] = d_inv[d][0];
+      }
+    }
     QEdge<NTE>::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::GVP, first, lane, et[0], active, bse[0], bve[0], ce[0], gr, tscr);
   }
   write_slab_row<B::SIZE, PW>(a.slab, blocks);
@@ -1026,6 +1036,12 @@ int edge_bwd_impl(EdgeBArgs& a, int* grid, int bf16, hipStream_t st) {
   const int G = (int)(tiles < 1 ? 1 : (tiles > 2 * BW_MAX_GRID ? 2 * BW_MAX_GRID : tiles));
   *grid = G;
   const size_t lds = (size_t)edge_bwd_lds_floats<NTE>() * sizeof(float);
+  if (a.g_e_s) {
+#define K_(ST) edge_bwd_kernel<NTE, ST, true>
+    BWD_LAUNCH(K_, G, BW_TPB, lds, a);
+#undef K_
+    return 0;
+  }
 #define K_(ST) edge_bwd_kernel<NTE, ST>
   BWD_LAUNCH(K_, G, BW_TPB, lds, a);
 #undef K_
@@ -1034,9 +1050,10 @@ int edge_bwd_impl(EdgeBArgs& a, int* grid, int bf16, hipStream_t st) {
 
 int edge_embed_bwd(int nt_edge, const float* img, const float* imgT, const float* e_s, const float* e_v,
                    const int64_t* etypes, const int32_t* eperm, int64_t E, const float* const* g_e, int n_g,
-                   float* slab, int* grid, int bf16, hipStream_t st) {
+                   float* g_e_s, float* g_e_v, float* slab, int* grid, int bf16, hipStream_t st) {
   if (n_g < 1 || n_g > EB_MAX_LAYERS) return CGVP_ERR_BAD_ARG;
-  EdgeBArgs a{img, imgT, e_s, e_v, etypes, eperm, E, {}, n_g, slab};
+  if ((g_e_s == nullptr) != (g_e_v == nullptr)) return CGVP_ERR_BAD_ARG;
+  EdgeBArgs a{img, imgT, e_s, e_v, etypes, eperm, E, {}, n_g, slab, g_e_s, g_e_v};
   for (int l = 0; l < n_g; ++l) a.g_e[l] = g_e[l];
   if (nt_edge == 0) return edge_bwd_impl<0>(a, grid, bf16, st);
   if (nt_edge == 1) return edge_bwd_impl<1>(a, grid, bf16, st);

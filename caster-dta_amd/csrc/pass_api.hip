@@ -282,10 +282,10 @@ int64_t cgvp_lba_bwd_workspace_bytes(const cgvp_dims* dims, const cgvp_layout* l
 int cgvp_lba_backward_pass(const cgvp_dims* dims, const cgvp_layout* layout, const cgvp_lba_batch* batch,
                            int32_t aggr_mean, float dropout_p, const float* masks, const void* fwd_workspace,
                            const float* g_out, void* bwd_workspace, float* grad_params, float* g_x_s, float* g_x_v,
-                           void* stream) {
+                           float* g_e_s, float* g_e_v, void* stream) {
   if (!dims || !layout || !batch || !fwd_workspace || !bwd_workspace || !grad_params) return CGVP_ERR_BAD_ARG;
   if (((uintptr_t)fwd_workspace & 255) || ((uintptr_t)bwd_workspace & 255)) return CGVP_ERR_BAD_ARG;
-  if ((g_x_s == nullptr) != (g_x_v == nullptr)) return CGVP_ERR_BAD_ARG;
+  if ((g_x_s == nullptr) != (g_x_v == nullptr) || (g_e_s == nullptr) != (g_e_v == nullptr)) return CGVP_ERR_BAD_ARG;
   const int64_t N = batch->num_nodes, E = batch->num_edges;
   cgvp_lba_fwd_ws ws;
   if (int rc = cgvp_lba_fwd_workspace(dims, layout, N, E, 1, &ws)) return rc;
@@ -358,7 +358,7 @@ int cgvp_lba_backward_pass(const cgvp_dims* dims, const cgvp_layout* layout, con
     if (nc > 16) return CGVP_ERR_UNSUPPORTED_DIMS;
     for (int l = 0; l < nc; ++l) ge[l] = g_e + (int64_t)l * bw.g_e_stride;
     if (int rc = cgvp_edge_embed_bwd(dims, layout, image, batch->e_s, batch->e_v, batch->etypes, eperm, E, ge, nc,
-                                     grad_params, region(), segs + nseg, &cnt, stream))
+                                     g_e_s, g_e_v, grad_params, region(), segs + nseg, &cnt, stream))
       return rc;
     nseg += cnt;
   } else {                                               // no edge stage: gvp_edge's gradient block is covered by no segment

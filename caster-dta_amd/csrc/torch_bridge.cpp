@@ -159,7 +159,7 @@ struct LbaBackward : public Node {
       Tic tic_c("lba_bwd.c_call");
       check(cgvp_lba_backward_pass(&cfg.dims, &cfg.layout, &b, cfg.mean, (float)dropout_p, (const float*)ptr(masks), ptr(ws),
                                    (const float*)ptr(g_out), ptr(bws), (float*)ptr(gparams), (float*)ptr(g_x_s),
-                                   (float*)ptr(g_x_v), current_stream(x_s)),
+                                   (float*)ptr(g_x_v), nullptr, nullptr, current_stream(x_s)),
             "cgvp_lba_backward_pass");
     }
     Tic tic_v("lba_bwd.views");

@@ -15,11 +15,11 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CGVP_LIB_PATH: A/B builds of the same ABI (diagnostics); the default is the in-tree library
 LIB_PATH = os.environ.get("CGVP_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libcaster_gvp.so")
-ABI_VERSION = 25
+ABI_VERSION = 26
 # sha256 of include/caster_gvp.h with comments, blank space and the CGVP_ABI_VERSION line removed, as
 # `abi_header_digest()` computes it.  tests/test_abi.py fails when the header's declarations change
 # without CGVP_ABI_VERSION, ABI_VERSION and this digest being updated together.
-ABI_HEADER_SHA256 = "71551f848a3c46e7c0400891fd99c3fd0fd62effc80d0f9d0305565e0c6e298d"
+ABI_HEADER_SHA256 = "3cd536e18168d9c68b773235bdf1938fce934d75cf2bd24f1dbf298e69e084ce"
 
 
 class HipLibraryError(RuntimeError):
@@ -129,7 +129,7 @@ _SIGNATURES = {
     "cgvp_conv_bwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _I32, _P, _P, _P, _P, _P, _I64,
                                 _I64, _I32, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "cgvp_edge_embed_bwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _P, _P, _P, _I64, C.POINTER(_P), _I32,
-                                      _P, _P, _P, _P, _P]),
+                                      _P, _P, _P, _P, _P, _P, _P]),
     "cgvp_node_embed_bwd": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P,
                                       _P, _P, _P, _P, _P]),
     "cgvp_bwd_reduce": (C.c_int, [_P, _I32, _P, _I32, _P]),
@@ -145,7 +145,7 @@ _SIGNATURES = {
     "cgvp_lba_forward_plan": (C.c_int, [_I64, _I64, _I32, _I32, _I32, C.POINTER(_I32)]),
     "cgvp_lba_bwd_workspace_bytes": (C.c_int64, [C.POINTER(Dims), C.POINTER(Layout), _I64, _I64]),
     "cgvp_lba_backward_pass": (C.c_int, [C.POINTER(Dims), C.POINTER(Layout), C.POINTER(LbaBatch), _I32, C.c_float, _P, _P,
-                                         _P, _P, _P, _P, _P, _P]),
+                                         _P, _P, _P, _P, _P, _P, _P, _P]),
     "cgvp_gine_fwd_workspace": (C.c_int, [C.POINTER(GineCfg), _I64, _I64, _I32, C.POINTER(GineFwdWs)]),
     "cgvp_gine_forward_pass": (C.c_int, [C.POINTER(GineCfg), C.POINTER(GineW), C.POINTER(GineBatch), C.c_float, _P, _P, _P,
                                          _P, _I32, _I32, _P, _P]),

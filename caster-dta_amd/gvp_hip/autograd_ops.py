@@ -273,12 +273,15 @@ def _image_floats_for(cfg, sdt):
 @torch.library.custom_op("caster_gvp::lba_encoder_backward", mutates_args=(), device_types="cuda")
 def lba_encoder_backward_op(g_out: Tensor, x_s: Tensor, x_v: Tensor, ntypes: Tensor, e_s: Tensor, e_v: Tensor,
                             etypes: Tensor, edge_index: Tensor, csr: List[Tensor], ws: Tensor, masks: Tensor,
-                            cfg: List[int], dropout_p: float, need_x: bool) -> Tuple[Tensor, Tensor, Tensor]:
-    """-> (grad arena [layout.total], g_x_s [N, 17], g_x_v [N, 3, 3]) (the latter two empty unless need_x)."""
-    return lba_backward(g_out, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, csr, ws, masks, cfg, dropout_p, need_x)
+                            cfg: List[int], dropout_p: float, need_x: bool,
+                            need_e: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """-> (grad arena [layout.total], g_x_s [N, 17], g_x_v [N, 3, 3], g_e_s [E, 32], g_e_v [E, 1, 3]) -- the feature
+    gradients are empty unless need_x / need_e."""
+    return lba_backward(g_out, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, csr, ws, masks, cfg, dropout_p, need_x, need_e)
 
 
-def lba_backward(g_out, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, csr, ws, masks, cfg, dropout_p, need_x):
+def lba_backward(g_out, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, csr, ws, masks, cfg, dropout_p, need_x,
+                 need_e=False):
     """One cgvp_lba_backward_pass."""
     L = _lib.lib()
     sdt = ops.storage_dtype(x_s)
@@ -298,25 +301,34 @@ def lba_backward(g_out, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, csr, ws,
     bws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     g_x_s = torch.empty(N, dims.node_in_s, **f32) if need_x else None
     g_x_v = torch.empty(N, dims.node_in_v, 3, **f32) if need_x else None
+    if need_e and int(e_s.shape[0]) != E:
+        raise NotImplementedError("gradients w.r.t. the edge features of a resident feature table are not produced")
+    # rows of valid edges are STORED by the edge stage, the rest zero-filled by the pass (no edges: no edge stage)
+    g_e_s = (torch.empty if E > 0 else torch.zeros)(E, dims.edge_in_s, **f32) if need_e else None
+    g_e_v = (torch.empty if E > 0 else torch.zeros)(E, dims.edge_in_v, 3, **f32) if need_e else None
     batch = _lba_batch(x_s, x_v, nt, e_s, e_v, et, edge_index, csr, N, E)
     if ws.data_ptr() % 256:
         ws = ws.clone()
     with torch.cuda.device(dev):
         rc = L.cgvp_lba_backward_pass(C.byref(dims), C.byref(layout), C.byref(batch), 1 if mean else 0, float(dropout_p),
                                       _ptr(masks), _ptr(ws), _ptr(g_out), _ptr(bws), _ptr(gparams), _ptr(g_x_s),
-                                      _ptr(g_x_v), _stream())
+                                      _ptr(g_x_v), _ptr(g_e_s if E > 0 else None), _ptr(g_e_v if E > 0 else None), _stream())
     _lib.check(rc, "cgvp_lba_backward_pass")
-    return gparams, (g_x_s if need_x else torch.empty(0, **f32)), (g_x_v if need_x else torch.empty(0, **f32))
+    none = lambda: torch.empty(0, **f32)                     # (outputs of a custom op must not alias each other)
+    return (gparams, g_x_s if need_x else none(), g_x_v if need_x else none(), g_e_s if need_e else none(),
+            g_e_v if need_e else none())
 
 
 @lba_encoder_backward_op.register_fake
-def _(g_out, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, csr, ws, masks, cfg, dropout_p, need_x):
+def _(g_out, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, csr, ws, masks, cfg, dropout_p, need_x, need_e):
     sdt = torch.bfloat16 if x_s.dtype == torch.bfloat16 else torch.float32
     total = _dims_layout([int(c) for c in cfg], sdt)[1].total
     gp = x_s.new_empty((total,), dtype=torch.float32)
-    if need_x:
-        return gp, x_s.new_empty(x_s.shape, dtype=torch.float32), x_v.new_empty(x_v.shape, dtype=torch.float32)
-    return gp, x_s.new_empty((0,), dtype=torch.float32), x_s.new_empty((0,), dtype=torch.float32)
+    none = lambda: x_s.new_empty((0,), dtype=torch.float32)
+    f32 = dict(dtype=torch.float32)
+    gx = (x_s.new_empty(x_s.shape, **f32), x_v.new_empty(x_v.shape, **f32)) if need_x else (none(), none())
+    ge = (e_s.new_empty(e_s.shape, **f32), e_v.new_empty(e_v.shape, **f32)) if need_e else (none(), none())
+    return (gp, *gx, *ge)
 
 
 def _lba_setup(ctx, inputs, output):
@@ -342,14 +354,17 @@ def _lba_backward(ctx, g_out, g_ws, g_masks):
         return (None,) * 8 + ([None] * ctx.ncsr, None, None, None)
     x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, ws, masks, *csr = ctx.saved_tensors
     need_x = bool(ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-    gflat, g_x_s, g_x_v = torch.ops.caster_gvp.lba_encoder_backward(
+    need_e = bool(ctx.needs_input_grad[4] or ctx.needs_input_grad[5])
+    gflat, g_x_s, g_x_v, g_e_s, g_e_v = torch.ops.caster_gvp.lba_encoder_backward(
         g_out.contiguous(), x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, list(csr), ws, masks, ctx.cfg,
-        ctx.dropout_p, need_x)
+        ctx.dropout_p, need_x, need_e)
     grads = [g.view(s) for g, s in zip(torch.split(gflat, [_numel(s) for s in ctx.shapes]), ctx.shapes)]
     if need_x and x_s.dtype != torch.float32:                 # input gradients are produced in fp32
         g_x_s, g_x_v = g_x_s.to(x_s.dtype), g_x_v.to(x_v.dtype)
-    return (grads, g_x_s if need_x else None, g_x_v if need_x else None, None, None, None, None, None, [None] * ctx.ncsr,
-            None, None, None)
+    if need_e and e_s.dtype != torch.float32:
+        g_e_s, g_e_v = g_e_s.to(e_s.dtype), g_e_v.to(e_v.dtype)
+    return (grads, g_x_s if need_x else None, g_x_v if need_x else None, None, g_e_s if need_e else None,
+            g_e_v if need_e else None, None, None, [None] * ctx.ncsr, None, None, None)
 
 
 torch.library.register_autograd("caster_gvp::lba_encoder", _lba_backward, setup_context=_lba_setup)
@@ -369,8 +384,6 @@ def _memo_tables(edge_index, num_nodes):
 
 def lba_encoder(model, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, train_dropout, save_state):
     """VectorProteinGNN_LBAModel.forward through the custom op (autograd, dropout when training)."""
-    if e_s.requires_grad or e_v.requires_grad:
-        raise NotImplementedError("gradients w.r.t. raw edge features are not produced by the backward kernels")
     # plain Python ints only (no ctypes objects here: this function is traced by Dynamo under torch.compile);
     # the op validates them against the compiled kernel configuration
     cfg = [model.in_channels[0], model.in_channels[1], model.edge_dim[0], model.edge_dim[1],
@@ -379,6 +392,8 @@ def lba_encoder(model, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, train_dro
            model.num_convs, 1 if model.aggr == "mean" else 0]
     p = float(model.dropout_rate) if train_dropout else 0.0
     br = _eager_bridge()
+    if br is not None and torch.is_grad_enabled() and (e_s.requires_grad or e_v.requires_grad):
+        br = None       # gradients w.r.t. the raw edge features (rare: attribution studies): the custom-op path returns them
     if br is not None:
         # eager mode: the C++ autograd node (csrc/torch_bridge.cpp) -- same C entry points, a fraction of the host time
         dev, N = x_s.device, x_s.shape[0]

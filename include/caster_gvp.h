@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 25
+#define CGVP_ABI_VERSION 26
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
@@ -328,13 +328,15 @@ int cgvp_conv_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float*
                   void* stream);
 
 /* Backward of gvp_edge = Sequential(GVP, LayerNorm) (protein_gnn.py:331-335, :376), once per step: the upstream
- * gradient of edge p is the SUM over g_e[0 .. num_g) of row p (the buffers the conv backward calls wrote).  Raw
- * edge features receive no gradient; only gvp_edge.0 / gvp_edge.1 weight gradients are produced (ADDED into
- * grad_params, or described in `segs` for the deferred reduction).  `g_e` is a HOST array of device pointers. */
+ * gradient of edge p is the SUM over g_e[0 .. num_g) of row p (the buffers the conv backward calls wrote).
+ * gvp_edge.0 / gvp_edge.1 weight gradients are ADDED into grad_params (or described in `segs` for the deferred
+ * reduction).  g_e_s [E][32] / g_e_v [E][1][3] (fp32, ORIGINAL edge order; both or neither): when given, also the
+ * gradient w.r.t. the raw edge features (what autograd returns for `eattr` in the reference); rows of edges the CSR
+ * build dropped are zero (two fill launches in front).  `g_e` is a HOST array of device pointers. */
 int cgvp_edge_embed_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image,
                         const float* e_s, const float* e_v, const int64_t* etypes, const int32_t* eperm,
-                        int64_t num_edges, const float* const* g_e, int32_t num_g, float* grad_params,
-                        float* workspace, cgvp_segment* segs, int32_t* nsegs, void* stream);
+                        int64_t num_edges, const float* const* g_e, int32_t num_g, float* g_e_s, float* g_e_v,
+                        float* grad_params, float* workspace, cgvp_segment* segs, int32_t* nsegs, void* stream);
 
 /* d/d(x_s, x_v, weights) of cgvp_node_embed_fwd; upstream = sum of g_up0..2.
  * g_x_s [N][17] / g_x_v [N][3][3] may both be NULL (inputs without gradient). */
@@ -493,12 +495,13 @@ int cgvp_lba_forward_plan(int64_t num_nodes, int64_t num_edges, int32_t num_conv
 int64_t cgvp_lba_bwd_workspace_bytes(const cgvp_dims* dims, const cgvp_layout* layout, int64_t num_nodes,
                                      int64_t num_edges);
 /* Autograd of cgvp_lba_forward_pass(save_state = 1): g_out [N][64] fp32 -> grad_params (arena layout, every element
- * STORED: no zero fill needed) and, when both are non-NULL, g_x_s [N][17] / g_x_v [N][3][3].  `batch`, aggr_mean,
+ * STORED: no zero fill needed) and, when both of a pair are non-NULL, the gradients w.r.t. the raw features: g_x_s
+ * [N][17] / g_x_v [N][3][3] and g_e_s [E][32] / g_e_v [E][1][3] (original edge order).  `batch`, aggr_mean,
  * dropout_p and masks must be the forward's; `fwd_workspace` is the buffer the forward filled (read only). */
 int cgvp_lba_backward_pass(const cgvp_dims* dims, const cgvp_layout* layout, const cgvp_lba_batch* batch,
                            int32_t aggr_mean, float dropout_p, const float* masks, const void* fwd_workspace,
                            const float* g_out, void* bwd_workspace, float* grad_params, float* g_x_s, float* g_x_v,
-                           void* stream);
+                           float* g_e_s, float* g_e_v, void* stream);
 
 #define CGVP_GINE_MAX_LAYERS 8
 typedef struct {

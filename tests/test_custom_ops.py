@@ -64,8 +64,11 @@ def test_fake_kernels_propagate_shapes_without_a_gpu(protein_params, molecule_pa
         assert ws.dtype == torch.uint8 and ws.shape == (_c_lba_ws_bytes(N, E, True),)
         out, ws0, masks = torch.ops.caster_gvp.lba_encoder(*args, 0.0, False)
         assert out.shape == (N, 64) and ws0.numel() == 0 and masks.numel() == 0
-        g, gxs, gxv = torch.ops.caster_gvp.lba_encoder_backward(f(N, 64), *args[1:9], ws, f(0), CFG, 0.2, True)
+        g, gxs, gxv, ges, gev = torch.ops.caster_gvp.lba_encoder_backward(f(N, 64), *args[1:9], ws, f(0), CFG, 0.2, True, True)
         assert g.shape == (15117,) and gxs.shape == (N, 17) and gxv.shape == (N, 3, 3)
+        assert ges.shape == (E, 32) and gev.shape == (E, 1, 3)
+        g, gxs, gxv, ges, gev = torch.ops.caster_gvp.lba_encoder_backward(f(N, 64), *args[1:9], ws, f(0), CFG, 0.2, False, False)
+        assert gxs.numel() == gxv.numel() == ges.numel() == gev.numel() == 0
         keys = ("eps", "nn.lins.0.weight", "nn.lins.0.bias", "nn.lins.1.weight", "nn.lins.1.bias", "lin.weight", "lin.bias")
         mparams = [f(*molecule_params[f"conv_list.{l}.{k}"].shape) for l in range(2) for k in keys]
         Na, Ea = 40, 130

@@ -67,6 +67,34 @@ def test_backward_golden(lba_small, protein_params):
     assert rel_err(xv.grad, g["gin_x_v"]) < 2e-4
 
 
+@pytest.mark.parametrize("fixture", ["lba_small", "lba_sparse"])
+def test_edge_feature_gradients_golden(request, protein_params, fixture):
+    """d(loss)/d(eattr) -- what the reference's autograd returns for the raw edge features (attribution studies; the
+    training loop never asks for it) -- from the edge stage of the backward pass, against the reference's own numbers;
+    the weight and node-feature gradients of the same call stay what they are without it.  lba_small takes the
+    two-launch layers, lba_sparse (E <= 4 N) the fused ones."""
+    g = request.getfixturevalue(fixture)
+    model = _encoder(protein_params).eval()
+    xs, xv = T(g["x_s"]).to(DEV).requires_grad_(), T(g["x_v"]).to(DEV).requires_grad_()
+    es, ev = T(g["e_s"]).to(DEV).requires_grad_(), T(g["e_v"]).to(DEV).requires_grad_()
+    out = model((xs, xv), T(g["edge_index"]).to(DEV), T(g["ntypes"]).to(DEV), T(g["etypes"]).to(DEV),
+                eattr=(es, ev), batch=T(g["batch"]).to(DEV))
+    (out * T(g["r"]).to(DEV)).sum().backward()
+    assert es.grad.shape == es.shape and ev.grad.shape == ev.shape
+    assert rel_err(es.grad, g["gin_e_s"]) < 2e-4
+    assert rel_err(ev.grad, g["gin_e_v"]) < 2e-4
+    assert rel_err(xs.grad, g["gin_x_s"]) < 2e-4 and rel_err(xv.grad, g["gin_x_v"]) < 2e-4
+    ref = {k[2:]: T(v) for k, v in g.items() if k.startswith("g_")}
+    assert _check_grads(model, ref) >= 60
+    # only the edge features ask for a gradient (frozen weights, no node-feature gradient): same numbers
+    frozen = _encoder(protein_params).eval().requires_grad_(False)
+    es2 = T(g["e_s"]).to(DEV).requires_grad_()
+    out2 = frozen((T(g["x_s"]).to(DEV), T(g["x_v"]).to(DEV)), T(g["edge_index"]).to(DEV), T(g["ntypes"]).to(DEV),
+                  T(g["etypes"]).to(DEV), eattr=(es2, T(g["e_v"]).to(DEV)), batch=T(g["batch"]).to(DEV))
+    (out2 * T(g["r"]).to(DEV)).sum().backward()
+    assert rel_err(es2.grad, es.grad) < 1e-5          # (not bitwise: d h[src] is accumulated with float atomics)
+
+
 @pytest.mark.parametrize("case", ["c1_davis16_sum", "knn_mean", "radius_mean", "depth4_ragged"])
 def test_backward_vs_oracle_autograd(protein_params, case):
     if case == "c1_davis16_sum":
