@@ -581,7 +581,34 @@ def epoch_leg(args, model, dev, train, prot_params, drug_params):
                    "ms_per_step": round(t_ga / steps * 1e3, 4), "host_issue_ms_per_step": round(t_gi / steps * 1e3, 4),
                    "pairs_per_s": round(B * steps / t_ga, 1), "buckets": len(runner.buckets),
                    "bucket_sizes_residues_edges_atoms_bonds": [list(k) for k in sizes][:12]}
+    # ---- the eager epoch once more with the protein encoder's parameters fused into ONE autograd leaf
+    # (JointGNN.fuse_encoder_parameters, opt-in): what the 74 per-tensor leaves cost on the host.  Last: cannot be undone.
+    fused = None
+    gm = model.protein_gnn.gnn_model
+    if train and args.dtype != "bf16" and getattr(gm, "_onehot_ntypes", False) and gm._onehot_etypes:
+        model.fuse_encoder_parameters()
+        prot_params = [p for p in model.protein_gnn.parameters() if p.numel()]
+        drug_params = [p for p in model.molecule_gnn.parameters() if p.numel()]
+        with torch.set_grad_enabled(True):
+            for b in batches[:MIN_WARMUP]:
+                step(*b)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for b in batches:
+                step(*b)
+            t_fi = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            t_fa = time.perf_counter() - t0
+        fused = {"what": "same eager epoch after JointGNN.fuse_encoder_parameters(): each encoder's parameter arena is its "
+                         "one trainable leaf (checkpoint keys unchanged)", "leaves": len(prot_params) + len(drug_params),
+                 "ms_per_step": round(t_fa / steps * 1e3, 4), "host_issue_ms_per_step": round(t_fi / steps * 1e3, 4),
+                 "pairs_per_s": round(B * steps / t_fa, 1)}
     edges = [int(b[0]["edge_index"].shape[1]) for b in batches]
+    ret_extra = {"eager_fused_parameters": fused}
+    return {**_epoch_summary(args, steps, B, n_prot, n_drug, t_all, t_issue, batches, edges, t_gen, graphed), **ret_extra}
+
+
+def _epoch_summary(args, steps, B, n_prot, n_drug, t_all, t_issue, batches, edges, t_gen, graphed):
     return {"what": "one epoch of DIFFERENT batches, eager (no HIP graph), nn.Module API, C++ autograd fast path" if
             __import__("gvp_hip._lib", fromlist=["bridge"]).bridge() is not None else
             "one epoch of DIFFERENT batches, eager (no HIP graph), nn.Module API, Python custom ops",

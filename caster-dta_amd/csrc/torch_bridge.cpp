@@ -274,6 +274,30 @@ GineMeta gine_meta(const std::vector<int64_t>& widths, int64_t nt, int64_t net, 
   m.cfg.num_ntypes = (int32_t)nt; m.cfg.num_etypes = (int32_t)net; m.cfg.edge_dim = (int32_t)edge_dim; m.cfg.act_slope = (float)slope;
   return m;
 }
+// ONE-LEAF MODE (HomoMoleculeGNN_GINE.fuse_parameters): `params` is a single flat tensor holding the 7 L tensors end to
+// end in the order below; it is split into views here (shapes follow from the configuration) and the backward node
+// returns ONE gradient, the flat buffer the kernels' gradients are written to anyway.
+std::vector<at::Tensor> gine_split_arena(const at::Tensor& arena, const GineMeta& m) {
+  std::vector<at::Tensor> v;
+  const at::Tensor flat = arena.detach();
+  TORCH_CHECK(flat.dim() == 1 && flat.is_contiguous(), "the fused GINE parameter arena must be a contiguous 1-D tensor");
+  int64_t off = 0;
+  auto take = [&](std::initializer_list<int64_t> shape) {
+    int64_t n = 1;
+    for (int64_t d : shape) n *= d;
+    TORCH_CHECK(off + n <= flat.numel(), "the fused GINE parameter arena is shorter than the configuration needs");
+    v.push_back(flat.narrow(0, off, n).view(at::IntArrayRef(shape.begin(), shape.size())));
+    off += n;
+  };
+  const int64_t ew = m.cfg.num_etypes + m.cfg.edge_dim;
+  for (int l = 0; l < m.L; ++l) {
+    const int64_t a = m.cfg.widths[l], b = m.cfg.widths[l + 1];
+    take({1}); take({b, a}); take({b}); take({b, b}); take({b}); take({a, ew}); take({a});
+  }
+  TORCH_CHECK(off == flat.numel(), "the fused GINE parameter arena has ", flat.numel(), " floats, the configuration needs ", off);
+  return v;
+}
+
 // params: 7 tensors per layer in slab / state_dict order  eps | w0 | b0 | w1 | b1 | we | be
 void gine_weights(const std::vector<at::Tensor>& params, int L, std::vector<at::Tensor>& keep, std::vector<cgvp_gine_w>& w) {
   TORCH_CHECK((int)params.size() == 7 * L, "expected 7 parameter tensors per GINE layer");
@@ -295,11 +319,12 @@ struct GineBackward : public Node {
   int64_t N = 0, E = 0;
   double dropout_p = 0;
   bool need_x = false;
+  bool one_leaf = false;          // the caller's `params` was the single fused arena: return one gradient
   int max_workgroups = 0;
 
   variable_list apply(variable_list&& grads) override {
     Tic tic_all("gine_bwd.apply");
-    const size_t np = params.size();
+    const size_t np = one_leaf ? 1 : params.size();
     variable_list out(np + 1);
     if (grads.empty() || !grads[0].defined()) return out;
     TORCH_CHECK(ws.defined(), "caster_gvp: backward through a drug encoder pass whose saved state was already released "
@@ -330,11 +355,15 @@ struct GineBackward : public Node {
                                     current_stream(x)),
             "cgvp_gine_backward_pass");
     }
-    int64_t off = 0;
-    for (size_t i = 0; i < np; ++i) {
-      const int64_t n = params[i].numel();
-      if (task_should_compute_output(i)) out[i] = gflat.as_strided(params[i].sizes(), c10::contiguous_strides(params[i].sizes()), off);
-      off += n;
+    if (one_leaf) {
+      if (task_should_compute_output(0)) out[0] = gflat;
+    } else {
+      int64_t off = 0;
+      for (size_t i = 0; i < np; ++i) {
+        const int64_t n = params[i].numel();
+        if (task_should_compute_output(i)) out[i] = gflat.as_strided(params[i].sizes(), c10::contiguous_strides(params[i].sizes()), off);
+        off += n;
+      }
     }
     if (need_x) out[np] = g_x;
     return out;
@@ -345,7 +374,7 @@ struct GineBackward : public Node {
   std::string name() const override { return "CasterGvpGineEncoderBackward"; }
 };
 
-std::tuple<at::Tensor, at::Tensor> gine_encoder(std::vector<at::Tensor> params, at::Tensor x_in, at::Tensor ntypes_in,
+std::tuple<at::Tensor, at::Tensor> gine_encoder(std::vector<at::Tensor> params_in, at::Tensor x_in, at::Tensor ntypes_in,
                                                 at::Tensor eattr_in, at::Tensor etypes_in, at::Tensor edge_index_in,
                                                 std::vector<at::Tensor> csr, std::vector<int64_t> widths, int64_t num_ntypes,
                                                 int64_t num_etypes, double slope, double dropout_p, bool save_state,
@@ -364,6 +393,8 @@ std::tuple<at::Tensor, at::Tensor> gine_encoder(std::vector<at::Tensor> params, 
   if (num_ntypes > 0) ntypes = ready(ntypes_in, "ntypes", at::kLong);
   if (num_etypes > 0) etypes = ready(etypes_in, "etypes", at::kLong);
   if (!tables) edge_index = ready(edge_index_in, "edge_index", at::kLong);
+  const bool one_leaf = params_in.size() == 1;
+  const std::vector<at::Tensor> params = one_leaf ? gine_split_arena(params_in[0], meta) : params_in;
   std::vector<at::Tensor> keep;
   std::vector<cgvp_gine_w> w;
   gine_weights(params, meta.L, keep, w);
@@ -394,12 +425,13 @@ std::tuple<at::Tensor, at::Tensor> gine_encoder(std::vector<at::Tensor> params, 
   check(rc, "cgvp_gine_forward_pass");
   if (!save_state) return {out, at::Tensor()};
   bool any = false;
-  for (const at::Tensor& p : params) any = any || p.requires_grad();
+  for (const at::Tensor& p : params_in) any = any || p.requires_grad();
   const bool need_x = x_in.requires_grad();
   if (at::GradMode::is_enabled() && (any || need_x)) {
     auto node = std::shared_ptr<GineBackward>(new GineBackward(), torch::autograd::deleteNode);
-    node->set_next_edges(torch::autograd::collect_next_edges(params, x_in));
+    node->set_next_edges(torch::autograd::collect_next_edges(params_in, x_in));
     node->meta = meta;
+    node->one_leaf = one_leaf;
     node->params.reserve(params.size());
     for (const at::Tensor& p : params) node->params.push_back(p.detach());
     node->csr = csr;

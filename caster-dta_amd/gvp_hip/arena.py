@@ -83,3 +83,74 @@ def flatten_state(state, num_convs, device=None):
     parts = [state[k].detach().reshape(-1).float() for k in lba_param_keys(num_convs)]
     flat = torch.cat(parts)
     return flat.to(device) if device is not None else flat
+
+
+class FusedLeaf:
+    """ONE trainable leaf for a module tree (opt-in `fuse_parameters()` of the two encoders).
+
+    PyTorch's autograd engine spends 3-4 us of host time per parameter leaf in every backward pass (one AccumulateGrad
+    node each); the kernels already write all weight gradients into one flat buffer.  `FusedLeaf` replaces the listed
+    nn.Parameters of `root` by a single `nn.Parameter` (`root.arena`, their values end to end in the given order):
+
+      * the per-module attributes (`lin.weight`, ...) stay readable: plain tensor views of the arena's storage, re-seated
+        whenever the arena is re-materialised (`.to()`, `.float()`);
+      * `state_dict()` / `load_state_dict(strict=True)` keep the per-tensor keys and shapes (hooks), so checkpoints are
+        interchangeable with the unfused model and with the reference;
+      * `named_parameters()` lists `arena` instead: build the optimizer AFTER fusing.  Cannot be undone.
+    """
+
+    def __init__(self, root, keys):
+        """`keys`: dotted attribute paths below `root`, in arena order (zero-size parameters are skipped)."""
+        self.root = root
+        named = dict(root.named_parameters())
+        self.items = [(k, tuple(named[k].shape), named[k].numel()) for k in keys if named[k].numel() > 0]
+        flat = torch.cat([named[k].detach().reshape(-1) for k, _, _ in self.items])
+        for k, _, _ in self.items:
+            mod, name = self.owner(k)
+            del mod._parameters[name]
+        root.arena = torch.nn.Parameter(flat)
+        self.seat()
+        root._register_state_dict_hook(self._state_dict_hook)
+        root._register_load_state_dict_pre_hook(self._load_hook)
+
+    def owner(self, key):
+        mod = self.root
+        *path, name = key.split(".")
+        for part in path:
+            mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
+        return mod, name
+
+    def views(self, flat):
+        off = 0
+        for k, shape, n in self.items:
+            yield k, flat[off:off + n].view(shape)
+            off += n
+
+    def seat(self):
+        for k, v in self.views(self.root.arena.detach()):
+            mod, name = self.owner(k)
+            object.__setattr__(mod, name, v)
+
+    def _state_dict_hook(self, module, state_dict, prefix, local_metadata):
+        flat = state_dict.pop(prefix + "arena")
+        for k, v in self.views(flat):
+            state_dict[prefix + k] = v
+
+    def _load_hook(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        if prefix + "arena" in state_dict:
+            return
+        cur = self.root.arena.detach()
+        parts = []
+        for k, v in self.views(cur):
+            t = state_dict.pop(prefix + k, None)
+            if t is None:
+                if strict:
+                    missing_keys.append(prefix + k)
+                parts.append(v.reshape(-1))
+            elif tuple(t.shape) != tuple(v.shape):
+                error_msgs.append(f"size mismatch for {prefix + k}: copying a param with shape {tuple(t.shape)} from "
+                                  f"checkpoint, the shape in current model is {tuple(v.shape)}.")
+                parts.append(v.reshape(-1))
+            else:
+                parts.append(t.detach().reshape(-1).to(cur))
+        state_dict[prefix + "arena"] = torch.cat(parts)

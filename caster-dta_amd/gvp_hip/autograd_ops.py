@@ -410,7 +410,7 @@ def lba_encoder(model, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, train_dro
                                                 None if csr else ops.csr_counters(dev, N), ops.FUSE_LAYER)
         if draw:
             _LAST_WS["lba"] = (ws, 0)
-        if not zero_copy and model._onehot_ntypes and model._onehot_etypes:
+        if not zero_copy and not model._fused and model._onehot_ntypes and model._onehot_etypes:
             model._arena.rebuild()          # something re-materialised the parameters: re-seat them as arena views
         return out
     out, _, _ = torch.ops.caster_gvp.lba_encoder(
@@ -610,7 +610,13 @@ torch.library.register_autograd("caster_gvp::gine_encoder", _gine_backward, setu
 torch.library.register_autocast("caster_gvp::gine_encoder", "cuda", torch.float32)
 
 
-def gine_params(model):
+def gine_params(model, one_leaf_ok=False):
+    """The 7 L tensors the kernels take, in _GINE_KEYS order.  A model in one-leaf mode (`fuse_parameters`): the arena
+    itself for the C++ fast path (`one_leaf_ok`), else autograd-connected views of it."""
+    if getattr(model, "_fused", False):
+        if one_leaf_ok:
+            return [model.arena]
+        return [v for _, v in model._leaf.views(model.arena)]
     emb = None if model._onehot_etypes else model.etype_embedding
     params = []
     for conv in model.conv_list:
@@ -636,7 +642,7 @@ def gine_encoder(model, x, ntypes, eattr, etypes, edge_index, slope, train_dropo
             else:
                 draw = True
         with torch.cuda.device(dev):
-            out, ws = br.gine_encoder(gine_params(model), x, ntypes, eattr, etypes, edge_index, csr, widths,
+            out, ws = br.gine_encoder(gine_params(model, one_leaf_ok=True), x, ntypes, eattr, etypes, edge_index, csr, widths,
                                       model.num_ntypes if model._onehot_ntypes else 0,
                                       model.num_etypes, float(slope), p, save_state, masks,
                                       rng_state("gine", dev) if draw else None, None if csr else ops.csr_counters(dev, N),

@@ -185,6 +185,14 @@ class JointGNN(nn.Module):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self._pair_group)
         torch._foreach_copy_([p.grad for p in ps], [c.view_as(p) for c, p in zip(flat.split([p.numel() for p in ps]), ps)])
 
+    def fuse_encoder_parameters(self):
+        """Opt-in, eager-mode host time: the protein encoder's 74 parameter tensors and the drug encoder's 7 per layer
+        become ONE trainable leaf each (`arena`), see `gvp_hip.arena.FusedLeaf`.  Checkpoints keep the reference's
+        keys.  Call after `.to(device)` and before building the optimizer."""
+        self.protein_gnn.gnn_model.fuse_parameters()
+        self.molecule_gnn.gnn_model.fuse_parameters()
+        return self
+
     # ------------------------------------------------------------ forward
     def forward_with_graphs(self, protein_graph, molecule_graph):
         return self.forward(*self._graphs_to_dicts(protein_graph, molecule_graph))

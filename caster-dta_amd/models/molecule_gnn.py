@@ -158,6 +158,30 @@ class HomoMoleculeGNN_GINE(BaseMoleculeGNN):
             GINEConv(MLP([a, b, b]), gin_trainable_eps, edge_w, a, aggr=self.aggr)
             for a, b in zip(widths[:-1], widths[1:])])
         self._widths = widths
+        self._fused = False
+
+    def fuse_parameters(self):
+        """ONE trainable leaf (`arena`: per layer eps | nn.lins.0 | nn.lins.1 | lin, the order the kernels' gradient
+        buffer has) instead of 7 per layer; see `gvp_hip.arena.FusedLeaf` and
+        `VectorProteinGNN_LBAModel.fuse_parameters`.  One-hot type encoders and trainable eps only."""
+        if self._fused:
+            return self
+        if not (self._onehot_ntypes and self._onehot_etypes) or not self.gin_trainable_eps:
+            raise NotImplementedError("fuse_parameters: needs one-hot type encoders and gin_trainable_eps=True")
+        from gvp_hip.arena import FusedLeaf
+        keys = []
+        for l in range(self.num_convs):
+            keys += [f"conv_list.{l}.{k}" for k in ("eps", "nn.lins.0.weight", "nn.lins.0.bias", "nn.lins.1.weight",
+                                                    "nn.lins.1.bias", "lin.weight", "lin.bias")]
+        self._leaf = FusedLeaf(self, keys)
+        self._fused = True
+        return self
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if getattr(self, "_fused", False):
+            self._leaf.seat()
+        return out
 
     def forward(self, x, edge_index, ntypes, etypes, eattr=None, batch=None):
         slope = activation_slope(self.activation)

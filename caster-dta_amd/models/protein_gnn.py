@@ -144,6 +144,28 @@ class VectorProteinGNN_LBAModel(BaseProteinGNN):
         named = dict(self.named_parameters())
         self._arena = ParamArena([named[k] for k in lba_param_keys(self.num_convs)])
         self._hip_cfg = None
+        self._fused = False
+
+    # ------------------------------------------------------------------ one-leaf mode (opt-in)
+    def fuse_parameters(self):
+        """Make the parameter arena itself the model's ONE trainable leaf, `arena` [15,117 floats for CASTER-DTA(2,2)].
+
+        Why: in eager mode PyTorch's autograd engine spends 3-4 us per parameter leaf after the backward kernels have
+        been issued (one AccumulateGrad node each); this encoder has 74 leaves, i.e. ~0.3 ms of host time per step --
+        more than the whole step takes on the GPU.  After this call the backward pass hands the engine ONE gradient
+        (the gradient arena the kernels write anyway), and an optimizer built over `model.parameters()` updates the
+        arena in place (element-wise optimizers -- SGD, Adam, AdamW -- compute exactly what they compute per tensor).
+        Checkpoints keep the reference's keys; `named_parameters()` lists `arena` (gvp_hip.arena.FusedLeaf).
+        One-hot type encoders only.  Call it after the model is on its device and BEFORE building the optimizer."""
+        if self._fused:
+            return self
+        if not (self._onehot_ntypes and self._onehot_etypes):
+            raise NotImplementedError("fuse_parameters: nn.Embedding type encoders are folded per call (op_params) and "
+                                      "keep their own leaves")
+        from gvp_hip.arena import FusedLeaf
+        self._leaf = FusedLeaf(self, lba_param_keys(self.num_convs))
+        self._fused = True
+        return self
 
     # ------------------------------------------------------------------ HIP path
     def _hip_config(self):
@@ -167,6 +189,8 @@ class VectorProteinGNN_LBAModel(BaseProteinGNN):
         what Linear(cat[embedding(type), s, |v|]) contributes -- so an equivalent [so, num_types + si + h] weight is
         built here (one tiny matmul + cat per call, differentiable: autograd carries the kernels' gradient of the
         equivalent weight back to `ws.weight` and to the embedding table)."""
+        if self._fused:
+            return [self.arena]
         params = list(self._arena.params)
         if self._onehot_ntypes and self._onehot_etypes:
             return params
@@ -194,6 +218,9 @@ class VectorProteinGNN_LBAModel(BaseProteinGNN):
         """.to() / .cuda() / .float() re-materialise every parameter: rebuild the arena right away, so that a
         model handed to torch.compile (which never runs the eager bookkeeping in forward) is already zero-copy."""
         out = super()._apply(fn, *args, **kwargs)
+        if self._fused:
+            self._leaf.seat()           # the arena moved / was re-materialised: re-point the per-module views
+            return out
         p0 = self._arena.params[0]
         if p0.is_cuda and p0.dtype == torch.float32:
             self._arena.rebuild()
@@ -208,17 +235,18 @@ class VectorProteinGNN_LBAModel(BaseProteinGNN):
             raise ValueError(f"unsupported aggregation {self.aggr!r}")
         if not x_s.is_cuda:
             raise RuntimeError(f"x: caster-dta_amd runs on MI355X only (got a {x_s.device} tensor); there is no CPU path")
-        p0 = self._arena.params[0]
+        p0 = self.arena if self._fused else self._arena.params[0]
         if p0.dtype != torch.float32:
             raise TypeError("the MI355X kernels are fp32; call .float() on the model")
         if self.out_channels[1] != 0:
             raise NotImplementedError("the fused head produces scalars only (out_channels = (n, 0))")
         from gvp_hip import autograd_ops
-        if self._onehot_ntypes and self._onehot_etypes and not torch.compiler.is_compiling() \
+        if not self._fused and self._onehot_ntypes and self._onehot_etypes and not torch.compiler.is_compiling() \
                 and autograd_ops._eager_bridge() is None:       # (the C++ fast path checks the arena itself)
             self._arena_buffer()
+        leaves = [self.arena] if self._fused else self._arena.params
         needs_grad = torch.is_grad_enabled() and (
-            any(p.requires_grad for p in self._arena.params) or any(t.requires_grad for t in (x_s, x_v, e_s, e_v)))
+            any(p.requires_grad for p in leaves) or any(t.requires_grad for t in (x_s, x_v, e_s, e_v)))
         train_dropout = self.training and self.dropout_rate > 0
         # ONE host call (C++ autograd node in eager mode, the caster_gvp::lba_encoder custom op under torch.compile)
         # for the whole encoder pass: 1 + num_convs launches (+ the CSR build)

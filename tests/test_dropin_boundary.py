@@ -43,6 +43,55 @@ def test_checkpoint_contract(joint, pretrained):
     assert count(joint.molecule_gnn) == 7390            # model_summary.txt:17
 
 
+def test_fused_parameter_mode_keeps_the_checkpoint_contract(kwargs, pretrained):
+    """`JointGNN.fuse_encoder_parameters()` (opt-in, eager host time): the protein encoder owns ONE trainable leaf, its
+    arena; `state_dict()` still has the reference's keys / shapes / values, `load_state_dict(strict=True)` still takes a
+    reference checkpoint, per-module attributes stay readable views that follow an in-place update of the arena."""
+    from models.joint_gnn import JointGNN
+    make = lambda: JointGNN(protein_gnn_kwargs=kwargs["protein_gnn_kwargs"],
+                            molecule_gnn_kwargs=kwargs["molecule_gnn_kwargs"], **kwargs["joint_gnn_kwargs"])
+    model = make()
+    model.load_state_dict(pretrained, strict=True)
+    model.fuse_encoder_parameters()
+    assert model.fuse_encoder_parameters() is model                       # idempotent
+    gm = model.protein_gnn.gnn_model
+    names = [k for k, p in model.protein_gnn.named_parameters() if p.numel()]
+    assert names == ["gnn_model.arena"] and gm.arena.numel() == 15117
+    dnames = [k for k, p in model.molecule_gnn.named_parameters() if p.numel()]
+    assert dnames == ["gnn_model.arena"] and model.molecule_gnn.gnn_model.arena.numel() == 7390
+    assert sum(p.numel() for p in model.parameters()) == 764396
+    sd = model.state_dict()
+    assert set(sd) == set(pretrained)
+    for k, v in pretrained.items():
+        assert tuple(sd[k].shape) == tuple(v.shape) and torch.equal(sd[k], v), k
+    # a reference-format checkpoint loads into the fused model, strictly
+    fresh = make().fuse_encoder_parameters()
+    assert not torch.equal(fresh.protein_gnn.gnn_model.arena, gm.arena)
+    fresh.load_state_dict(pretrained, strict=True)
+    assert torch.equal(fresh.protein_gnn.gnn_model.arena, gm.arena)
+    w = pretrained["protein_gnn.gnn_model.conv_list.1.conv.message_func.0.ws.weight"]
+    assert torch.equal(fresh.protein_gnn.gnn_model.conv_list[1].conv.message_func[0].ws.weight, w)
+    # ... and a fused model's checkpoint loads into an unfused one
+    plain = make()
+    plain.load_state_dict(sd, strict=True)
+    # strict loading still reports what a checkpoint lacks / has too much of
+    broken = {k: v for k, v in pretrained.items() if not k.endswith("gvp_to_scalar.ws.bias")}
+    with pytest.raises(RuntimeError, match="gvp_to_scalar.ws.bias"):
+        make().fuse_encoder_parameters().load_state_dict(broken, strict=True)
+    # in-place update of the arena (what an optimizer does) is what the per-module views show
+    with torch.no_grad():
+        gm.arena.mul_(2.0)
+        model.molecule_gnn.gnn_model.arena.add_(1.0)
+    assert torch.equal(gm.conv_list[1].conv.message_func[0].ws.weight, 2.0 * w)
+    assert torch.equal(model.molecule_gnn.gnn_model.conv_list[1].lin.bias,
+                       pretrained["molecule_gnn.gnn_model.conv_list.1.lin.bias"] + 1.0)
+    assert float(model.molecule_gnn.gnn_model.conv_list[0].eps) == float(pretrained["molecule_gnn.gnn_model.conv_list.0.eps"]) + 1.0
+    # .double()/.float() round trip re-seats the views on the new storage
+    model.double().float()
+    assert gm.conv_list[0].norm[0].scalar_norm.weight.data_ptr() >= gm.arena.data_ptr()
+    assert torch.equal(gm.conv_list[1].conv.message_func[0].ws.weight, 2.0 * w)
+
+
 def test_wrapper_passthrough_and_errors(joint, kwargs):
     from models.protein_gnn import SelectableProteinModelWrapper
     from models.molecule_gnn import SelectableMoleculeModelWrapper

@@ -441,3 +441,90 @@ def test_bucketed_graph_replay_equals_eager_on_changing_batches(pretrained):
         for a, b in zip(got[2:], want[2:]):
             assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 2e-6 * scale, (seed, tuple(a.shape))
     assert len(runner.buckets) == len(seen) < len(cases)               # cases 1, 2 and 4 share a bucket
+
+
+def test_fused_parameter_mode_trains_like_the_per_tensor_model(pretrained, lba_small, monkeypatch):
+    """`JointGNN.fuse_encoder_parameters()`: one autograd leaf for the protein encoder.  Same outputs, the gradient of
+    the arena is the per-tensor gradients laid end to end (against the REFERENCE's autograd numbers of lba_small too),
+    and two SGD-with-momentum steps move both models to the same weights (checkpoints compared key by key).  Eager C++ fast path
+    and the Python custom-op path."""
+    from models.joint_gnn import JointGNN
+    from gvp_hip.arena import lba_param_keys
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))
+    make = lambda: JointGNN(protein_gnn_kwargs=kw["protein_gnn_kwargs"], molecule_gnn_kwargs=kw["molecule_gnn_kwargs"],
+                            **kw["joint_gnn_kwargs"])
+    plain, fused = make(), make()
+    for m in (plain, fused):
+        m.load_state_dict(pretrained, strict=True)
+        m.to(DEV).train()
+    fused.fuse_encoder_parameters()
+    gm = fused.protein_gnn.gnn_model
+    g = lba_small
+    T = torch.from_numpy
+    d = _to(dict(x=(T(g["x_s"]), T(g["x_v"])), edge_index=T(g["edge_index"]), ntypes=T(g["ntypes"]),
+                 etypes=T(g["etypes"]), eattr=(T(g["e_s"]), T(g["e_v"])), batch=T(g["batch"])))
+    r = T(g["r"]).to(DEV)
+    from gvp_hip import autograd_ops
+    for use_bridge in (True, False):
+        with monkeypatch.context() as mp:
+            if not use_bridge:                               # the torch.library custom ops in eager mode
+                mp.setattr(autograd_ops, "_eager_bridge", lambda: None)
+            for m in (plain, fused):
+                m.eval()
+                m.zero_grad(set_to_none=True)
+            out_p = plain.protein_gnn(**d)
+            out_f = fused.protein_gnn(**d)
+            assert rel_err(out_f, g["out"]) < TOL and rel_err(out_f, out_p.detach().cpu().numpy()) < 1e-6
+            (out_p * r).sum().backward()
+            (out_f * r).sum().backward()
+            named = dict(plain.protein_gnn.gnn_model.named_parameters())
+            flat = torch.cat([named[k].grad.reshape(-1) for k in lba_param_keys(2) if named[k].numel()])
+            assert gm.arena.grad.shape == (15117,)
+            assert float((gm.arena.grad - flat).abs().max()) <= 1e-5 * float(flat.abs().max())
+            off = 0
+            for k in lba_param_keys(2):                      # ... and against the reference's autograd
+                n = named[k].numel()
+                if n:
+                    ref = T(g["g_" + k]).to(DEV).reshape(-1)
+                    assert float((gm.arena.grad[off:off + n] - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 2e-6 * float(flat.abs().max()), k
+                    off += n
+    # drug encoder: the arena's gradient through the C++ node (one leaf) and through the custom op (connected views)
+    # equals the per-tensor gradients of the unfused model laid end to end
+    p6, m6 = ds.pair_batch(6, 3)
+    md = _to(ds.to_torch(m6))
+    dm = fused.molecule_gnn.gnn_model
+    ga = torch.randn(md["x"].shape[0], 64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    plain.zero_grad(set_to_none=True)
+    (plain.molecule_gnn(**md) * ga).sum().backward()
+    keys = ("eps", "nn.lins.0.weight", "nn.lins.0.bias", "nn.lins.1.weight", "nn.lins.1.bias", "lin.weight", "lin.bias")
+    named = dict(plain.molecule_gnn.gnn_model.named_parameters())
+    dflat = torch.cat([named[f"conv_list.{l}.{k}"].grad.reshape(-1) for l in range(2) for k in keys])
+    for use_bridge in (True, False):
+        with monkeypatch.context() as mp:
+            if not use_bridge:
+                mp.setattr(autograd_ops, "_eager_bridge", lambda: None)
+            fused.zero_grad(set_to_none=True)
+            (fused.molecule_gnn(**md) * ga).sum().backward()
+            assert dm.arena.grad.shape == (7390,)
+            assert float((dm.arena.grad - dflat).abs().max()) <= 1e-5 * float(dflat.abs().max()), use_bridge
+    # two optimizer steps (dropout off so both models see the same numbers)
+    # (SGD: linear in the gradient.  Adam's first steps move every weight by lr * sign(g), which turns the run-to-run
+    # rounding noise of analytically-zero gradients -- float atomics in d h[src] -- into +-lr differences)
+    opts = [torch.optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-2) for m in (plain, fused)]
+    pd = _to(ds.to_torch(p6))
+    for _ in range(2):
+        for m, opt in zip((plain, fused), opts):
+            m.eval()
+            opt.zero_grad(set_to_none=True)
+            y, _ = m(pd, md)
+            y.square().sum().backward()
+            opt.step()
+    sp, sf = plain.state_dict(), fused.state_dict()
+    assert set(sp) == set(sf)
+    moved = 0
+    for k in sp:
+        if not sp[k].numel():                                # the zero-size dummy_params
+            continue
+        assert float((sp[k] - sf[k]).abs().max()) <= 2e-5 * max(float(sp[k].abs().max()), 1e-3), k
+        moved += int(not torch.equal(sp[k].cpu(), pretrained[k]))
+    assert moved > 100

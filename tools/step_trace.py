@@ -1,7 +1,8 @@
 """Timeline of ONE step from a `rocprofv3 --kernel-trace --output-format csv` run of bench.py.
 
     python tools/step_trace.py <dir with *_kernel_trace.csv> [nth-from-last step; default: the shortest step,
-                                                               i.e. one HIP-graph replay of the timed region]
+                                                               that runs both encoders, i.e. one HIP-graph
+                                                               replay of the timed region]
 
 Prints every kernel of the chosen step with start / end relative to the step's first kernel, its queue, and the gap to
 the previous kernel on the same queue.  A step is delimited by `reduce_segments_kernel` (the last launch of the protein
@@ -18,8 +19,12 @@ for p in paths:
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ends = [i for i, r in enumerate(rows) if "reduce_segments_kernel" in r["Kernel_Name"]]
 if nth is None:
+    # candidates: steps that run BOTH encoders (bench.py's roofline leg launches protein-only passes: not a step) --
+    # of those, the shortest is a HIP-graph replay of the timed region
     span = lambda k: int(rows[ends[k]]["End_Timestamp"]) - int(rows[ends[k - 1]]["End_Timestamp"])
-    nth = len(ends) - min(range(2, len(ends) - 1), key=span)
+    both = [k for k in range(2, len(ends) - 1)
+            if any("gine_quad_bwd" in r["Kernel_Name"] for r in rows[ends[k - 1] + 1:ends[k] + 1])]
+    nth = len(ends) - min(both or range(2, len(ends) - 1), key=span)
 hi, lo = ends[-nth], ends[-nth - 1]
 t_prev_end = int(rows[lo]["End_Timestamp"])
 step = [r for r in rows[lo + 1:] if int(r["Start_Timestamp"]) <= int(rows[hi]["End_Timestamp"])]
