@@ -27,7 +27,6 @@ def main():
         if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "SQ_BUSY_CYCLES" in v and v["SQ_BUSY_CYCLES"]:
             v["_mfma_busy_over_sq_busy"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / v["SQ_BUSY_CYCLES"], 3)
         kernels[k] = v
-    import os
     tag = os.path.basename(out).replace("pmc_sq_stalls_", "").replace(".json", "")      # workload (and dtype) of this file
     json.dump({"note": f"rocprofv3 --pmc SQ_* (separate passes), {tag} fwd+bwd eager, per-launch averages; raw counter "
                        "units as rocprofv3 reports them on gfx950 (WAVE/WAIT/ACTIVE in quad-cycles summed over waves)",
