@@ -88,6 +88,8 @@ def parse():
                          "computes in half precision; the encoder ops' autocast rule keeps them in fp32)")
     ap.add_argument("--compile-graph", action="store_true",
                     help="with --compile: additionally capture the compiled step into a HIP graph (experiment)")
+    ap.add_argument("--issue-order", default="protein", choices=["protein", "drug"],
+                    help="which encoder's launches are issued (and captured) first in a step (A/B)")
     ap.add_argument("--drug-priority", type=int, default=0,
                     help="diagnostic: priority of the drug encoder's side stream (-1 = high)")
     ap.add_argument("--gine-bwd-wgs", type=int, default=0,
@@ -261,24 +263,33 @@ def main():
         side.wait_stream(main_s)
         # the protein chain is the critical path: it is issued first and stays on the launch stream (a HIP graph keeps
         # the first-captured branch on the launch queue; the other branch pays the cross-queue joins)
+        def drug_forward():
+            with torch.cuda.stream(side if args.drug_stream == "side" else main_s):   # drug graphs are tiny: run them beside the protein kernels
+                if collate:
+                    collate[1][0].collate(collate[1][1], attach_to=mdata["edge_index"])
+                return model.molecule_gnn(**mdata)
+        if args.issue_order == "drug":
+            atoms = drug_forward()
         if collate:
             collate[0][0].collate(collate[0][1], attach_to=pdata["edge_index"])
         residues = model.protein_gnn(**pdata)
-        with torch.cuda.stream(side if args.drug_stream == "side" else main_s):   # drug graphs are tiny: run them beside the protein kernels
-            if collate:
-                collate[1][0].collate(collate[1][1], attach_to=mdata["edge_index"])
-            atoms = model.molecule_gnn(**mdata)
+        if args.issue_order != "drug":
+            atoms = drug_forward()
         if not train:
             main_s.wait_stream(side)
             return residues, atoms
         # backward of both encoders: every weight gradient (22,507 parameters) is produced.  Two engine calls, so that
         # the protein backward is again the first-issued branch and the drug backward stays on its side stream
+        def drug_backward():
+            if args.drug_stream == "side":
+                with torch.cuda.stream(side):
+                    return torch.autograd.grad([atoms], drug_params, [g_atm])
+            return torch.autograd.grad([atoms], drug_params, [g_atm])
+        if args.issue_order == "drug":
+            gd = drug_backward()
         gp = torch.autograd.grad([residues], prot_params, [g_res])
-        if args.drug_stream == "side":
-            with torch.cuda.stream(side):
-                gd = torch.autograd.grad([atoms], drug_params, [g_atm])
-        else:
-            gd = torch.autograd.grad([atoms], drug_params, [g_atm])
+        if args.issue_order != "drug":
+            gd = drug_backward()
         main_s.wait_stream(side)
         return gp + gd
 

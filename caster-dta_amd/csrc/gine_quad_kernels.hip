@@ -86,7 +86,10 @@ struct GineQ {
   typedef GemmT<KHid, KOut, CHID> G1T;
   typedef GemmT<KIn, KHid, CIN> G0T;
   static constexpr int F_E = 0, F_0 = F_E + GE::NFRAG * 64, F_0T = F_0 + G0::NFRAG * 64, F_1 = F_0T + G0T::NFRAG * 64,
-                       F_1T = F_1 + G1::NFRAG * 64, F_SIZE = F_1T + G1T::NFRAG * 64;
+                       F_1T = F_1 + G1::NFRAG * 64,
+                       // the three bias vectors sit behind the fragments (be zero-padded to CINP): the tile loops read
+                       // them from LDS -- a global load per use put a memory round trip in front of every GEMM
+                       V_BE = F_1T + G1T::NFRAG * 64, V_B0 = V_BE + CINP, V_B1 = V_B0 + CHID, F_SIZE = V_B1 + COUT;
   static constexpr int ROWS = TILE * CINP;       // per wave: agg rows, then dh rows
   // Waves per workgroup: as many as one CU's LDS holds (the grid is capped at the 16 CUs the protein
   // backward leaves free, so waves per CU is what sets the number of tiles a wave has to walk).
@@ -125,6 +128,122 @@ __device__ __forceinline__ void stage_fragments(float* lds, const float* __restr
   }
 }
 
+#define KEEP_UNCONDITIONAL(V) asm volatile("" : "+v"(V))
+// CGVP_GINE_PIN = 1 pins every gather (below) in front of the selects (52-wide backward: 334 -> 17 `vmcnt(0)` waits,
+// 538 -> 109 branches).  A/B in one GPU-box call at davis_b64 (tools/build_variant.sh + tools/ab_libs.sh, unprofiled
+// replays, custom-op host path): drug chain alone 170.6 (un-pinned) vs 172.4 us (pinned), step with both encoders 260.0
+// vs 262.5 us -- the loads hit in L2 and were overlapping already; pinning only adds registers.  Default 0.
+#ifndef CGVP_GINE_PIN
+#define CGVP_GINE_PIN 0
+#endif
+constexpr bool G_PIN = CGVP_GINE_PIN != 0;
+// BRANCH-FREE GATHERS.  Every global load below is unconditional on a CLAMPED index and the value is selected afterwards:
+// a load under a per-lane branch is its own `s_waitcnt vmcnt(0)` round trip (188 of them in the 52-wide backward before
+// this), an unconditional one joins the others in flight.  Row 0 of every table exists whenever a tile / chunk does.
+//   chunk metadata of sorted position c0 + lane (dst = -1 behind the chunk's last edge)
+template <int NET, typename ArgsT>
+__device__ __forceinline__ void chunk_meta(const ArgsT& a, int32_t c0, int32_t e1, int lane, int32_t& m_eid, int32_t& m_src,
+                                           int32_t& m_dst, int32_t& m_et) {
+  const bool in = c0 + lane < e1;
+  const int32_t p = in ? c0 + lane : e1 - 1;
+  m_eid = a.eperm[p];
+  m_src = a.esrc[p];
+  const int32_t d = a.edst[p];
+  m_et = 0;
+  if (NET > 0) {
+    const int et = (int)a.etypes[m_eid];
+    m_et = et < 0 ? 0 : (et >= NET ? NET - 1 : et);
+  }
+  m_dst = in ? d : -1;
+}
+//   k-slots [onehot(bond type) | bond features] of edge `eid` and the (typed) feature row of its source atom
+template <class Q, int CIN, int NT, int NET, int ED, bool PIN, typename ArgsT>
+__device__ __forceinline__ void edge_inputs(const ArgsT& a, int32_t eid, int32_t et, int32_t src, bool active, int g,
+                                            float (&fs)[4], f4 (&xj)[Q::MI]) {
+  constexpr int KE = Q::KE, XW = Q::XW;
+  const int64_t er = (int64_t)(active ? eid : 0) * ED, xr = (int64_t)(active ? src : 0) * XW;
+  int nty = -1;
+  if (NT > 0) nty = (int)a.ntypes[active ? src : 0];
+  float f[4], xv[Q::MI][4];
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) {
+    int col = 4 * s_ + g - NET;
+    col = col < 0 ? 0 : (col >= ED ? ED - 1 : col);
+    f[s_] = a.eattr[er + col];
+  }
+#pragma unroll
+  for (int mt = 0; mt < Q::MI; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int col = 16 * mt + 4 * g + r - NT;
+      col = col < 0 ? 0 : (col >= XW ? XW - 1 : col);
+      xv[mt][r] = a.x[xr + col];
+    }
+  // every load above is CONSUMED here, outside any branch: without this the compiler sinks each load into the taken
+  // side of the select below and the round trips are back
+  if (PIN) {
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) KEEP_UNCONDITIONAL(f[s_]);
+#pragma unroll
+    for (int mt = 0; mt < Q::MI; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) KEEP_UNCONDITIONAL(xv[mt][r]);
+  }
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) {
+    const int idx = 4 * s_ + g;
+    const float v = idx < NET ? (et == idx ? 1.f : 0.f) : (idx < KE ? f[s_] : 0.f);
+    fs[s_] = active ? v : 0.f;
+  }
+#pragma unroll
+  for (int mt = 0; mt < Q::MI; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * mt + 4 * g + r;
+      const float v = c < NT ? (nty == c ? 1.f : 0.f) : (c < CIN ? xv[mt][r] : 0.f);
+      xj[mt][r] = active ? v : 0.f;
+    }
+}
+//   the (typed) feature row of atom n0 + i of the tile (zeros for the lanes behind the last atom)
+template <class Q, int CIN, int NT, bool PIN, typename ArgsT>
+__device__ __forceinline__ void node_inputs(const ArgsT& a, int64_t n, bool valid, int64_t n0, int g, f4 (&xi)[Q::MI]) {
+  constexpr int XW = Q::XW;
+  const int64_t nr = valid ? n : n0;
+  int nty = -1;
+  if (NT > 0) nty = (int)a.ntypes[nr];
+  float xv[Q::MI][4];
+#pragma unroll
+  for (int mt = 0; mt < Q::MI; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int col = 16 * mt + 4 * g + r - NT;
+      col = col < 0 ? 0 : (col >= XW ? XW - 1 : col);
+      xv[mt][r] = a.x[nr * XW + col];
+    }
+  if (PIN) {
+#pragma unroll
+    for (int mt = 0; mt < Q::MI; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) KEEP_UNCONDITIONAL(xv[mt][r]);
+  }
+#pragma unroll
+  for (int mt = 0; mt < Q::MI; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * mt + 4 * g + r;
+      const float v = c < NT ? (nty == c ? 1.f : 0.f) : (c < CIN ? xv[mt][r] : 0.f);
+      xi[mt][r] = valid ? v : 0.f;
+    }
+}
+
+template <int CIN, int CINP, int CHID, int COUT, int NTHR>
+__device__ __forceinline__ void stage_biases(float* v_be, float* v_b0, float* v_b1, const float* __restrict__ be,
+                                             const float* __restrict__ b0, const float* __restrict__ b1) {
+  for (int k = threadIdx.x; k < CINP; k += NTHR) v_be[k] = k < CIN ? be[k] : 0.f;
+  for (int k = threadIdx.x; k < CHID; k += NTHR) v_b0[k] = b0[k];
+  for (int k = threadIdx.x; k < COUT; k += NTHR) v_b1[k] = b1[k];
+}
+
 // rows [16 X, 16 X + 16) of dW1 = dy (x) t
 template <class Q, int X>
 __device__ __forceinline__ void dw1_band(const f4 (&AT)[Q::MO], const f4 (&BT)[Q::MH], float* blk, int lane) {
@@ -156,6 +275,7 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
   stage_fragments<typename Q::G0T, GQ_TPB>(frag + Q::F_0T, a.w0);
   stage_fragments<typename Q::G1, GQ_TPB>(frag + Q::F_1, a.w1);
   stage_fragments<typename Q::G1T, GQ_TPB>(frag + Q::F_1T, a.w1);
+  stage_biases<CIN, CINP, CHID, COUT, GQ_TPB>(frag + Q::V_BE, frag + Q::V_B0, frag + Q::V_B1, a.be, a.b0, a.b1);
   for (int k = lane0; k < Q::BLK / 4; k += WAVE) reinterpret_cast<f4*>(blk)[k] = f4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
@@ -184,43 +304,15 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
 
     auto load_chunk = [&](int32_t c0, int lane, f4 (&xj)[NTL][MI]) {
       const int i = lane & 15, g = lane >> 4;
-      int32_t m_eid = 0, m_src = 0, m_dst = -1, m_et = 0;
-      if (c0 + lane < e1) {
-        m_eid = a.eperm[c0 + lane];
-        m_src = a.esrc[c0 + lane];
-        m_dst = a.edst[c0 + lane];
-        if (NET > 0) {
-          m_et = (int)a.etypes[m_eid];
-          m_et = m_et < 0 ? 0 : (m_et >= NET ? NET - 1 : m_et);
-        }
-      }
+      int32_t m_eid, m_src, m_dst, m_et;
+      chunk_meta<NET>(a, c0, e1, lane, m_eid, m_src, m_dst, m_et);
 #pragma unroll
       for (int t = 0; t < NTL; ++t) {
         const int sl = 16 * t + i;
         const int32_t eid = __shfl(m_eid, sl), et = __shfl(m_et, sl);
         c_src[t] = __shfl(m_src, sl);
         c_dst[t] = __shfl(m_dst, sl);                      // -1: no such edge
-        const bool active = c_dst[t] >= 0;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {                       // k-slots of [onehot(type) | bond features]
-          const int idx = 4 * s + g;
-          float v = 0.f;
-          if (active) {
-            if (idx < NET) v = (et == idx) ? 1.f : 0.f;
-            else if (idx < KE) v = a.eattr[(int64_t)eid * ED + (idx - NET)];
-          }
-          c_fs[t][0][s] = v;
-        }
-#pragma unroll
-        for (int mt = 0; mt < MI; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int c = 16 * mt + 4 * g + r;
-            float v = 0.f;
-            if (active && c < CIN)
-              v = c < NT ? (((int)a.ntypes[c_src[t]] == c) ? 1.f : 0.f) : a.x[(int64_t)c_src[t] * XW + (c - NT)];
-            xj[t][mt][r] = v;
-          }
+        edge_inputs<Q, CIN, NT, NET, ED, G_PIN>(a, eid, et, c_src[t], c_dst[t] >= 0, g, c_fs[t][0], xj[t]);
       }
     };
     // message pre-activation of tile t of the loaded chunk -> ReLU pattern (and the messages)
@@ -229,12 +321,7 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
       unsigned pos = 0u;
 #pragma unroll
       for (int mt = 0; mt < MI; ++mt) {
-        f4 acc[1];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = 16 * mt + 4 * g + r;
-          acc[0][r] = c < CIN ? a.be[c] : 0.f;
-        }
+        f4 acc[1] = {*reinterpret_cast<const f4*>(frag + Q::V_BE + 16 * mt + 4 * g)};
         apply<typename Q::GE, 1>(frag + Q::F_E, mt, c_fs[t], acc, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -285,17 +372,12 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
       const bool valid = i < nn;
       const int64_t n = n0 + i;
       f4 xi[MI], h[MI];
+      node_inputs<Q, CIN, NT, G_PIN>(a, n, valid, n0, g, xi);
 #pragma unroll
       for (int mt = 0; mt < MI; ++mt) {
         const f4 ag = *reinterpret_cast<const f4*>(rows + i * CINP + 16 * mt + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = 16 * mt + 4 * g + r;
-          float v = 0.f;
-          if (valid && c < CIN) v = c < NT ? (((int)a.ntypes[n] == c) ? 1.f : 0.f) : a.x[n * XW + (c - NT)];
-          xi[mt][r] = v;
-          h[mt][r] = fmaf(eps1, v, ag[r]);
-        }
+        for (int r = 0; r < 4; ++r) h[mt][r] = fmaf(eps1, xi[mt][r], ag[r]);
       }
       float bh[1][Q::KIn::steps];
 #pragma unroll
@@ -303,9 +385,7 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
       f4 tpre[MH], t[MH];
 #pragma unroll
       for (int mt = 0; mt < MH; ++mt) {
-        f4 acc[1];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[0][r] = a.b0[16 * mt + 4 * g + r];
+        f4 acc[1] = {*reinterpret_cast<const f4*>(frag + Q::V_B0 + 16 * mt + 4 * g)};
         apply<typename Q::G0, 1>(frag + Q::F_0, mt, bh, acc, lane);
         tpre[mt] = acc[0];
 #pragma unroll
@@ -317,15 +397,11 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
       f4 dy[MO];
 #pragma unroll
       for (int mt = 0; mt < MO; ++mt) {
-        f4 acc[1];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[0][r] = a.b1[16 * mt + 4 * g + r];
+        f4 acc[1] = {*reinterpret_cast<const f4*>(frag + Q::V_B1 + 16 * mt + 4 * g)};
         apply<typename Q::G1, 1>(frag + Q::F_1, mt, bt, acc, lane);
-        f4 gy = zero;
-        if (valid) {
-          gy = *reinterpret_cast<const f4*>(a.g_out + n * COUT + 16 * mt + 4 * g);
-          gy = gy * gine_dropout<COUT>(a.mask, a.rng, n, mt, g);
-        }
+        f4 gy = *reinterpret_cast<const f4*>(a.g_out + (valid ? n : n0) * COUT + 16 * mt + 4 * g);
+        gy = gy * gine_dropout<COUT>(a.mask, a.rng, valid ? n : n0, mt, g);
+        if (!valid) gy = zero;
 #pragma unroll
         for (int r = 0; r < 4; ++r) dy[mt][r] = gy[r] * (acc[0][r] > 0.f ? 1.f : a.slope);
       }
@@ -497,8 +573,11 @@ struct GineFArgs {
   const float* eps; const float* we; const float* be; const float* w0; const float* b0;
   const float* w1; const float* b1; float slope; const float* mask; gvp::RngArgs rng; float* out;
 };
+// Waves per workgroup of the forward kernel.  Same A/B: 4 waves (40 workgroups at davis_b64) -> drug chain alone 163 us,
+// step with both encoders 266-270 us; 8 waves (20 workgroups) -> 171 us alone, 260 us with both: fewer CUs are taken
+// away from the one-workgroup-per-CU protein backward kernels while a forward workgroup lives.
 #ifndef CGVP_GINE_FWD_WAVES
-#define CGVP_GINE_FWD_WAVES 4
+#define CGVP_GINE_FWD_WAVES 8
 #endif
 constexpr int GF_WPB = CGVP_GINE_FWD_WAVES, GF_TPB = WAVE * GF_WPB;
 
@@ -506,7 +585,8 @@ template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
 __global__ __launch_bounds__(GF_TPB) void gine_quad_fwd_kernel(GineFArgs a) {
   typedef GineQ<CIN, CHID, COUT, NT, NET, ED> Q;
   constexpr int KE = Q::KE, XW = Q::XW, CINP = Q::CINP, MI = Q::MI, MH = Q::MH, MO = Q::MO;
-  constexpr int FE = 0, F0 = FE + Q::GE::NFRAG * 64, F1 = F0 + Q::G0::NFRAG * 64, FSZ = F1 + Q::G1::NFRAG * 64;
+  constexpr int FE = 0, F0 = FE + Q::GE::NFRAG * 64, F1 = F0 + Q::G0::NFRAG * 64, VBE = F1 + Q::G1::NFRAG * 64,
+                VB0 = VBE + CINP, VB1 = VB0 + CHID, FSZ = VB1 + COUT;      // fragments, then the bias vectors (as in the backward)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* frag = lds;
   const int lane0 = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -514,6 +594,7 @@ __global__ __launch_bounds__(GF_TPB) void gine_quad_fwd_kernel(GineFArgs a) {
   stage_fragments<typename Q::GE, GF_TPB>(frag + FE, a.we);
   stage_fragments<typename Q::G0, GF_TPB>(frag + F0, a.w0);
   stage_fragments<typename Q::G1, GF_TPB>(frag + F1, a.w1);
+  stage_biases<CIN, CINP, CHID, COUT, GF_TPB>(frag + VBE, frag + VB0, frag + VB1, a.be, a.b0, a.b1);
   __syncthreads();
 
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -530,16 +611,8 @@ __global__ __launch_bounds__(GF_TPB) void gine_quad_fwd_kernel(GineFArgs a) {
     // ---- A. messages of the incoming edges, 64 at a time (see the backward kernel)
     for (int32_t c0 = e0; c0 < e1; c0 += NTL * TILE) {
       const int lane = opaque_lane(lane0), i = lane & 15, g = lane >> 4;
-      int32_t m_eid = 0, m_src = 0, m_dst = -1, m_et = 0;
-      if (c0 + lane < e1) {
-        m_eid = a.eperm[c0 + lane];
-        m_src = a.esrc[c0 + lane];
-        m_dst = a.edst[c0 + lane];
-        if (NET > 0) {
-          m_et = (int)a.etypes[m_eid];
-          m_et = m_et < 0 ? 0 : (m_et >= NET ? NET - 1 : m_et);
-        }
-      }
+      int32_t m_eid, m_src, m_dst, m_et;
+      chunk_meta<NET>(a, c0, e1, lane, m_eid, m_src, m_dst, m_et);
       int32_t c_dst[NTL];
       float c_fs[NTL][1][4];
       f4 xj[NTL][MI];
@@ -548,26 +621,7 @@ __global__ __launch_bounds__(GF_TPB) void gine_quad_fwd_kernel(GineFArgs a) {
         const int sl = 16 * t + i;
         const int32_t eid = __shfl(m_eid, sl), et = __shfl(m_et, sl), src = __shfl(m_src, sl);
         c_dst[t] = __shfl(m_dst, sl);
-        const bool active = c_dst[t] >= 0;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int idx = 4 * s + g;
-          float v = 0.f;
-          if (active) {
-            if (idx < NET) v = (et == idx) ? 1.f : 0.f;
-            else if (idx < KE) v = a.eattr[(int64_t)eid * ED + (idx - NET)];
-          }
-          c_fs[t][0][s] = v;
-        }
-#pragma unroll
-        for (int mt = 0; mt < MI; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int c = 16 * mt + 4 * g + r;
-            float v = 0.f;
-            if (active && c < CIN) v = c < NT ? (((int)a.ntypes[src] == c) ? 1.f : 0.f) : a.x[(int64_t)src * XW + (c - NT)];
-            xj[t][mt][r] = v;
-          }
+        edge_inputs<Q, CIN, NT, NET, ED, G_PIN>(a, eid, et, src, c_dst[t] >= 0, g, c_fs[t][0], xj[t]);
       }
 #pragma unroll
       for (int t = 0; t < NTL; ++t) {
@@ -575,12 +629,7 @@ __global__ __launch_bounds__(GF_TPB) void gine_quad_fwd_kernel(GineFArgs a) {
         float xs[4 * MI];
 #pragma unroll
         for (int mt = 0; mt < MI; ++mt) {
-          f4 acc[1];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int c = 16 * mt + 4 * g + r;
-            acc[0][r] = c < CIN ? a.be[c] : 0.f;
-          }
+          f4 acc[1] = {*reinterpret_cast<const f4*>(frag + VBE + 16 * mt + 4 * g)};
           apply<typename Q::GE, 1>(frag + FE, mt, c_fs[t], acc, lane);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -610,32 +659,25 @@ __global__ __launch_bounds__(GF_TPB) void gine_quad_fwd_kernel(GineFArgs a) {
       const bool valid = i < nn;
       const int64_t n = n0 + i;
       float bh[1][Q::KIn::steps];
+      f4 xi[MI];
+      node_inputs<Q, CIN, NT, G_PIN>(a, n, valid, n0, g, xi);
 #pragma unroll
       for (int mt = 0; mt < MI; ++mt) {
         const f4 ag = *reinterpret_cast<const f4*>(rows + i * CINP + 16 * mt + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = 16 * mt + 4 * g + r;
-          float v = 0.f;
-          if (valid && c < CIN) v = c < NT ? (((int)a.ntypes[n] == c) ? 1.f : 0.f) : a.x[n * XW + (c - NT)];
-          bh[0][4 * mt + r] = fmaf(eps1, v, ag[r]);
-        }
+        for (int r = 0; r < 4; ++r) bh[0][4 * mt + r] = fmaf(eps1, xi[mt][r], ag[r]);
       }
       float bt[1][Q::KHid::steps];
 #pragma unroll
       for (int mt = 0; mt < MH; ++mt) {
-        f4 acc[1];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[0][r] = a.b0[16 * mt + 4 * g + r];
+        f4 acc[1] = {*reinterpret_cast<const f4*>(frag + VB0 + 16 * mt + 4 * g)};
         apply<typename Q::G0, 1>(frag + F0, mt, bh, acc, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) bt[0][4 * mt + r] = acc[0][r] > 0.f ? acc[0][r] : acc[0][r] * a.slope;
       }
 #pragma unroll
       for (int mt = 0; mt < MO; ++mt) {
-        f4 acc[1];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[0][r] = a.b1[16 * mt + 4 * g + r];
+        f4 acc[1] = {*reinterpret_cast<const f4*>(frag + VB1 + 16 * mt + 4 * g)};
         apply<typename Q::G1, 1>(frag + F1, mt, bt, acc, lane);
         f4 y;
 #pragma unroll
@@ -661,7 +703,7 @@ int launch_fwd(GineFArgs& a, hipStream_t st) {
 #define CGVP_GINE_FWD_MAX_WGS 1024
 #endif
   const int G = (int)(wgs < 1 ? 1 : (wgs > CGVP_GINE_FWD_MAX_WGS ? CGVP_GINE_FWD_MAX_WGS : wgs));
-  const size_t lds = (size_t)((Q::GE::NFRAG + Q::G0::NFRAG + Q::G1::NFRAG) * 64 + GF_WPB * Q::ROWS) * sizeof(float);
+  const size_t lds = (size_t)((Q::GE::NFRAG + Q::G0::NFRAG + Q::G1::NFRAG) * 64 + Q::CINP + CHID + COUT + GF_WPB * Q::ROWS) * sizeof(float);
   CGVP_SET_DYN_LDS_ONCE((gine_quad_fwd_kernel<CIN, CHID, COUT, NT, NET, ED>), lds);
   hipLaunchKernelGGL((gine_quad_fwd_kernel<CIN, CHID, COUT, NT, NET, ED>), dim3(G), dim3(GF_TPB), lds, st, a);
   return 0;
