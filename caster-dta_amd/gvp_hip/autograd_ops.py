@@ -33,6 +33,7 @@ generation alive, `rng_state` re-seeds in place).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Tuple
 
 import torch
@@ -186,7 +187,7 @@ def lba_encoder_op(params: List[Tensor], x_s: Tensor, x_v: Tensor, ntypes: Tenso
             raise NotImplementedError("training / gradients need the MFMA kernels (CGVP_VARIANT=mfma)")
         return _lba_simt_inference(params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, csr, cfg)
     out, ws, masks = lba_forward(flat_arena(params), x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, csr, cfg, dropout_p,
-                                 save_state, torch.zeros)
+                                 save_state, _WS_ALLOC)
     if not save_state:
         ws = ws.new_empty(0)
     return out, ws, masks
@@ -263,6 +264,14 @@ def _(params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, csr, cfg, dropout_
     img = _image_floats_for(cfg, sdt)
     ws = x_s.new_empty((lba_fwd_ws_bytes(N, E, nc, img, 2 if sdt == torch.bfloat16 else 4, True),), dtype=torch.uint8)
     return out, ws, masks
+
+
+# The custom ops return the forward workspace (saved for the backward op), and an op's outputs must be a pure function
+# of its inputs for opcheck / compiled-vs-eager comparisons: alignment gaps, the odd-N padding row of the state blocks
+# and the rows of dropped edges are written by no kernel, so the workspace is zero-filled first.  That fill (20 MB at
+# davis_b64) costs 10 us of a 260 us captured step on this host path (measured: 0.2600 vs 0.2493 ms; the C++ eager
+# nodes allocate with empty).  CGVP_WS_EMPTY=1 trades the bitwise reproducibility of those unread bytes for the 10 us.
+_WS_ALLOC = torch.empty if os.environ.get("CGVP_WS_EMPTY") == "1" else torch.zeros
 
 
 def _image_floats_for(cfg, sdt):
@@ -470,7 +479,7 @@ def gine_encoder_op(params: List[Tensor], x: Tensor, ntypes: Tensor, eattr: Tens
     tables, dropout seed; empty when save_state is False), masks [m_0 .. m_{L-2}] (PINNED_MASKS test hook only; empty
     tensors otherwise))."""
     out, ws, masks = gine_forward(params, x, ntypes, eattr, etypes, edge_index, csr, widths, num_ntypes, num_etypes, slope,
-                                  dropout_p, save_state, torch.zeros)
+                                  dropout_p, save_state, _WS_ALLOC)
     if not save_state:
         return out, ws.new_empty(0), []
     # what the op hands on is the part the backward reads: the scratch behind it holds edge ids in arrival order
