@@ -37,6 +37,21 @@ __device__ __forceinline__ int opaque_lane(int lane) {     // see gvp_quad_bwd_k
 }
 
 // P1 slots over W (a multiple of 16) channels of which only the first VALID exist.
+#ifdef CGVP_STAMPS     // diagnostic build only (tools/stamp_gine_bwd.py): s_memtime at phase boundaries, one row of 16 per wave
+__device__ unsigned long long* g_stamp_buf_gine = nullptr;
+#define GSTAMP(slot)                                                                         \
+  do {                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    unsigned long long t_;                                                                   \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    if (g_stamp_buf_gine && (threadIdx.x & 63) == 0)                                         \
+      g_stamp_buf_gine[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (slot)] = t_;   \
+  } while (0)
+#else
+#define GSTAMP(slot) do {} while (0)
+#endif
+
 template <int W, int VALID>
 struct SegClip {
   static_assert(W % 16 == 0, "whole 16-channel tiles");
@@ -277,7 +292,9 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
   stage_fragments<typename Q::G1T, GQ_TPB>(frag + Q::F_1T, a.w1);
   stage_biases<CIN, CINP, CHID, COUT, GQ_TPB>(frag + Q::V_BE, frag + Q::V_B0, frag + Q::V_B1, a.be, a.b0, a.b1);
   for (int k = lane0; k < Q::BLK / 4; k += WAVE) reinterpret_cast<f4*>(blk)[k] = f4{0.f, 0.f, 0.f, 0.f};
+  GSTAMP(0);
   __syncthreads();
+  GSTAMP(1);
 
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
   const float eps1 = 1.0f + a.eps[0];
@@ -338,7 +355,9 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
     for (int32_t c0 = e0; c0 < e1; c0 += NTL * TILE) {
       const int lane = opaque_lane(lane0), i = lane & 15, g = lane >> 4;
       f4 xj[NTL][MI];
+      GSTAMP(8);
       load_chunk(c0, lane, xj);
+      GSTAMP(9);
 #pragma unroll
       for (int t = 0; t < NTL; ++t) {
         if (c0 + t * TILE >= e1) break;
@@ -366,6 +385,7 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
       }
     }
 
+    GSTAMP(2);
     // ---- B. the MLP of the 16 atoms, forward and backward
     {
       const int lane = opaque_lane(lane0), i = lane & 15, g = lane >> 4;
@@ -426,6 +446,7 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
         apply<typename Q::G0T, 1>(frag + Q::F_0T, mt, bdt, acc, lane);
         dh[mt] = acc[0];
       }
+      GSTAMP(3);
       // ---- weight gradients of the two Linear layers
       {
         f4 AT[MO], BT[MH];
@@ -474,6 +495,7 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
           add_where<AccPriv, 4>(q, on, tot);
         }
       }
+      GSTAMP(4);
       // ---- d eps, d x (self term), and dh rows for the edge phase
 #pragma unroll
       for (int mt = 0; mt < MI; ++mt) {
@@ -490,6 +512,7 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 
+    GSTAMP(5);
     // ---- C. edges again: d message -> sources, lin weight gradients
     for (int32_t c0 = e0; c0 < e1; c0 += NTL * TILE) {
       const int lane = opaque_lane(lane0), i = lane & 15, g = lane >> 4;
@@ -550,6 +573,7 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
+  GSTAMP(6);
   // d eps: sum over the lanes of the wave, into the private block
   for (int off = 32; off > 0; off >>= 1) acc_eps += __shfl_down(acc_eps, off);
   if (lane0 == 0) blk[Q::L_EPS] += acc_eps;
@@ -562,6 +586,7 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
     for (int ww = 0; ww < GQ_WPB; ++ww) s += blocks[ww * Q::BLK + k];
     out[k] = s;
   }
+  GSTAMP(7);
 }
 
 // ---------------------------------------------------------------- forward on the same tiles
@@ -760,3 +785,9 @@ int gine_fwd(int cin, int chid, int cout, int nt, int net, int ed, const float* 
 }
 
 }  // namespace quad
+
+#ifdef CGVP_STAMPS
+extern "C" int cgvp_debug_set_stamp_buffer_gine(unsigned long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf_gine), &buf, sizeof(buf));
+}
+#endif
