@@ -259,3 +259,38 @@ def test_empty_graph_and_isolated_nodes():
     finally:
         K.ENABLED = True
     assert float((out[0] - ref[0]).detach().abs().max()) < 1e-5 and float((out[1] - ref[1]).detach().abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("kind", list(KINDS))
+def test_rotation_equivariance_at_full_batch_size(kind):
+    """Size-independent property at the headline batch size (19,200 nodes, ~57k edges): scalar outputs are invariant and
+    vector outputs co-rotate when every input vector is rotated -- for each layer kind on the kernels, forward and the
+    gradient w.r.t. the node vectors (which must co-rotate too)."""
+    import davis_synth as ds
+    layer = _layer(kind, 32).eval()
+    pb = ds.protein_batch(64, 3)
+    ei = torch.from_numpy(pb.edge_index).to(DEV)
+    n, e = pb.num_nodes, ei.shape[1]
+    assert n == 19200 and e > 50000
+    x, ea, r = _feats(n, (16, 4), 61), _feats(e, (32, 1), 62), _feats(n, (16, 4), 63)
+    g = torch.Generator().manual_seed(7)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    R = q.to(DEV)
+    rot = lambda t: (t[0], t[1] @ R.T)
+
+    def run(xin, ein, rin):
+        xs, xv = xin[0].clone().requires_grad_(), xin[1].clone().requires_grad_()
+        out = layer((xs, xv), ei, ein)
+        ((out[0] * rin[0]).sum() + (out[1] * rin[1]).sum()).backward()
+        return out[0].detach(), out[1].detach(), xs.grad, xv.grad
+
+    s0, v0, gs0, gv0 = run(x, ea, r)
+    s1, v1, gs1, gv1 = run(rot(x), rot(ea), rot(r))
+    tol = lambda ref: 5e-5 * float(ref.abs().max())
+    assert float((s1 - s0).abs().max()) <= tol(s0)
+    assert float((v1 - v0 @ R.T).abs().max()) <= tol(v0)
+    assert float((gs1 - gs0).abs().max()) <= tol(gs0) * 4
+    assert float((gv1 - gv0 @ R.T).abs().max()) <= tol(gv0) * 4
+    assert float(v0.abs().max()) > 0 and not torch.allclose(v1, v0, atol=1e-3)
