@@ -406,7 +406,8 @@ class CrossAttentionModule(nn.Module):
         core of both directions is one launch of caster_gvp::cross_attention; projections and feed-forward are
         GEMMs on the compact rows.  Returns (embed_1, embed_2, (w1, w2) or None)."""
         from gvp_hip import attention_ops  # noqa: F401  (registers the ops)
-        n1, n2 = self.preattn_norm1(embed_1), self.preattn_norm2(embed_2)
+        from gvp_hip.head_ops import fast_layer_norm      # nn.LayerNorm on compact rows: one-pass kernels each way
+        n1, n2 = fast_layer_norm(embed_1, self.preattn_norm1), fast_layer_norm(embed_2, self.preattn_norm2)
         q1, k1, v1 = self._qkv(self.embed1_to_2, n1, n2)
         q2, k2, v2 = self._qkv(self.embed2_to_1, n2, n1)
         heads = self.embed1_to_2.num_heads
@@ -425,9 +426,9 @@ class CrossAttentionModule(nn.Module):
             def ff(seq, t):          # nn.Sequential(Linear, ReLU, Dropout, Linear) with the row-wise Linear layers on fast_linear
                 return fast_linear(seq[2](seq[1](fast_linear(t, seq[0].weight, seq[0].bias))), seq[3].weight, seq[3].bias)
             embed_1 = embed_1 + self.ff_dropout(a1)
-            embed_1 = embed_1 + self.ff_dropout(ff(self.ff1, self.ff_norm1(embed_1)))
+            embed_1 = embed_1 + self.ff_dropout(ff(self.ff1, fast_layer_norm(embed_1, self.ff_norm1)))
             embed_2 = embed_2 + self.ff_dropout(a2)
-            embed_2 = embed_2 + self.ff_dropout(ff(self.ff2, self.ff_norm2(embed_2)))
+            embed_2 = embed_2 + self.ff_dropout(ff(self.ff2, fast_layer_norm(embed_2, self.ff_norm2)))
         else:
             embed_1, embed_2 = a1, a2
         return embed_1, embed_2, weights

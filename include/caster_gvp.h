@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 26
+#define CGVP_ABI_VERSION 27
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
@@ -548,6 +548,17 @@ int cgvp_gine_backward_pass(const cgvp_gine_cfg* cfg, const cgvp_gine_w* w, cons
  * cgvp_linear_wgrad_workspace_floats(R, I, O) floats (per-split partial sums; < 0 = unsupported shape).
  * I a multiple of 16 up to 256, O a multiple of 64.  Two launches (split-row MFMA kernel, fixed-order reduce):
  * deterministic, exact fp32. */
+/* Row-wise nn.LayerNorm of the joint head (joint_gnn.py:376-389, the pre-attention and feed-forward norms on compact
+ * residue / atom rows): y = (x - mean) * rstd * gamma + beta per row of `dim` floats (dim in {64, 128, 256, 512}), biased
+ * variance, rstd = 1 / sqrt(var + eps); mean / rstd [rows] are saved for the backward.  gamma / beta may be NULL
+ * (elementwise_affine=False).  Backward: gx [rows][dim], g_gamma_beta [2 * dim] = [d gamma | d beta] (STORED; per-workgroup
+ * partials in `workspace` of cgvp_layer_norm_bwd_workspace_floats() floats are added in a fixed order). */
+int cgvp_layer_norm_fwd(const float* x, const float* gamma, const float* beta, int64_t rows, int32_t dim, float eps,
+                        float* y, float* mean, float* rstd, void* stream);
+int64_t cgvp_layer_norm_bwd_workspace_floats(int64_t rows, int32_t dim);
+int cgvp_layer_norm_bwd(const float* gy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                        int64_t rows, int32_t dim, float* gx, float* workspace, float* g_gamma_beta, void* stream);
+
 int64_t cgvp_linear_wgrad_workspace_floats(int64_t num_rows, int32_t in_features, int32_t out_features);
 int cgvp_linear_wgrad(const float* x, const float* gy, int64_t num_rows, int32_t in_features, int32_t out_features,
                       float* workspace, float* out, void* stream);

@@ -199,3 +199,57 @@ def test_fast_linear_is_f_linear_with_the_same_gradients():
     assert rel_err(gw, hw) < 1e-5 and rel_err(gb, hb) < 1e-5
     assert not head_ops.supported(x[:100], lin.weight, lin.bias)            # few rows: the library GEMM
     assert not head_ops.supported(x, torch.nn.Linear(128, 100).to(DEV).weight, lin.bias)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,dim", [(19200, 128), (2560, 128), (777, 256), (300, 64), (1025, 512)])
+def test_layer_norm_kernels_vs_torch(rows, dim):
+    """caster_gvp::layer_norm (csrc/norm_kernels.hip) against F.layer_norm in fp64 -- and no further from it than torch's
+    own fp32 kernels are: output, d x, d gamma, d beta; bitwise reproducible (fixed-order reduction)."""
+    from gvp_hip import head_ops
+    g = torch.Generator(device=DEV).manual_seed(rows + dim)
+    x = (torch.randn(rows, dim, device=DEV, generator=g) * 2.0 + 0.5)
+    w = torch.randn(dim, device=DEV, generator=g) * 0.3 + 1.0
+    b = torch.randn(dim, device=DEV, generator=g) * 0.1
+    r = torch.randn(rows, dim, device=DEV, generator=g)
+    norm = torch.nn.LayerNorm(dim).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(w)
+        norm.bias.copy_(b)
+
+    def run(fn, dtype=torch.float32):
+        xx = x.to(dtype).clone().requires_grad_()
+        m = norm if dtype == torch.float32 else torch.nn.LayerNorm(dim).to(DEV).double()
+        if dtype != torch.float32:
+            with torch.no_grad():
+                m.weight.copy_(w.double())
+                m.bias.copy_(b.double())
+        m.zero_grad(set_to_none=True)
+        y = fn(xx, m)
+        (y * r.to(dtype)).sum().backward()
+        return y.detach(), xx.grad, m.weight.grad.clone(), m.bias.grad.clone()
+
+    ref = run(lambda t, m: m(t), torch.float64)
+    stock = run(lambda t, m: m(t))
+    ours = run(head_ops.fast_layer_norm)
+    again = run(head_ops.fast_layer_norm)
+    for a, b_ in zip(ours, again):
+        assert torch.equal(a, b_)
+    for k, (o, s, f) in enumerate(zip(ours, stock, ref)):
+        scale = float(f.abs().max())
+        e_ours, e_stock = float((o.double() - f).abs().max()), float((s.double() - f).abs().max())
+        assert e_ours <= max(2.0 * e_stock, 2e-6 * scale), (k, e_ours, e_stock, scale)
+
+
+@pytest.mark.gpu
+def test_fast_layer_norm_falls_back_outside_its_shapes():
+    from gvp_hip import head_ops
+    for shape, dim in (((100, 128), 128), ((4000, 96), 96), ((8, 300, 128), 128)):
+        norm = torch.nn.LayerNorm(dim).to(DEV)
+        x = torch.randn(*shape, device=DEV)
+        assert torch.allclose(head_ops.fast_layer_norm(x, norm), norm(x), atol=1e-6)
+    norm = torch.nn.LayerNorm(128, elementwise_affine=False).to(DEV)
+    x = torch.randn(5000, 128, device=DEV)
+    assert torch.allclose(head_ops.fast_layer_norm(x, norm), norm(x), atol=1e-6)
+    ident = torch.nn.Identity()
+    assert head_ops.fast_layer_norm(x, ident) is x
