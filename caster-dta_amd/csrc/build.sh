@@ -11,6 +11,7 @@ SRCS=(gvp_kernels gvp_quad_kernels gvp_quad_bwd_kernels gine_quad_kernels pass_a
 [ -f "$HERE/feat_kernels.hip" ] && SRCS+=(feat_kernels)
 [ -f "$HERE/linear_kernels.hip" ] && SRCS+=(linear_kernels)
 [ -f "$HERE/norm_kernels.hip" ] && SRCS+=(norm_kernels)
+[ -f "$HERE/elementwise_kernels.hip" ] && SRCS+=(elementwise_kernels)
 pids=()
 for s in "${SRCS[@]}"; do
   ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -o "$TMP/$s.o" "$HERE/$s.hip" \

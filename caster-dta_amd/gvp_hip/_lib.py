@@ -15,11 +15,11 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CGVP_LIB_PATH: A/B builds of the same ABI (diagnostics); the default is the in-tree library
 LIB_PATH = os.environ.get("CGVP_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libcaster_gvp.so")
-ABI_VERSION = 27
+ABI_VERSION = 28
 # sha256 of include/caster_gvp.h with comments, blank space and the CGVP_ABI_VERSION line removed, as
 # `abi_header_digest()` computes it.  tests/test_abi.py fails when the header's declarations change
 # without CGVP_ABI_VERSION, ABI_VERSION and this digest being updated together.
-ABI_HEADER_SHA256 = "307916fa14205bab7d28eccb065abfa9c1d2e3553be3b777f6a773fb7ad9617e"
+ABI_HEADER_SHA256 = "1eed80772966b9bacdc7fe690477bba4b8e1ada1e5b03f566031727b31e48534"
 
 
 class HipLibraryError(RuntimeError):
@@ -157,6 +157,10 @@ _SIGNATURES = {
     "cgvp_layer_norm_fwd": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_float, _P, _P, _P, _P]),
     "cgvp_layer_norm_bwd_workspace_floats": (C.c_int64, [_I64, _I32]),
     "cgvp_layer_norm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P]),
+    "cgvp_dropout_add": (C.c_int, [_P, _P, C.POINTER(Rng), _I64, _I32, _P, _P]),
+    "cgvp_dropout_scale": (C.c_int, [_P, C.POINTER(Rng), _I64, _I32, _P, _P]),
+    "cgvp_act_dropout_fwd": (C.c_int, [_P, C.POINTER(Rng), C.c_float, _I64, _I32, _P, _P]),
+    "cgvp_act_dropout_bwd": (C.c_int, [_P, _P, C.POINTER(Rng), C.c_float, _I64, _I32, _P, _P]),
     "cgvp_stage_buffers": (C.c_int, [C.POINTER(StageItem), _I32, _P]),
     "cgvp_debug_kernel_timing": (C.c_int, [_I32]),
     "cgvp_debug_kernel_times": (C.c_int, [_P, _P, _I32]),

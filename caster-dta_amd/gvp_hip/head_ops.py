@@ -154,3 +154,191 @@ def fast_layer_norm(x, norm):
             and norm.weight.dtype == torch.float32 and x.shape[0] >= LN_MIN_ROWS):
         return torch.ops.caster_gvp.layer_norm(x, norm.weight, norm.bias, float(norm.eps))[0]
     return norm(x)
+
+
+# ------------------------------------------------------------------------------------------------ fused dropout sites
+# `x + dropout(a)` and `dropout(act(t))` of the head as ONE launch each way (csrc/elementwise_kernels.hip), masks
+# regenerated from a per-step {seed, offset} pair instead of stored.  Eager / captured-graph training in fp32 only: under
+# torch.compile Inductor fuses the stock ops itself, under autocast the rows are not fp32 -- both keep the torch ops.
+from .ops import Rng
+
+_HEAD_RNG = {}          # device index -> [generator seed it was drawn from, persistent int64[2] {seed, offset}]
+
+
+def _head_rng_state(device):
+    """Persistent device-side generator state of the head's fused dropout sites (never replaced: captured graphs keep
+    its address; re-seeded in place after torch.manual_seed)."""
+    from . import autograd_ops
+    gen_seed = torch.cuda.default_generators[device.index].initial_seed()
+    hit = _HEAD_RNG.get(device.index)
+    if hit is None or hit[0] != gen_seed:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the dropout generator state must exist before HIP-graph capture: run one training step "
+                               "eagerly first (any warm-up does)")
+        seed = autograd_ops.draw_seed(device)
+        if hit is None:
+            _HEAD_RNG[device.index] = hit = [gen_seed, seed]
+        else:
+            hit[1].copy_(seed)
+            hit[0] = gen_seed
+    return hit[1]
+
+
+@torch.library.custom_op("caster_gvp::rng_next", mutates_args=("state",), device_types="cuda")
+def rng_next_op(state: Tensor) -> Tensor:
+    """Advance the persistent {seed, offset} state by one step and return this step's pair (int64[2])."""
+    out = torch.empty(2, dtype=torch.int64, device=state.device)
+    with torch.cuda.device(state.device):
+        _lib.check(_lib.lib().cgvp_rng_next(_ptr(state), _ptr(out), _stream()), "cgvp_rng_next")
+    return out
+
+
+@rng_next_op.register_fake
+def _(state):
+    return state.new_empty((2,))
+
+
+def _rng(pair, p, site):
+    return C.byref(Rng(pair.data_ptr(), float(p), int(site))) if p > 0 else None
+
+
+def _rows(t):
+    return int(t.numel() // t.shape[-1]), int(t.shape[-1])
+
+
+@torch.library.custom_op("caster_gvp::dropout_add", mutates_args=(), device_types="cuda")
+def dropout_add_op(a: Tensor, x: Tensor, pair: Tensor, site: int, p: float) -> Tensor:
+    """x + dropout_p(a); an empty `x` means dropout_p(a) alone."""
+    a = _f32(a, "a")
+    x = _f32(x, "x") if x.numel() else None
+    R, D = _rows(a)
+    y = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.lib().cgvp_dropout_add(_ptr(a), _ptr(x), _rng(pair, p, site), R, D, _ptr(y), _stream()), "cgvp_dropout_add")
+    return y
+
+
+@dropout_add_op.register_fake
+def _(a, x, pair, site, p):
+    return torch.empty_like(a)
+
+
+@torch.library.custom_op("caster_gvp::dropout_scale", mutates_args=(), device_types="cuda")
+def dropout_scale_op(g: Tensor, pair: Tensor, site: int, p: float) -> Tensor:
+    g = _f32(g, "grad_output")
+    R, D = _rows(g)
+    out = torch.empty_like(g)
+    with torch.cuda.device(g.device):
+        _lib.check(_lib.lib().cgvp_dropout_scale(_ptr(g), _rng(pair, p, site), R, D, _ptr(out), _stream()), "cgvp_dropout_scale")
+    return out
+
+
+@dropout_scale_op.register_fake
+def _(g, pair, site, p):
+    return torch.empty_like(g)
+
+
+def _da_setup(ctx, inputs, output):
+    a, x, pair, site, p = inputs
+    ctx.save_for_backward(pair)
+    ctx.site, ctx.p, ctx.has_x = site, p, bool(x.numel())
+
+
+def _da_backward(ctx, g):
+    (pair,) = ctx.saved_tensors
+    ga = torch.ops.caster_gvp.dropout_scale(g.contiguous(), pair, ctx.site, ctx.p) if ctx.needs_input_grad[0] else None
+    return ga, (g if (ctx.has_x and ctx.needs_input_grad[1]) else None), None, None, None
+
+
+torch.library.register_autograd("caster_gvp::dropout_add", _da_backward, setup_context=_da_setup)
+
+
+@torch.library.custom_op("caster_gvp::act_dropout", mutates_args=(), device_types="cuda")
+def act_dropout_op(t: Tensor, pair: Tensor, site: int, p: float, slope: float) -> Tensor:
+    """dropout_p(LeakyReLU_slope(t)); slope 0 = ReLU."""
+    t = _f32(t, "t")
+    R, D = _rows(t)
+    y = torch.empty_like(t)
+    with torch.cuda.device(t.device):
+        _lib.check(_lib.lib().cgvp_act_dropout_fwd(_ptr(t), _rng(pair, p, site), float(slope), R, D, _ptr(y), _stream()),
+                   "cgvp_act_dropout_fwd")
+    return y
+
+
+@act_dropout_op.register_fake
+def _(t, pair, site, p, slope):
+    return torch.empty_like(t)
+
+
+@torch.library.custom_op("caster_gvp::act_dropout_backward", mutates_args=(), device_types="cuda")
+def act_dropout_backward_op(g: Tensor, y: Tensor, pair: Tensor, site: int, p: float, slope: float) -> Tensor:
+    g, y = _f32(g, "grad_output"), _f32(y, "y")
+    R, D = _rows(g)
+    gt = torch.empty_like(g)
+    with torch.cuda.device(g.device):
+        _lib.check(_lib.lib().cgvp_act_dropout_bwd(_ptr(g), _ptr(y), _rng(pair, p, site), float(slope), R, D, _ptr(gt), _stream()),
+                   "cgvp_act_dropout_bwd")
+    return gt
+
+
+@act_dropout_backward_op.register_fake
+def _(g, y, pair, site, p, slope):
+    return torch.empty_like(g)
+
+
+def _ad_setup(ctx, inputs, output):
+    t, pair, site, p, slope = inputs
+    ctx.save_for_backward(output, pair)
+    ctx.site, ctx.p, ctx.slope = site, p, slope
+
+
+def _ad_backward(ctx, g):
+    y, pair = ctx.saved_tensors
+    return torch.ops.caster_gvp.act_dropout_backward(g.contiguous(), y, pair, ctx.site, ctx.p, ctx.slope), None, None, None, None
+
+
+torch.library.register_autograd("caster_gvp::act_dropout", _ad_backward, setup_context=_ad_setup)
+
+
+class DropSites:
+    """The fused dropout sites of ONE training forward of the head: one generator advance per step (`pair`), a fresh
+    stream id per call site (call order is the same every step, so a site keeps its id).  `active` is False in eval
+    mode, with p = 0, under torch.compile / autocast or off the GPU -- the callers then use the stock ops."""
+
+    def __init__(self, rows, training, p):
+        self.p = float(p)
+        self.active = bool(training and p > 0 and rows.is_cuda and rows.dtype == torch.float32
+                           and not torch.compiler.is_compiling() and not torch.is_autocast_enabled("cuda")
+                           and torch.is_grad_enabled())
+        self.site = 0
+        self.pair = torch.ops.caster_gvp.rng_next(_head_rng_state(rows.device)) if self.active else None
+        self._none = rows.new_empty(0) if self.active else None
+
+    def _ok(self, t):
+        return self.active and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] % 8 == 0 \
+            and t.is_contiguous() and t.data_ptr() % 16 == 0
+
+    def _next(self):
+        self.site += 1
+        return self.site
+
+    def dropout_add(self, x, a, dropout):
+        """x + dropout(a)."""
+        if self._ok(a) and self._ok(x) and abs(dropout.p - self.p) < 1e-12:
+            return torch.ops.caster_gvp.dropout_add(a, x, self.pair, self._next(), self.p)
+        return x + dropout(a)
+
+    def act_dropout(self, t, activation, dropout):
+        """dropout(activation(t)) for ReLU / LeakyReLU activations."""
+        slope = _slope(activation)
+        if slope is not None and self._ok(t) and abs(dropout.p - self.p) < 1e-12:
+            return torch.ops.caster_gvp.act_dropout(t, self.pair, self._next(), self.p, slope)
+        return dropout(activation(t))
+
+
+def _slope(activation):
+    if isinstance(activation, torch.nn.ReLU) or activation is torch.relu or activation is torch.nn.functional.relu:
+        return 0.0
+    if isinstance(activation, torch.nn.LeakyReLU):
+        return float(activation.negative_slope)
+    return None

@@ -208,10 +208,12 @@ class JointGNN(nn.Module):
             return d
         return as_dict(protein_graph), as_dict(molecule_graph)
 
-    def _stack(self, t, lins, norms):
+    def _stack(self, t, lins, norms, sites=None):
         from gvp_hip.head_ops import fast_linear      # F.linear; weight gradients of the per-row layers by the split-row kernel
         for lin, norm in zip(lins, norms):
-            t = self.dropout(self.activation(norm(fast_linear(t, lin.weight, lin.bias))))
+            t = norm(fast_linear(t, lin.weight, lin.bias))
+            # activation + dropout: one launch each way on the big compact-row stacks (gvp_hip.head_ops.DropSites)
+            t = sites.act_dropout(t, self.activation, self.dropout) if sites is not None else self.dropout(self.activation(t))
         return t
 
     def _pool(self, dense, mask):
@@ -268,8 +270,10 @@ class JointGNN(nn.Module):
             residue = residue.to(hdt)
         if atom.dtype != hdt and not torch.is_autocast_enabled():
             atom = atom.to(hdt)
-        residue = self._stack(residue, self.residue_lins, self.residue_norms)
-        atom = self._stack(atom, self.atom_lins, self.atom_norms)
+        from gvp_hip.head_ops import DropSites
+        sites = DropSites(residue, self.training, self.dropout.p)     # fused dropout sites of this forward (eager fp32 training)
+        residue = self._stack(residue, self.residue_lins, self.residue_norms, sites)
+        atom = self._stack(atom, self.atom_lins, self.atom_norms, sites)
         attn = None
         if self.cross_attn_module is None or self.cross_attn_module.varlen_supported(residue):
             # compact rows end to end: varlen cross attention (one launch for both directions) + segment pooling
@@ -279,7 +283,7 @@ class JointGNN(nn.Module):
                 raise ValueError("protein and molecule batches hold different numbers of graphs")
             if self.cross_attn_module is not None:
                 want = self.attention_weights == "always" or (self.attention_weights == "auto" and not self.training)
-                residue, atom, attn = self.cross_attn_module.forward_varlen(residue, atom, rptr, aptr, want)
+                residue, atom, attn = self.cross_attn_module.forward_varlen(residue, atom, rptr, aptr, want, sites)
             protein, molecule = self._pool_rows(residue, pbatch, rptr), self._pool_rows(atom, mbatch, aptr)
         else:
             # the reference's dense formulation (head shapes the varlen kernel is not compiled for)
@@ -289,15 +293,15 @@ class JointGNN(nn.Module):
             protein, molecule = self._pool(residue, rmask), self._pool(atom, amask)
         if self.include_post_pool_layernorm:
             protein, molecule = self.protein_post_pool_norm(protein), self.molecule_post_pool_norm(molecule)
-        protein = self.dropout(self.activation(protein))
-        molecule = self.dropout(self.activation(molecule))
-        protein = self._stack(protein, self.protein_lins, self.protein_norms)
-        molecule = self._stack(molecule, self.molecule_lins, self.molecule_norms)
+        protein = sites.act_dropout(protein, self.activation, self.dropout)
+        molecule = sites.act_dropout(molecule, self.activation, self.dropout)
+        protein = self._stack(protein, self.protein_lins, self.protein_norms, sites)
+        molecule = self._stack(molecule, self.molecule_lins, self.molecule_norms, sites)
         pair = torch.cat([protein, molecule], dim=-1)
         if self._pair_parallel:
             pair = self._gather_pairs(pair)
-        z = self.dropout(self.activation(self.pm_embed_lin(pair)))
-        z = self._stack(z, self.out_fc_layers, self.out_fc_norms)
+        z = sites.act_dropout(self.pm_embed_lin(pair), self.activation, self.dropout)
+        z = self._stack(z, self.out_fc_layers, self.out_fc_norms, sites)
         return self.output_layer(z), attn
 
     @staticmethod
@@ -400,7 +404,7 @@ class CrossAttentionModule(nn.Module):
             wq, wk, wv = mha.q_proj_weight, mha.k_proj_weight, mha.v_proj_weight
         return fast_linear(x_q, wq, bq), fast_linear(x_kv, wk, bk), fast_linear(x_kv, wv, bv)
 
-    def forward_varlen(self, embed_1, embed_2, ptr1, ptr2, need_weights=False):
+    def forward_varlen(self, embed_1, embed_2, ptr1, ptr2, need_weights=False, sites=None):
         """`forward` on compact rows: embed_1 [N1, D] with graph offsets ptr1, embed_2 [N2, D] with ptr2; every
         graph b of side 1 attends to graph b of side 2 and vice versa (joint_gnn.py:376-398).  The softmax(QK^T)V
         core of both directions is one launch of caster_gvp::cross_attention; projections and feed-forward are
@@ -423,12 +427,16 @@ class CrossAttentionModule(nn.Module):
                                                                          q2.detach(), k2.detach(), lse2.detach(),
                                                                          ptr1, ptr2, heads, l1, l2))
         if self.include_residual_stream:
+            if sites is None:
+                from gvp_hip.head_ops import DropSites
+                sites = DropSites(embed_1, False, 0.0)          # inactive: the stock ops
             def ff(seq, t):          # nn.Sequential(Linear, ReLU, Dropout, Linear) with the row-wise Linear layers on fast_linear
-                return fast_linear(seq[2](seq[1](fast_linear(t, seq[0].weight, seq[0].bias))), seq[3].weight, seq[3].bias)
-            embed_1 = embed_1 + self.ff_dropout(a1)
-            embed_1 = embed_1 + self.ff_dropout(ff(self.ff1, fast_layer_norm(embed_1, self.ff_norm1)))
-            embed_2 = embed_2 + self.ff_dropout(a2)
-            embed_2 = embed_2 + self.ff_dropout(ff(self.ff2, fast_layer_norm(embed_2, self.ff_norm2)))
+                h = sites.act_dropout(fast_linear(t, seq[0].weight, seq[0].bias), seq[1], seq[2])
+                return fast_linear(h, seq[3].weight, seq[3].bias)
+            embed_1 = sites.dropout_add(embed_1, a1, self.ff_dropout)
+            embed_1 = sites.dropout_add(embed_1, ff(self.ff1, fast_layer_norm(embed_1, self.ff_norm1)), self.ff_dropout)
+            embed_2 = sites.dropout_add(embed_2, a2, self.ff_dropout)
+            embed_2 = sites.dropout_add(embed_2, ff(self.ff2, fast_layer_norm(embed_2, self.ff_norm2)), self.ff_dropout)
         else:
             embed_1, embed_2 = a1, a2
         return embed_1, embed_2, weights
@@ -455,10 +463,10 @@ class StackedCrossAttentionModule(nn.Module):
     def varlen_supported(self, rows):
         return all(layer.varlen_supported(rows) for layer in self.cross_attn_layers)
 
-    def forward_varlen(self, embed_1, embed_2, ptr1, ptr2, need_weights=False):
+    def forward_varlen(self, embed_1, embed_2, ptr1, ptr2, need_weights=False, sites=None):
         weights = []
         for layer in self.cross_attn_layers:
-            embed_1, embed_2, w = layer.forward_varlen(embed_1, embed_2, ptr1, ptr2, need_weights)
+            embed_1, embed_2, w = layer.forward_varlen(embed_1, embed_2, ptr1, ptr2, need_weights, sites)
             weights.append(w)
         return embed_1, embed_2, (weights if need_weights else None)
 

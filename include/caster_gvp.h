@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 27
+#define CGVP_ABI_VERSION 28
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
@@ -558,6 +558,20 @@ int cgvp_layer_norm_fwd(const float* x, const float* gamma, const float* beta, i
 int64_t cgvp_layer_norm_bwd_workspace_floats(int64_t rows, int32_t dim);
 int cgvp_layer_norm_bwd(const float* gy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         int64_t rows, int32_t dim, float* gx, float* workspace, float* g_gamma_beta, void* stream);
+
+/* The dropout sites of the joint head fused with their neighbours (joint_gnn.py:188-198, :376-389), on compact fp32
+ * rows [rows][dim] (dim a multiple of 8, 16-B aligned buffers):
+ *   cgvp_dropout_add      y = x + a * f   (x may be NULL: y = a * f)     residual + nn.Dropout
+ *   cgvp_dropout_scale    out = g * f                                    its backward w.r.t. a (d x = g)
+ *   cgvp_act_dropout_fwd  y = LeakyReLU_slope(t) * f  (slope 0: ReLU)    activation + nn.Dropout
+ *   cgvp_act_dropout_bwd  gt = g * f * (y > 0 ? 1 : slope)               from the saved OUTPUT y
+ * f = inverted-dropout factor of (row, column) regenerated from `rng` ({seed, offset} pair on the device, p, stream id =
+ * the call site; rng NULL or p = 0: f = 1); same generator as the encoders' in-kernel dropout (cgvp_rng above). */
+int cgvp_dropout_add(const float* a, const float* x, const cgvp_rng* rng, int64_t rows, int32_t dim, float* y, void* stream);
+int cgvp_dropout_scale(const float* g, const cgvp_rng* rng, int64_t rows, int32_t dim, float* out, void* stream);
+int cgvp_act_dropout_fwd(const float* t, const cgvp_rng* rng, float slope, int64_t rows, int32_t dim, float* y, void* stream);
+int cgvp_act_dropout_bwd(const float* g, const float* y, const cgvp_rng* rng, float slope, int64_t rows, int32_t dim, float* gt,
+                         void* stream);
 
 int64_t cgvp_linear_wgrad_workspace_floats(int64_t num_rows, int32_t in_features, int32_t out_features);
 int cgvp_linear_wgrad(const float* x, const float* gy, int64_t num_rows, int32_t in_features, int32_t out_features,

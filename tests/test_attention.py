@@ -253,3 +253,44 @@ def test_fast_layer_norm_falls_back_outside_its_shapes():
     assert torch.allclose(head_ops.fast_layer_norm(x, norm), norm(x), atol=1e-6)
     ident = torch.nn.Identity()
     assert head_ops.fast_layer_norm(x, ident) is x
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,dim,p", [(19200, 128, 0.1), (2560, 256, 0.25), (64, 512, 0.5), (333, 8, 0.1)])
+def test_fused_dropout_sites_vs_stock_ops_with_the_same_mask(rows, dim, p):
+    """caster_gvp::dropout_add / act_dropout (csrc/elementwise_kernels.hip): the factor tensor a site used is read back
+    through the op itself (a = 1, x absent), then outputs and gradients are compared with the stock ops under that mask;
+    factors are 0 or 1/(1-p) at the right rate, differ between sites and between steps, and the backward regenerates
+    exactly the forward's mask."""
+    from gvp_hip import head_ops
+    dev = torch.device(DEV)
+    state = head_ops._head_rng_state(dev)
+    pair = torch.ops.caster_gvp.rng_next(state)
+    pair2 = torch.ops.caster_gvp.rng_next(state)
+    assert int(pair2[1]) == int(pair[1]) + 1 and int(pair2[0]) == int(pair[0])
+    none = torch.empty(0, device=DEV)
+    ones = torch.ones(rows, dim, device=DEV)
+    mask = torch.ops.caster_gvp.dropout_add(ones, none, pair, 3, p)
+    vals = torch.unique(mask)
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1 / (1 - p)) < 1e-6
+    assert abs(float((mask == 0).float().mean()) - p) < max(0.02, 3.0 / (rows * dim) ** 0.5)
+    assert not torch.equal(mask, torch.ops.caster_gvp.dropout_add(ones, none, pair, 4, p))       # another site
+    assert not torch.equal(mask, torch.ops.caster_gvp.dropout_add(ones, none, pair2, 3, p))      # the next step
+    assert torch.equal(mask, torch.ops.caster_gvp.dropout_add(ones, none, pair, 3, p))           # a pure function
+    g = torch.Generator(device=DEV).manual_seed(rows)
+    a = torch.randn(rows, dim, device=DEV, generator=g, requires_grad=True)
+    x = torch.randn(rows, dim, device=DEV, generator=g, requires_grad=True)
+    r = torch.randn(rows, dim, device=DEV, generator=g)
+    y = torch.ops.caster_gvp.dropout_add(a, x, pair, 3, p)
+    ga, gx = torch.autograd.grad((y * r).sum(), [a, x])
+    assert torch.allclose(y, x + a * mask, atol=1e-6) and torch.equal(gx, r) and torch.allclose(ga, r * mask, atol=1e-6)
+    for slope in (0.0, 0.01):
+        t = torch.randn(rows, dim, device=DEV, generator=g, requires_grad=True)
+        y = torch.ops.caster_gvp.act_dropout(t, pair, 3, p, slope)
+        (gt,) = torch.autograd.grad((y * r).sum(), [t])
+        t2 = t.detach().clone().requires_grad_()
+        y2 = torch.nn.functional.leaky_relu(t2, slope) * mask
+        (gt2,) = torch.autograd.grad((y2 * r).sum(), [t2])
+        assert torch.allclose(y, y2, atol=1e-6) and torch.allclose(gt, gt2, atol=1e-6)
+    # p = 0: no generator needed, identity factors
+    assert torch.equal(torch.ops.caster_gvp.dropout_add(a.detach(), x.detach(), pair, 1, 0.0), x.detach() + a.detach())
