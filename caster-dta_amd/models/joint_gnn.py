@@ -392,10 +392,13 @@ class CrossAttentionModule(nn.Module):
             # K and V read the same rows and their weights are adjacent in in_proj_weight: ONE [*, 2E] GEMM, split by
             # column views (what the attention kernel takes: rows of stride 2E would need a copy, so the halves are
             # made contiguous -- still two launches fewer per direction, forward and backward)
-            W = mha.in_proj_weight
-            q = fast_linear(x_q, W[:E], b[:E])
-            kv = fast_linear(x_kv, W[E:], b[E:])
-            return q, kv[:, :E].contiguous(), kv[:, E:].contiguous()
+            # (split, not slices: the backward of a split is ONE cat of its parts' gradients, the backward of every slice
+            # is a zero-filled full-size tensor + a copy + an add -- 12 slices made 12 fills and 12 copies per step)
+            wq, wkv = mha.in_proj_weight.split([E, 2 * E])
+            bq, bkv = b.split([E, 2 * E])
+            q = fast_linear(x_q, wq, bq)
+            k, v = fast_linear(x_kv, wkv, bkv).split([E, E], dim=1)
+            return q, k.contiguous(), v.contiguous()
         bq, bk, bv = (b[:E], b[E:2 * E], b[2 * E:]) if b is not None else (None, None, None)
         if mha._qkv_same_embed_dim:
             W = mha.in_proj_weight
