@@ -88,6 +88,9 @@ def parse():
                          "computes in half precision; the encoder ops' autocast rule keeps them in fp32)")
     ap.add_argument("--compile-graph", action="store_true",
                     help="with --compile: additionally capture the compiled step into a HIP graph (experiment)")
+    ap.add_argument("--tunable-gemms", action="store_true",
+                    help="--scope joint: let PyTorch's TunableOp pick the library GEMM solution per shape (torch.cuda.tunable; "
+                         "tuned during the untimed warm-up, nothing written to disk)")
     ap.add_argument("--issue-order", default="protein", choices=["protein", "drug"],
                     help="which encoder's launches are issued (and captured) first in a step (A/B)")
     ap.add_argument("--drug-priority", type=int, default=0,
@@ -226,6 +229,11 @@ def main():
     if args.collate_csr:
         collate = (store_of(pb, pdata), store_of(mb, mdata))
 
+    if args.tunable_gemms:
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(True)
+        tunable.write_file_on_exit(False)
     prot_params = [p for p in model.protein_gnn.parameters() if p.numel()]
     drug_params = [p for p in model.molecule_gnn.parameters() if p.numel()]
     enc_params = prot_params + drug_params
@@ -515,7 +523,7 @@ def main():
                        "protein_edges_per_gpu": pb.num_edges, "atoms_per_gpu": mb.num_nodes,
                        "drug_edges_per_gpu": mb.num_edges, "encoder": f"CASTER-DTA({convs},{convs})", "pass": args.mode,
                        "activation_storage": "bf16 (protein encoder: bf16 activations in HBM and bf16 matrix-core operands, fp32 accumulate, fp32 weights and gradient buffers)" if args.dtype == "bf16" else "fp32",
-                       "scope": args.scope, "untimed_warmup_steps": max(args.warmup, MIN_WARMUP), "torch_compile": bool(args.compile and args.scope == "joint"), "autocast": args.autocast if args.scope == "joint" else None, "train_mode": bool(dropout_on), "dropout_p": 0.2 if dropout_on else 0.0,
+                       "scope": args.scope, "untimed_warmup_steps": max(args.warmup, MIN_WARMUP), "torch_compile": bool(args.compile and args.scope == "joint"), "tunable_gemms": bool(args.tunable_gemms), "autocast": args.autocast if args.scope == "joint" else None, "train_mode": bool(dropout_on), "dropout_p": 0.2 if dropout_on else 0.0,
                        "csr_build_in_step": ("collate" if args.collate_csr else not args.cache_csr),
                        "hip_graph": graph is not None, "kernels": ops.VARIANT, "parallelism": par,
                        "baseline_config": args.config, "rccl_ranks": (dist.get_world_size() if (dist is not None and not rehearsal) else 0),
