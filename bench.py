@@ -90,7 +90,7 @@ def parse():
                     help="with --compile: additionally capture the compiled step into a HIP graph (experiment)")
     ap.add_argument("--tunable-gemms", action="store_true",
                     help="--scope joint: let PyTorch's TunableOp pick the library GEMM solution per shape (torch.cuda.tunable; "
-                         "tuned during the untimed warm-up, nothing written to disk)")
+                         "tuned during the untimed warm-up; the results file goes to $TMPDIR)")
     ap.add_argument("--issue-order", default="protein", choices=["protein", "drug"],
                     help="which encoder's launches are issued (and captured) first in a step (A/B)")
     ap.add_argument("--drug-priority", type=int, default=0,
@@ -233,7 +233,7 @@ def main():
         import torch.cuda.tunable as tunable
         tunable.enable(True)
         tunable.tuning_enable(True)
-        tunable.write_file_on_exit(False)
+        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "caster_gvp_tunableop.csv"))    # (results file: scratch)
     prot_params = [p for p in model.protein_gnn.parameters() if p.numel()]
     drug_params = [p for p in model.molecule_gnn.parameters() if p.numel()]
     enc_params = prot_params + drug_params
