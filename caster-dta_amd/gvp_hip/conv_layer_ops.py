@@ -167,7 +167,7 @@ def edge_rows(edge_attr, eperm, num_edges):
     """Stored edge-embedding rows [E + 1][CGVP_EDGE_ROW] in sorted-edge order (32 scalars zero-padded | xyz | pad; the
     extra last row is zeros).  Differentiable gather."""
     e_s, e_v = edge_attr
-    idx = eperm[:num_edges].long()
+    idx = eperm[:num_edges].long().clamp_min(0)      # (-1: positions behind the last valid edge when the build dropped edges; never read)
     rows = torch.cat([e_s.index_select(0, idx), e_s.new_zeros(num_edges, ES - e_s.shape[1]),
                       e_v.index_select(0, idx).reshape(num_edges, 3), e_s.new_zeros(num_edges, EROW - ES - 3)], dim=1)
     return torch.cat([rows, rows.new_zeros(1, EROW)], dim=0).contiguous()
