@@ -88,6 +88,8 @@ def parse():
                          "computes in half precision; the encoder ops' autocast rule keeps them in fp32)")
     ap.add_argument("--compile-graph", action="store_true",
                     help="with --compile: additionally capture the compiled step into a HIP graph (experiment)")
+    ap.add_argument("--two-lane-head", action="store_true",
+                    help="--scope joint: JointGNN.two_stream_head = True (the atom side of the head on a side stream)")
     ap.add_argument("--tunable-gemms", action="store_true",
                     help="--scope joint: let PyTorch's TunableOp pick the library GEMM solution per shape (torch.cuda.tunable; "
                          "tuned during the untimed warm-up; the results file goes to $TMPDIR)")
@@ -229,6 +231,8 @@ def main():
     if args.collate_csr:
         collate = (store_of(pb, pdata), store_of(mb, mdata))
 
+    if args.two_lane_head:
+        model.two_stream_head = True
     if args.tunable_gemms:
         import torch.cuda.tunable as tunable
         tunable.enable(True)
@@ -523,7 +527,7 @@ def main():
                        "protein_edges_per_gpu": pb.num_edges, "atoms_per_gpu": mb.num_nodes,
                        "drug_edges_per_gpu": mb.num_edges, "encoder": f"CASTER-DTA({convs},{convs})", "pass": args.mode,
                        "activation_storage": "bf16 (protein encoder: bf16 activations in HBM and bf16 matrix-core operands, fp32 accumulate, fp32 weights and gradient buffers)" if args.dtype == "bf16" else "fp32",
-                       "scope": args.scope, "untimed_warmup_steps": max(args.warmup, MIN_WARMUP), "torch_compile": bool(args.compile and args.scope == "joint"), "tunable_gemms": bool(args.tunable_gemms), "autocast": args.autocast if args.scope == "joint" else None, "train_mode": bool(dropout_on), "dropout_p": 0.2 if dropout_on else 0.0,
+                       "scope": args.scope, "untimed_warmup_steps": max(args.warmup, MIN_WARMUP), "torch_compile": bool(args.compile and args.scope == "joint"), "tunable_gemms": bool(args.tunable_gemms), "two_lane_head": bool(args.two_lane_head), "autocast": args.autocast if args.scope == "joint" else None, "train_mode": bool(dropout_on), "dropout_p": 0.2 if dropout_on else 0.0,
                        "csr_build_in_step": ("collate" if args.collate_csr else not args.cache_csr),
                        "hip_graph": graph is not None, "kernels": ops.VARIANT, "parallelism": par,
                        "baseline_config": args.config, "rccl_ranks": (dist.get_world_size() if (dist is not None and not rehearsal) else 0),

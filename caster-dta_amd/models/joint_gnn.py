@@ -65,6 +65,62 @@ class _BatchNorm(nn.Module):
         return self.module(x)
 
 
+_SIDE_STREAMS = {}
+
+
+class _Lanes:
+    """Two lanes for the head's row work (opt-in, `JointGNN.two_stream_head`): everything on the ATOM side -- its stack,
+    LayerNorms, projections, feed-forward, pooling, molecule MLP: ~15 launches of a few microseconds each way on 2,560
+    rows -- runs on a side stream beside the residue side (19,200 rows) instead of in between; the lanes meet at the
+    attention core and at the pair concatenation.  Autograd runs every backward node on its forward's stream, so the
+    backward overlaps the same way.  Tensors that cross lanes are recorded on the consuming stream (allocator safety)."""
+
+    def __init__(self, on, device):
+        self.on = bool(on)
+        if self.on:
+            self.main = torch.cuda.current_stream(device)
+            key = (device.index, self.main.cuda_stream)
+            if key not in _SIDE_STREAMS:
+                _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+            self.side = _SIDE_STREAMS[key]
+
+    def fork(self, *to_side):
+        if self.on:
+            self.side.wait_stream(self.main)
+            for t in to_side:
+                if t is not None:
+                    t.record_stream(self.side)
+
+    def join(self, *to_main):
+        if self.on:
+            self.main.wait_stream(self.side)
+            for t in to_main:
+                if t is not None:
+                    t.record_stream(self.main)
+
+    def atom(self):
+        import contextlib
+        return torch.cuda.stream(self.side) if self.on else contextlib.nullcontext()
+
+
+class _JoinLanesAfterBackward(torch.autograd.Function):
+    """Identity in the forward (placed where the lanes meet); its backward -- the FIRST node of the head's backward --
+    queues an end-of-backward callback that makes the launch stream wait for the atom lane once more: the parameter
+    gradients of the atom side are produced on that lane and consumed by nobody inside the graph, so without it a
+    captured step would end with unjoined work (hipErrorStreamCaptureUnjoined) and an eager caller could read them early."""
+
+    @staticmethod
+    def forward(ctx, t, lanes):
+        ctx.lanes = lanes
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        lanes = ctx.lanes
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: lanes.main.wait_stream(lanes.side))
+        return g, None
+
+
 class JointGNN(nn.Module):
     """Protein encoder + drug encoder + cross-attention + affinity head -> [B, 1]."""
 
@@ -272,10 +328,15 @@ class JointGNN(nn.Module):
             atom = atom.to(hdt)
         from gvp_hip.head_ops import DropSites
         sites = DropSites(residue, self.training, self.dropout.p)     # fused dropout sites of this forward (eager fp32 training)
+        varlen = self.cross_attn_module is None or self.cross_attn_module.varlen_supported(residue)
+        lanes = _Lanes(getattr(self, "two_stream_head", False) and residue.is_cuda and varlen
+                       and not torch.compiler.is_compiling(), residue.device)
+        lanes.fork(atom, sites.pair)
         residue = self._stack(residue, self.residue_lins, self.residue_norms, sites)
-        atom = self._stack(atom, self.atom_lins, self.atom_norms, sites)
+        with lanes.atom():
+            atom = self._stack(atom, self.atom_lins, self.atom_norms, sites)
         attn = None
-        if self.cross_attn_module is None or self.cross_attn_module.varlen_supported(residue):
+        if varlen:
             # compact rows end to end: varlen cross attention (one launch for both directions) + segment pooling
             pbatch, rptr = self._offsets(protein_graph_data, pbatch, residue)
             mbatch, aptr = self._offsets(molecule_graph_data, mbatch, atom)
@@ -283,8 +344,10 @@ class JointGNN(nn.Module):
                 raise ValueError("protein and molecule batches hold different numbers of graphs")
             if self.cross_attn_module is not None:
                 want = self.attention_weights == "always" or (self.attention_weights == "auto" and not self.training)
-                residue, atom, attn = self.cross_attn_module.forward_varlen(residue, atom, rptr, aptr, want, sites)
-            protein, molecule = self._pool_rows(residue, pbatch, rptr), self._pool_rows(atom, mbatch, aptr)
+                residue, atom, attn = self.cross_attn_module.forward_varlen(residue, atom, rptr, aptr, want, sites, lanes)
+            protein = self._pool_rows(residue, pbatch, rptr)
+            with lanes.atom():
+                molecule = self._pool_rows(atom, mbatch, aptr)
         else:
             # the reference's dense formulation (head shapes the varlen kernel is not compiled for)
             residue, rmask = to_dense_batch(residue, pbatch)
@@ -292,11 +355,17 @@ class JointGNN(nn.Module):
             residue, atom, attn = self.cross_attn_module(residue, atom, rmask, amask)
             protein, molecule = self._pool(residue, rmask), self._pool(atom, amask)
         if self.include_post_pool_layernorm:
-            protein, molecule = self.protein_post_pool_norm(protein), self.molecule_post_pool_norm(molecule)
+            protein = self.protein_post_pool_norm(protein)
         protein = sites.act_dropout(protein, self.activation, self.dropout)
-        molecule = sites.act_dropout(molecule, self.activation, self.dropout)
         protein = self._stack(protein, self.protein_lins, self.protein_norms, sites)
-        molecule = self._stack(molecule, self.molecule_lins, self.molecule_norms, sites)
+        with lanes.atom():
+            if self.include_post_pool_layernorm:
+                molecule = self.molecule_post_pool_norm(molecule)
+            molecule = sites.act_dropout(molecule, self.activation, self.dropout)
+            molecule = self._stack(molecule, self.molecule_lins, self.molecule_norms, sites)
+        lanes.join(molecule)
+        if lanes.on and torch.is_grad_enabled() and molecule.requires_grad:
+            molecule = _JoinLanesAfterBackward.apply(molecule, lanes)
         pair = torch.cat([protein, molecule], dim=-1)
         if self._pair_parallel:
             pair = self._gather_pairs(pair)
@@ -383,45 +452,66 @@ class CrossAttentionModule(nn.Module):
                 and m1.num_heads == m2.num_heads and not (self.training and (m1.dropout > 0 or m2.dropout > 0)))
 
     @staticmethod
-    def _qkv(mha, x_q, x_kv):
-        """nn.MultiheadAttention's input projections on compact rows (three library GEMMs, contiguous outputs)."""
-        from gvp_hip.head_ops import fast_linear
-        E = mha.embed_dim
-        b = mha.in_proj_bias
+    def _proj_parts(mha):
+        """(wq, bq, wkv, bkv, wk, bk, wv, bv) of an nn.MultiheadAttention: the packed in_proj weight / bias SPLIT once (the
+        backward of a split is ONE cat of its parts' gradients; the backward of every slice is a zero-filled full-size
+        tensor + a copy + an add -- 12 slices made 12 fills and 12 copies per step).  wkv / bkv: K and V packed, for the
+        one-GEMM projection (None when the weights are separate or there is no bias)."""
+        E, b = mha.embed_dim, mha.in_proj_bias
         if mha._qkv_same_embed_dim and b is not None:
-            # K and V read the same rows and their weights are adjacent in in_proj_weight: ONE [*, 2E] GEMM, split by
-            # column views (what the attention kernel takes: rows of stride 2E would need a copy, so the halves are
-            # made contiguous -- still two launches fewer per direction, forward and backward)
-            # (split, not slices: the backward of a split is ONE cat of its parts' gradients, the backward of every slice
-            # is a zero-filled full-size tensor + a copy + an add -- 12 slices made 12 fills and 12 copies per step)
             wq, wkv = mha.in_proj_weight.split([E, 2 * E])
             bq, bkv = b.split([E, 2 * E])
-            q = fast_linear(x_q, wq, bq)
-            k, v = fast_linear(x_kv, wkv, bkv).split([E, E], dim=1)
-            return q, k.contiguous(), v.contiguous()
-        bq, bk, bv = (b[:E], b[E:2 * E], b[2 * E:]) if b is not None else (None, None, None)
+            return wq, bq, wkv, bkv, None, None, None, None
+        bq, bk, bv = (None, None, None) if b is None else b.split([E, E, E])
         if mha._qkv_same_embed_dim:
-            W = mha.in_proj_weight
-            wq, wk, wv = W[:E], W[E:2 * E], W[2 * E:]
+            wq, wk, wv = mha.in_proj_weight.split([E, E, E])
         else:
             wq, wk, wv = mha.q_proj_weight, mha.k_proj_weight, mha.v_proj_weight
-        return fast_linear(x_q, wq, bq), fast_linear(x_kv, wk, bk), fast_linear(x_kv, wv, bv)
+        return wq, bq, None, None, wk, bk, wv, bv
 
-    def forward_varlen(self, embed_1, embed_2, ptr1, ptr2, need_weights=False, sites=None):
+    @staticmethod
+    def _q(parts, x_q):
+        from gvp_hip.head_ops import fast_linear
+        return fast_linear(x_q, parts[0], parts[1])
+
+    @staticmethod
+    def _kv(parts, x_kv, E):
+        """Key and value projections: ONE [*, 2E] GEMM when the weights are packed (K and V read the same rows and their
+        weights are adjacent in in_proj_weight), halves made contiguous for the attention kernel."""
+        from gvp_hip.head_ops import fast_linear
+        if parts[2] is not None:
+            k, v = fast_linear(x_kv, parts[2], parts[3]).split([E, E], dim=1)
+            return k.contiguous(), v.contiguous()
+        return fast_linear(x_kv, parts[4], parts[5]), fast_linear(x_kv, parts[6], parts[7])
+
+    def forward_varlen(self, embed_1, embed_2, ptr1, ptr2, need_weights=False, sites=None, lanes=None):
         """`forward` on compact rows: embed_1 [N1, D] with graph offsets ptr1, embed_2 [N2, D] with ptr2; every
         graph b of side 1 attends to graph b of side 2 and vice versa (joint_gnn.py:376-398).  The softmax(QK^T)V
         core of both directions is one launch of caster_gvp::cross_attention; projections and feed-forward are
         GEMMs on the compact rows.  Returns (embed_1, embed_2, (w1, w2) or None)."""
         from gvp_hip import attention_ops  # noqa: F401  (registers the ops)
         from gvp_hip.head_ops import fast_layer_norm      # nn.LayerNorm on compact rows: one-pass kernels each way
-        n1, n2 = fast_layer_norm(embed_1, self.preattn_norm1), fast_layer_norm(embed_2, self.preattn_norm2)
-        q1, k1, v1 = self._qkv(self.embed1_to_2, n1, n2)
-        q2, k2, v2 = self._qkv(self.embed2_to_1, n2, n1)
+        if lanes is None:
+            lanes = _Lanes(False, embed_1.device)
+        # side 1 (residue rows) on the launch stream, side 2 (atom rows) on the other lane: each side's norm and the
+        # projections that read it (its own queries, the OTHER direction's keys / values)
+        E = self.embed1_to_2.embed_dim
+        p12, p21 = self._proj_parts(self.embed1_to_2), self._proj_parts(self.embed2_to_1)
+        n1 = fast_layer_norm(embed_1, self.preattn_norm1)
+        q1 = self._q(p12, n1)
+        k2, v2 = self._kv(p21, n1, E)
+        with lanes.atom():
+            n2 = fast_layer_norm(embed_2, self.preattn_norm2)
+            q2 = self._q(p21, n2)
+            k1, v1 = self._kv(p12, n2, E)
+        lanes.join(q2, k1, v1)
         heads = self.embed1_to_2.num_heads
         o1, o2, lse1, lse2 = torch.ops.caster_gvp.cross_attention(q1, k1, v1, q2, k2, v2, ptr1, ptr2, heads)
         from gvp_hip.head_ops import fast_linear
+        lanes.fork(o2)
         a1 = fast_linear(o1, self.embed1_to_2.out_proj.weight, self.embed1_to_2.out_proj.bias)
-        a2 = fast_linear(o2, self.embed2_to_1.out_proj.weight, self.embed2_to_1.out_proj.bias)
+        with lanes.atom():
+            a2 = fast_linear(o2, self.embed2_to_1.out_proj.weight, self.embed2_to_1.out_proj.bias)
         weights = None
         if need_weights:
             l1 = int((ptr1[1:] - ptr1[:-1]).max()) if ptr1.numel() > 1 else 0      # inference only: host sync
@@ -438,11 +528,12 @@ class CrossAttentionModule(nn.Module):
                 return fast_linear(h, seq[3].weight, seq[3].bias)
             embed_1 = sites.dropout_add(embed_1, a1, self.ff_dropout)
             embed_1 = sites.dropout_add(embed_1, ff(self.ff1, fast_layer_norm(embed_1, self.ff_norm1)), self.ff_dropout)
-            embed_2 = sites.dropout_add(embed_2, a2, self.ff_dropout)
-            embed_2 = sites.dropout_add(embed_2, ff(self.ff2, fast_layer_norm(embed_2, self.ff_norm2)), self.ff_dropout)
+            with lanes.atom():
+                embed_2 = sites.dropout_add(embed_2, a2, self.ff_dropout)
+                embed_2 = sites.dropout_add(embed_2, ff(self.ff2, fast_layer_norm(embed_2, self.ff_norm2)), self.ff_dropout)
         else:
             embed_1, embed_2 = a1, a2
-        return embed_1, embed_2, weights
+        return embed_1, embed_2, weights          # (embed_2 stays on the atom lane: the caller joins)
 
     def forward(self, embed_1, embed_2, mask1, mask2, return_weights=True):
         n1, n2 = self.preattn_norm1(embed_1), self.preattn_norm2(embed_2)
@@ -466,10 +557,10 @@ class StackedCrossAttentionModule(nn.Module):
     def varlen_supported(self, rows):
         return all(layer.varlen_supported(rows) for layer in self.cross_attn_layers)
 
-    def forward_varlen(self, embed_1, embed_2, ptr1, ptr2, need_weights=False, sites=None):
+    def forward_varlen(self, embed_1, embed_2, ptr1, ptr2, need_weights=False, sites=None, lanes=None):
         weights = []
         for layer in self.cross_attn_layers:
-            embed_1, embed_2, w = layer.forward_varlen(embed_1, embed_2, ptr1, ptr2, need_weights, sites)
+            embed_1, embed_2, w = layer.forward_varlen(embed_1, embed_2, ptr1, ptr2, need_weights, sites, lanes)
             weights.append(w)
         return embed_1, embed_2, (weights if need_weights else None)
 

@@ -528,3 +528,52 @@ def test_fused_parameter_mode_trains_like_the_per_tensor_model(pretrained, lba_s
         assert float((sp[k] - sf[k]).abs().max()) <= 2e-5 * max(float(sp[k].abs().max()), 1e-3), k
         moved += int(not torch.equal(sp[k].cpu(), pretrained[k]))
     assert moved > 100
+
+
+def test_two_lane_head_equals_the_single_stream_head(pretrained):
+    """`model.two_stream_head = True` (opt-in): the atom side of the head on a side stream.  Same predictions and the same
+    764,396 gradients as the single-stream head, eagerly (3 steps back to back, so that a missing cross-stream
+    dependency would show) and from a captured graph."""
+    from models.joint_gnn import JointGNN
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))
+    model = JointGNN(protein_gnn_kwargs=kw["protein_gnn_kwargs"], molecule_gnn_kwargs=kw["molecule_gnn_kwargs"],
+                     **kw["joint_gnn_kwargs"])
+    model.load_state_dict(pretrained, strict=True)
+    model.to(DEV).eval()                                   # eval: no dropout, the two runs see the same numbers
+    model.attention_weights = "never"                      # (the padded weight tensors need a host-side maximum: not capturable)
+    p, m = ds.pair_batch(24, 11)
+    pd, md = _to(ds.to_torch(p)), _to(ds.to_torch(m))
+    pd["ptr"], md["ptr"] = torch.as_tensor(p.ptr).to(DEV), torch.as_tensor(m.ptr).to(DEV)
+    params = [q for q in model.parameters() if q.numel()]
+    target = torch.randn(24, 1, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+
+    def step():
+        pred, _ = model(pd, md)
+        loss = torch.nn.functional.mse_loss(pred, target)
+        return [pred.detach().clone()] + [g.detach().clone() for g in torch.autograd.grad(loss, params)]
+
+    model.two_stream_head = False
+    ref = step()
+    model.two_stream_head = True
+    for _ in range(3):
+        got = step()
+    torch.cuda.synchronize()
+    scale = max(float(g.abs().max()) for g in ref[1:])
+    for a, b in zip(got, ref):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 2e-7 * scale
+    # captured: the side lane becomes a parallel branch of the graph
+    s = torch.cuda.Stream(device=DEV)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            step()
+        torch.cuda.current_stream().synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            out = step()
+        for _ in range(3):
+            g.replay()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    for a, b in zip(out, ref):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 2e-7 * scale
