@@ -24,6 +24,8 @@ all-reduce of the pre-gather parameter gradients (`reduce_pair_parallel_grads`).
 """
 from functools import partial
 
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -312,11 +314,19 @@ class JointGNN(nn.Module):
     def forward(self, protein_graph_data={}, molecule_graph_data={}):
         pbatch = protein_graph_data.get("batch", None)
         mbatch = molecule_graph_data.get("batch", None)
+        x0 = molecule_graph_data.get("x", None)
+        lanes = None
+        if getattr(self, "two_stream_head", False) and torch.is_tensor(x0) and x0.is_cuda and not torch.compiler.is_compiling():
+            # opt-in two lanes: the drug encoder (and later the atom side of the head) on a side stream beside the protein
+            # encoder -- forward and, because autograd runs a backward node on its forward's stream, backward
+            lanes = _Lanes(True, x0.device)
+            lanes.fork(*[t for t in molecule_graph_data.values() if torch.is_tensor(t)])
         residue = self.protein_gnn(**{k: v for k, v in protein_graph_data.items() if k != "ptr"})    # MI355X kernels
-        atom = self.molecule_gnn(**{k: v for k, v in molecule_graph_data.items() if k != "ptr"})     # MI355X kernels
-        return self.head(residue, atom, protein_graph_data, molecule_graph_data)
+        with (lanes.atom() if lanes is not None else contextlib.nullcontext()):
+            atom = self.molecule_gnn(**{k: v for k, v in molecule_graph_data.items() if k != "ptr"})     # MI355X kernels
+        return self.head(residue, atom, protein_graph_data, molecule_graph_data, lanes)
 
-    def head(self, residue, atom, protein_graph_data={}, molecule_graph_data={}):
+    def head(self, residue, atom, protein_graph_data={}, molecule_graph_data={}, lanes=None):
         """Everything after the two encoders (joint_gnn.py:188-286): residue / atom stacks, cross attention, pooling,
         affinity head.  `residue` [N, D], `atom` [Na, D] are the encoders' outputs; the dicts supply batch / ptr."""
         pbatch = protein_graph_data.get("batch", None)
@@ -325,12 +335,16 @@ class JointGNN(nn.Module):
         if residue.dtype != hdt and not torch.is_autocast_enabled():   # bf16-storage encoders feeding an fp32 head
             residue = residue.to(hdt)
         if atom.dtype != hdt and not torch.is_autocast_enabled():
-            atom = atom.to(hdt)
+            with (lanes.atom() if lanes is not None else contextlib.nullcontext()):      # (the lane `atom` was produced on)
+                atom = atom.to(hdt)
         from gvp_hip.head_ops import DropSites
         sites = DropSites(residue, self.training, self.dropout.p)     # fused dropout sites of this forward (eager fp32 training)
         varlen = self.cross_attn_module is None or self.cross_attn_module.varlen_supported(residue)
-        lanes = _Lanes(getattr(self, "two_stream_head", False) and residue.is_cuda and varlen
-                       and not torch.compiler.is_compiling(), residue.device)
+        if lanes is None or not varlen:
+            if lanes is not None:
+                lanes.join(atom)                  # dense fallback: everything back on the launch stream
+            lanes = _Lanes(getattr(self, "two_stream_head", False) and residue.is_cuda and varlen
+                           and not torch.compiler.is_compiling(), residue.device)
         lanes.fork(atom, sites.pair)
         residue = self._stack(residue, self.residue_lins, self.residue_norms, sites)
         with lanes.atom():
