@@ -9,8 +9,8 @@ bash tools/profile_round.sh $RND bindingdb_b32_44 --dtype bf16 > gpurun_out/prof
 bash tools/profile_round.sh $RND kiba_b32 > gpurun_out/prof_${RND}_d.log 2>&1; tail -1 gpurun_out/prof_${RND}_d.log
 bash tools/profile_sq.sh davis_b64 > gpurun_out/prof_${RND}_sq.log 2>&1; tail -3 gpurun_out/prof_${RND}_sq.log
 export TMPDIR=/tmp
-for extra in "" "--tunable-gemms" "--compile --compile-graph"; do
-  tag=joint$(echo "$extra" | tr -d ' -' | cut -c1-12)
+for extra in "" "--tunable-gemms" "--two-lane-head" "--two-lane-head --tunable-gemms" "--compile --compile-graph"; do
+  tag=joint$(echo "$extra" | tr -d ' -' | cut -c1-28)
   python bench.py --scope joint --steps 50 --no-cpu-baseline --epoch off $extra > gpurun_out/bench_davis_b64_$tag.json 2> gpurun_out/bench_$tag.err
   tail -c 400 gpurun_out/bench_davis_b64_$tag.json
 done
