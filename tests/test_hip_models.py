@@ -561,6 +561,26 @@ def test_two_lane_head_equals_the_single_stream_head(pretrained):
     scale = max(float(g.abs().max()) for g in ref[1:])
     for a, b in zip(got, ref):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 2e-7 * scale
+    # training mode with every dropout on: the masks are pure functions of the generator states, the call site and the
+    # element, so with the states restored the two schedules must agree here too
+    from gvp_hip import autograd_ops, head_ops
+    model.train()
+    model.two_stream_head = False
+    step()                                                  # (creates the three device-side generator states)
+    dev = torch.device(DEV)
+    states = [autograd_ops.rng_state("lba", dev), autograd_ops.rng_state("gine", dev), head_ops._head_rng_state(dev)]
+    saved = [t.clone() for t in states]
+    ref_t = step()
+    for t, v in zip(states, saved):
+        t.copy_(v)
+    model.two_stream_head = True
+    got_t = step()
+    torch.cuda.synchronize()
+    scale_t = max(float(g.abs().max()) for g in ref_t[1:])
+    for a, b in zip(got_t, ref_t):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 2e-7 * scale_t
+    assert not torch.allclose(ref_t[0], ref[0])            # (dropout did act)
+    model.eval()
     # captured: the side lane becomes a parallel branch of the graph
     s = torch.cuda.Stream(device=DEV)
     s.wait_stream(torch.cuda.current_stream())
