@@ -166,13 +166,56 @@ def committed_traffic(workload, kernel, dtype="f32"):
     return None
 
 
+def launcher_command(argv, gpus, port=None):
+    """Command line that starts `gpus` ranks of this script on one node (what the driver uses for N > 1)."""
+    if port is None:
+        import socket
+        with socket.socket() as s:                 # a free port now; torchrun binds it a moment later
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: this process -- which has touched no GPU and
+    never will -- starts the N ranks as CHILD processes, relays their output (rank 0 prints the one JSON line) and
+    returns their exit status.  Never an exec: the ranks are children, the parent only waits."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    cmd = launcher_command(argv, args.gpus)
+    print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus}` "
+                         f"(self-launching) or under torch.distributed.run with --nproc-per-node {args.gpus}")
+    if os.environ.get("BENCH_DRY_RUN") == "1":
+        # Control flow of the launch path without a GPU (tests/test_host_logic.py): rendezvous over gloo, the barrier /
+        # MAX-over-ranks pattern of the timed region on a stand-in duration, ONE line from rank 0.  No measurement.
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "max_over_ranks": float(t), "dtype": args.dtype,
+                              "config": {"workload": args.workload, "baseline_config": args.config, "ranks": world}}))
+        return
     # Rehearsal on a box with fewer GPUs than ranks (BENCH_REHEARSAL=1): all ranks share cuda:0 and the
     # collectives run over gloo on host copies.  The real multi-GPU run is one rank per GPU over RCCL ("nccl").
     rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"

@@ -14,3 +14,56 @@ def test_shard_pairs_by_edges_balances_and_covers():
     naive = [sum(edges[r * 32:(r + 1) * 32]) for r in range(8)]
     assert max(loads) <= max(naive)
     assert ops.shard_pairs_by_edges([5, 1], 4) == [[0], [1], [], []]
+
+
+# ---- bench.py --gpus N starts itself (VERDICT r3 "What's missing" #3): the driver may call `python bench.py --gpus 8`
+# the way it calls `--gpus 1`; the parent then launches the ranks as child processes before anything touches a GPU.
+def _bench_module():
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    spec = importlib.util.spec_from_file_location("bench_under_test", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, path
+
+
+def test_bench_launcher_command_line():
+    bench, path = _bench_module()
+    cmd = bench.launcher_command(["--gpus", "8", "--steps", "5", "--warmup", "2", "--config", "5"], 8, port=29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=8" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(path)
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "2", "--config", "5"]      # arguments pass through unchanged
+
+
+def test_bench_self_launch_dry_run_world2():
+    """`python bench.py --gpus 2` with no torchrun environment: the parent starts two ranks, they rendezvous over gloo,
+    run the barrier / MAX-over-ranks pattern and rank 0 prints ONE JSON line (BENCH_DRY_RUN stubs the GPU work)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    _, path = _bench_module()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["BENCH_DRY_RUN"] = "1"
+    out = subprocess.run([sys.executable, path, "--gpus", "2", "--steps", "7", "--warmup", "3", "--config", "3"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 7 and line["warmup"] == 3
+    assert line["config"]["workload"] == "kiba_b32" and line["config"]["ranks"] == 2
+    assert line["max_over_ranks"] == 2.0                      # rank 1's stand-in duration: the MAX went over both ranks
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    import os
+    import subprocess
+    import sys
+    _, path = _bench_module()
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0", BENCH_DRY_RUN="1")
+    out = subprocess.run([sys.executable, path, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "WORLD_SIZE=4" in out.stderr
