@@ -159,12 +159,16 @@ int cgvp_linear_wgrad(const float* x, const float* gy, int64_t R, int32_t I, int
   const dim3 grid((unsigned)((R + rps - 1) / rps), (unsigned)(O / OG));
   const size_t lds = (size_t)(KC * (I + 16) + KC * (OG + 16)) * sizeof(float);
   const int ntw = (I / 16 + 1 + 1) / 2;                    // column tiles of the busier parity
-#define LAUNCH(N_)                                                                                              \
+  // The dynamic-LDS attribute is set ONCE per instantiation and device, so it must cover the LARGEST I that instantiation
+  // serves (I <= 80 / 144 / 256 for N_ = 3 / 5 / 9), not the I of whichever call happened to come first.
+#define LAUNCH(N_, IMAX_)                                                                                       \
   do {                                                                                                          \
-    CGVP_SET_DYN_LDS_ONCE(linear_wgrad_kernel<N_>, lds);                                                        \
+    constexpr size_t lds_max_ = (size_t)(KC * ((IMAX_) + 16) + KC * (OG + 16)) * sizeof(float);                  \
+    static_assert(((IMAX_) / 16 + 2) / 2 <= (N_) && lds_max_ <= 160 * 1024, "instantiation bound");             \
+    CGVP_SET_DYN_LDS_ONCE(linear_wgrad_kernel<N_>, lds_max_);                                                   \
     hipLaunchKernelGGL(linear_wgrad_kernel<N_>, grid, dim3(TPB), lds, st, a);                                   \
   } while (0)
-  if (ntw <= 3) LAUNCH(3); else if (ntw <= 5) LAUNCH(5); else LAUNCH(9);
+  if (ntw <= 3) LAUNCH(3, 80); else if (ntw <= 5) LAUNCH(5, 144); else LAUNCH(9, 256);
 #undef LAUNCH
   cgvp_segment sg[2] = {{workspace, (int)grid.x, len, 0, O * I, 0}, {workspace, (int)grid.x, len, O * I, O, O * I}};
   quad::reduce_segments(sg, 2, out, st, 1);

@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "gvp_internal.h"
@@ -19,12 +21,15 @@
 namespace {
 
 // ------------------------------------------------------------------ opt-in kernel timing (cgvp_debug_kernel_timing)
+// The one piece of process state in the library (opt-in diagnostic): the flag is atomic, the list is only touched under
+// its mutex, so passes issued from several host threads (one per stream) stay re-entrant with timing on.
 struct TimedLaunch { hipEvent_t a, b; int kind; };
-bool g_timing = false;
+std::atomic<bool> g_timing{false};
+std::mutex g_timed_mutex;
 std::vector<TimedLaunch> g_timed;
 struct Timed {                 // brackets one launch with events when timing is on
   hipStream_t st; bool on; TimedLaunch t;
-  Timed(int kind, void* stream) : st((hipStream_t)stream), on(g_timing) {
+  Timed(int kind, void* stream) : st((hipStream_t)stream), on(g_timing.load(std::memory_order_relaxed)) {
     if (!on) return;
     t.kind = kind;
     if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) { on = false; return; }
@@ -33,6 +38,7 @@ struct Timed {                 // brackets one launch with events when timing is
   ~Timed() {
     if (!on) return;
     (void)hipEventRecord(t.b, st);
+    std::lock_guard<std::mutex> lock(g_timed_mutex);
     g_timed.push_back(t);
   }
 };
@@ -514,13 +520,18 @@ int cgvp_gine_backward_pass(const cgvp_gine_cfg* cfg, const cgvp_gine_w* w, cons
 
 // ===================================================================================== diagnostics
 int cgvp_debug_kernel_timing(int32_t enable) {
-  g_timing = enable != 0;
+  g_timing.store(enable != 0, std::memory_order_relaxed);
   return 0;
 }
 
 int cgvp_debug_kernel_times(float* ms, int32_t* kinds, int32_t capacity) {
   int n = 0;
-  for (const TimedLaunch& t : g_timed) {
+  std::vector<TimedLaunch> taken;
+  {
+    std::lock_guard<std::mutex> lock(g_timed_mutex);
+    taken.swap(g_timed);
+  }
+  for (const TimedLaunch& t : taken) {
     float v = 0.f;
     (void)hipEventSynchronize(t.b);
     (void)hipEventElapsedTime(&v, t.a, t.b);
@@ -529,7 +540,6 @@ int cgvp_debug_kernel_times(float* ms, int32_t* kinds, int32_t capacity) {
     (void)hipEventDestroy(t.a);
     (void)hipEventDestroy(t.b);
   }
-  g_timed.clear();
   return n;
 }
 

@@ -57,6 +57,25 @@ void check(int rc, const char* what) {
 void* current_stream(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
 
 // an activation / index buffer as the kernels want it: on the GPU, contiguous, 16-B aligned
+// What a backward node re-reads from LIVE storage (inputs; for the drug encoder also the weights -- the protein pass
+// snapshots its weights into the forward workspace) must not have been written in place since the forward: stock autograd
+// raises through SavedVariable's version check, these nodes hold plain tensors, so they keep the version counters themselves.
+struct Guarded { at::Tensor t; int64_t version; const char* what; };
+inline void guard_add(std::vector<Guarded>& g, const at::Tensor& t, const char* what) {
+  if (t.defined() && !t.is_inference()) g.push_back({t, t._version(), what});
+}
+inline void guard_check(const std::vector<Guarded>& g, const char* node) {
+  for (const Guarded& e : g)
+    TORCH_CHECK(e.t._version() == e.version, "caster_gvp: ", e.what, " needed by ", node, " was modified by an in-place "
+                "operation after the forward pass (version ", e.version, " -> ", e.t._version(), "): the gradients would be "
+                "computed from the new values");
+}
+// The kernels' backward is not itself differentiable: create_graph=True must fail loudly instead of returning constants.
+inline void once_differentiable(const char* node) {
+  TORCH_CHECK(!at::GradMode::is_enabled(), "caster_gvp: ", node, " is not differentiable twice (backward called with "
+              "create_graph=True); the encoder kernels provide first derivatives only");
+}
+
 at::Tensor ready(const at::Tensor& t, const char* name, c10::optional<at::ScalarType> dtype = c10::nullopt) {
   TORCH_CHECK(t.is_cuda(), name, ": caster-dta_amd runs on MI355X only (got a ", t.device(), " tensor); there is no CPU path");
   at::Tensor r = t;
@@ -131,14 +150,17 @@ struct LbaBackward : public Node {
   int64_t N = 0, E = 0;
   double dropout_p = 0;
   bool need_x = false;
+  std::vector<Guarded> guarded;
 
   variable_list apply(variable_list&& grads) override {
     Tic tic_all("lba_bwd.apply");
+    once_differentiable("CasterGvpLbaEncoderBackward");
     const size_t np = shapes.size();
     variable_list out(np + 2);
     if (grads.empty() || !grads[0].defined()) return out;
     TORCH_CHECK(ws.defined(), "caster_gvp: backward through a protein encoder pass whose saved state was already released "
                               "(call backward once, or pass retain_graph=True)");
+    guard_check(guarded, "the protein encoder's backward");
     c10::DeviceGuard guard(x_s.device());
     at::Tensor g_out = ready(grads[0], "grad_output", at::kFloat);
     auto f32 = x_s.options().dtype(at::kFloat).requires_grad(false);
@@ -176,7 +198,7 @@ struct LbaBackward : public Node {
   }
   void release_variables() override {
     ws.reset(); masks.reset(); x_s.reset(); x_v.reset(); e_s.reset(); e_v.reset(); ntypes.reset(); etypes.reset();
-    csr.clear();
+    csr.clear(); guarded.clear();
   }
   std::string name() const override { return "CasterGvpLbaEncoderBackward"; }
 };
@@ -248,6 +270,8 @@ std::tuple<at::Tensor, at::Tensor, bool> lba_encoder(std::vector<at::Tensor> par
     node->csr = csr;
     node->N = N; node->E = E; node->dropout_p = drop ? dropout_p : 0.0; node->need_x = need_x;
     node->x_dtype = x_s_in.scalar_type();
+    guard_add(node->guarded, x_s, "x_s"); guard_add(node->guarded, x_v, "x_v");
+    guard_add(node->guarded, e_s, "eattr_s"); guard_add(node->guarded, e_v, "eattr_v");
     node->shapes.reserve(params.size());
     node->strides.reserve(params.size());
     for (const at::Tensor& p : params) {
@@ -321,14 +345,17 @@ struct GineBackward : public Node {
   bool need_x = false;
   bool one_leaf = false;          // the caller's `params` was the single fused arena: return one gradient
   int max_workgroups = 0;
+  std::vector<Guarded> guarded;
 
   variable_list apply(variable_list&& grads) override {
     Tic tic_all("gine_bwd.apply");
+    once_differentiable("CasterGvpGineEncoderBackward");
     const size_t np = one_leaf ? 1 : params.size();
     variable_list out(np + 1);
     if (grads.empty() || !grads[0].defined()) return out;
     TORCH_CHECK(ws.defined(), "caster_gvp: backward through a drug encoder pass whose saved state was already released "
                               "(call backward once, or pass retain_graph=True)");
+    guard_check(guarded, "the drug encoder's backward");
     c10::DeviceGuard guard(x.device());
     at::Tensor g_out = ready(grads[0], "grad_output", at::kFloat);
     auto f32 = x.options().dtype(at::kFloat).requires_grad(false);
@@ -370,6 +397,7 @@ struct GineBackward : public Node {
   }
   void release_variables() override {
     ws.reset(); x.reset(); eattr.reset(); ntypes.reset(); etypes.reset(); params.clear(); csr.clear(); masks.clear();
+    guarded.clear();
   }
   std::string name() const override { return "CasterGvpGineEncoderBackward"; }
 };
@@ -433,12 +461,16 @@ std::tuple<at::Tensor, at::Tensor> gine_encoder(std::vector<at::Tensor> params_i
     node->meta = meta;
     node->one_leaf = one_leaf;
     node->params.reserve(params.size());
-    for (const at::Tensor& p : params) node->params.push_back(p.detach());
+    for (const at::Tensor& p : params) {
+      node->params.push_back(p.detach());
+      guard_add(node->guarded, node->params.back(), "a drug-encoder weight");     // (detach() shares the version counter)
+    }
     node->csr = csr;
     if (pinned) node->masks = masks;
     node->x = x; node->ntypes = ntypes; node->eattr = eattr; node->etypes = etypes; node->ws = ws;
     node->N = N; node->E = E; node->dropout_p = drop ? dropout_p : 0.0; node->need_x = need_x;
     node->max_workgroups = (int)bwd_workgroups;
+    guard_add(node->guarded, x, "x"); guard_add(node->guarded, eattr, "eattr");
     torch::autograd::set_history(out, node);
   }
   return {out, ws};
@@ -454,7 +486,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "eager fast path of caster-dta_amd: C++ autograd nodes over the whole-pass C ABI of libcaster_gvp.so";
   m.def("lba_encoder", &lba_encoder, "VectorProteinGNN_LBAModel.forward (protein_gnn.py:361-388) with autograd");
   m.def("gine_encoder", &gine_encoder, "HomoMoleculeGNN_GINE.forward (molecule_gnn.py:254-268) with autograd");
-  m.def("abi_version", []() { return cgvp_abi_version(); });
+  // the version of include/caster_gvp.h this bridge was COMPILED against (struct layouts, argument lists); the library
+  // loaded at run time reports its own through cgvp_abi_version(): _lib.bridge() requires all three to agree
+  m.def("abi_version", []() { return (int)CGVP_ABI_VERSION; });
+  m.def("library_abi_version", []() { return (int)cgvp_abi_version(); });
   m.def("timing_report", []() {
     std::string r;
     for (auto& kv : sections())

@@ -230,8 +230,11 @@ def bridge():
             spec = importlib.util.spec_from_file_location("caster_gvp_torch", path)
             mod = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(mod)
-            if mod.abi_version() != ABI_VERSION:
+            if mod.abi_version() != ABI_VERSION:          # the header version the bridge was COMPILED against
                 raise HipLibraryError(f"{path} was built against C ABI {mod.abi_version()}, binding expects {ABI_VERSION}; rebuild")
+            if mod.library_abi_version() != ABI_VERSION:  # ... and what the library it linked to reports at run time
+                raise HipLibraryError(f"{path} is linked to a libcaster_gvp.so of ABI {mod.library_abi_version()}, "
+                                      f"binding expects {ABI_VERSION}; rebuild")
             _bridge = mod
     return _bridge
 

@@ -356,6 +356,9 @@ class JointGNN(nn.Module):
             mbatch, aptr = self._offsets(molecule_graph_data, mbatch, atom)
             if rptr.numel() != aptr.numel():
                 raise ValueError("protein and molecule batches hold different numbers of graphs")
+            # `_offsets` may have CREATED aptr / mbatch on the launch stream (no 'ptr' / 'batch' from the caller); the atom
+            # lane reads them below.  With a cross-attention module its own forks come later; without one nothing does.
+            lanes.fork(aptr, mbatch)
             if self.cross_attn_module is not None:
                 want = self.attention_weights == "always" or (self.attention_weights == "auto" and not self.training)
                 residue, atom, attn = self.cross_attn_module.forward_varlen(residue, atom, rptr, aptr, want, sites, lanes)

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import davis_synth as ds
-from conftest import GOLDEN, rel_err
+from conftest import GOLDEN, PKG, REPO, rel_err
 from gvp_hip import attention_ops  # noqa: F401
 from oracle import gvp_oracle as O
 
@@ -181,6 +181,32 @@ def test_linear_wgrad_kernel_matches_torch(R, I, O):
     assert float((gb.double() - want_b).abs().max()) <= 2e-6 * max(1.0, float(want_b.abs().max())) * max(1, R) ** 0.5
     assert torch.equal(out, torch.ops.caster_gvp.linear_wgrad(x, gy))
     torch.library.opcheck(torch.ops.caster_gvp.linear_wgrad.default, (x[:300], gy[:300])) if R >= 300 else None
+
+
+@pytest.mark.gpu
+def test_linear_wgrad_small_input_width_first_then_the_largest_of_its_instantiation():
+    """the dynamic-LDS attribute of linear_wgrad_kernel<N> is set once per process and device, so it
+    has to cover the largest I the instantiation serves.  In a FRESH process (the attribute is process state): the
+    smallest I of each instantiation first, then its largest -- the second launch needs more LDS than the first asked for."""
+    import subprocess
+    import sys
+    code = """
+import sys, torch
+sys.path[:0] = [%r, %r]
+from gvp_hip import head_ops
+dev = torch.device('cuda:0')
+gen = torch.Generator(device=dev).manual_seed(0)
+for I in (16, 80, 96, 144, 160, 256):
+    x = torch.randn(2048, I, device=dev, generator=gen); gy = torch.randn(2048, 128, device=dev, generator=gen)
+    out = torch.ops.caster_gvp.linear_wgrad(x, gy)
+    torch.cuda.synchronize()
+    want = gy.double().t() @ x.double()
+    err = float((out[:128 * I].view(128, I).double() - want).abs().max())
+    assert err <= 2e-6 * float(want.abs().max()) * 2048 ** 0.5, (I, err)
+print('ok')
+""" % (PKG, REPO)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-3000:]
 
 
 @pytest.mark.gpu

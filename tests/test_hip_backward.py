@@ -421,3 +421,78 @@ def test_backward_without_edges(protein_params, molecule_params):
             assert rel_err(p.grad, g) < 2e-4, name
     assert rel_err(gx.grad, xr.grad) < 2e-4
 
+
+
+def test_davis_b64_both_encoders_fwd_bwd_vs_oracle(protein_params, molecule_params):
+    """BASELINE config 2 at EXACTLY its size -- the batch bench.py times (64 pairs x 300 residues, 4 A radius graphs,
+    ~40-atom drugs, seed 0, CASTER-DTA(2,2), train mode, dropout 0.2) -- both encoders forward + every gradient against the
+    CPU oracle run with the masks the kernels drew (until now this size was covered by properties and
+    self-comparison only)."""
+    from gvp_hip import autograd_ops, ops
+    from models.molecule_gnn import SelectableMoleculeModelWrapper
+    pb, mb = ds.pair_batch(64, 0, length=300, thresh=4.0, thresh_type="dist")
+    assert pb.num_nodes == 19200
+    pd, md = ds.to_torch(pb), ds.to_torch(mb)
+    model = _encoder(protein_params).train()
+    dd = _to(pd)
+    out = model(dd["x"], dd["edge_index"], dd["ntypes"], dd["etypes"], eattr=dd["eattr"])
+    seed = autograd_ops.last_seed("lba")
+    masks = ops.dropout_masks(seed, 0.2, 0, 4, pb.num_nodes, 20).cpu()
+    r = torch.randn(out.shape, generator=torch.Generator().manual_seed(4))
+    (out * r.to(DEV)).sum().backward()
+    P = {k: v.detach().cpu().clone().requires_grad_(v.numel() > 0) for k, v in model.gnn_model.state_dict().items()}
+    ref = O.protein_lba_forward(P, pd["x"], pd["edge_index"], pd["ntypes"], pd["etypes"], pd["eattr"],
+                                masks=[(masks[0], masks[1]), (masks[2], masks[3])])
+    assert rel_err(out, ref) < 2e-5
+    (ref * r).sum().backward()
+    assert _check_grads(model, {k: v.grad for k, v in P.items() if v.numel()}) >= 60
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))["molecule_gnn_kwargs"]
+    mol = SelectableMoleculeModelWrapper(**kw)
+    mol.load_state_dict({"gnn_model." + k: v for k, v in molecule_params.items()})
+    mol = mol.to(DEV).train()
+    dm = _to(md)
+    mout = mol(dm["x"], dm["edge_index"], dm["ntypes"], dm["etypes"], eattr=dm["eattr"])
+    mmask = ops.dropout_masks(autograd_ops.last_seed("gine"), 0.2, 0, 1, mb.num_nodes, 16).cpu()
+    Q = {k: v.clone().requires_grad_(True) for k, v in molecule_params.items()}
+    mref = O.molecule_gine_forward(Q, md["x"], md["edge_index"], md["ntypes"], md["etypes"], md["eattr"], masks=[mmask[0]])
+    assert rel_err(mout, mref) < 2e-5
+    r2 = torch.randn(mref.shape, generator=torch.Generator().manual_seed(5))
+    (mref * r2).sum().backward()
+    (mout * r2.to(DEV)).sum().backward()
+    for name, p in mol.gnn_model.named_parameters():
+        assert rel_err(p.grad, Q[name].grad) < 2e-4, name
+
+
+def test_in_place_edits_between_forward_and_backward_raise(protein_params, molecule_params):
+    """the C++ autograd nodes re-read inputs (and the drug encoder its weights) at backward time; an in-place
+    write in between must raise like stock autograd's saved-tensor version check, and create_graph=True must not return
+    silently non-differentiable gradients."""
+    from models.molecule_gnn import SelectableMoleculeModelWrapper
+    from gvp_hip import _lib
+    if _lib.bridge() is None:
+        pytest.skip("C++ bridge not in use (CGVP_BRIDGE=0 / CGVP_LIB_PATH)")
+    pb, mb = ds.pair_batch(2, 3, lengths=[40, 33])
+    dd, dm = _to(ds.to_torch(pb)), _to(ds.to_torch(mb))
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))["molecule_gnn_kwargs"]
+    mol = SelectableMoleculeModelWrapper(**kw)
+    mol.load_state_dict({"gnn_model." + k: v for k, v in molecule_params.items()})
+    mol = mol.to(DEV).eval()
+    out = mol(dm["x"], dm["edge_index"], dm["ntypes"], dm["etypes"], eattr=dm["eattr"])
+    with torch.no_grad():
+        next(p for p in mol.parameters() if p.numel()).mul_(1.5)           # an optimizer step before this pass's backward
+    with pytest.raises(RuntimeError, match="modified by an in-place"):
+        out.sum().backward()
+    model = _encoder(protein_params).eval()
+    xs = dd["x"][0].clone().requires_grad_()
+    xin = xs * 1.0                                                          # (a non-leaf the test may write in place)
+    out = model((xin, dd["x"][1]), dd["edge_index"], dd["ntypes"], dd["etypes"], eattr=dd["eattr"])
+    with torch.no_grad():
+        xin.add_(1.0)
+    with pytest.raises(RuntimeError, match="modified by an in-place"):
+        out.sum().backward()
+    out = model(dd["x"], dd["edge_index"], dd["ntypes"], dd["etypes"], eattr=dd["eattr"])
+    w = [p for p in model.parameters() if p.numel()]
+    with pytest.raises(RuntimeError, match="not differentiable twice"):
+        torch.autograd.grad(out.sum(), w, create_graph=True)
+    out = model(dd["x"], dd["edge_index"], dd["ntypes"], dd["etypes"], eattr=dd["eattr"])       # and the normal path still runs
+    out.sum().backward()

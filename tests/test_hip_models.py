@@ -597,3 +597,37 @@ def test_two_lane_head_equals_the_single_stream_head(pretrained):
     torch.cuda.synchronize()
     for a, b in zip(out, ref):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 2e-7 * scale
+
+
+def test_two_lane_head_without_cross_attention_and_without_ptr(pretrained):
+    """with `cross_attn_module = None` and no 'ptr' in the dicts, the atom-side offsets are created on the launch
+    stream and read by the pooling on the atom lane: the lane has to be forked after they exist.  Same outputs and gradients
+    as the single-stream head, several steps back to back."""
+    from models.joint_gnn import JointGNN
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))
+    jk = dict(kw["joint_gnn_kwargs"])
+    model = JointGNN(protein_gnn_kwargs=kw["protein_gnn_kwargs"], molecule_gnn_kwargs=kw["molecule_gnn_kwargs"], **jk)
+    model.load_state_dict(pretrained, strict=True)
+    model.cross_attn_module = None
+    model.to(DEV).eval()
+    p, m = ds.pair_batch(24, 12)
+    pd, md = _to(ds.to_torch(p)), _to(ds.to_torch(m))
+    pd.pop("ptr", None), md.pop("ptr", None)
+    params = [q for q in model.parameters() if q.numel()]
+    target = torch.randn(24, 1, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+
+    def step():
+        pred, _ = model(pd, md)
+        loss = torch.nn.functional.mse_loss(pred, target)
+        return [pred.detach().clone()] + [g.detach().clone() for g in torch.autograd.grad(loss, params, allow_unused=True) if g is not None]
+
+    model.two_stream_head = False
+    ref = step()
+    model.two_stream_head = True
+    for _ in range(4):
+        got = step()
+    torch.cuda.synchronize()
+    scale = max(float(g.abs().max()) for g in ref[1:])
+    assert len(got) == len(ref)
+    for a, b in zip(got, ref):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 2e-7 * scale
