@@ -116,6 +116,19 @@ struct Segs {
   }
 };
 
+// fp32 fragment image of one GEMM: per output tile mt a region of NSTEPS * 64 floats.  The first NSTEPS / 4 groups of four
+// k-steps are stored LANE-MAJOR -- [group][lane][4 steps]: ONE ds_read_b128 at (16 B x lane, conflict-free) fetches the A
+// operands of four MFMAs -- and the remaining NSTEPS % 4 steps step-major ([step][lane], one ds_read_b32 each, as every
+// step was until round 3: a read and a wait per MFMA pair).  idx = position in the image; (mt, s, lane) = what it holds.
+template <int NSTEPS>
+__host__ __device__ inline void frag_decode(int idx, int& mt, int& s, int& lane) {
+  constexpr int REGION = NSTEPS * 64, FULL = NSTEPS / 4;
+  mt = idx / REGION;
+  const int u = idx - mt * REGION;
+  if (u < FULL * 256) { s = 4 * (u >> 8) + (u & 3); lane = (u & 255) >> 2; }
+  else { const int v = u - FULL * 256; s = 4 * FULL + (v >> 6); lane = v & 63; }
+}
+
 // A weight matrix W[O][LD] (row-major nn.Linear) as MFMA A fragments.
 // Fragment (mt, step) holds, for lane (m, g): W[row(mt, m)][col(step, g)] or 0.
 template <int ROWKIND, int O, int LD, class KSegs>
@@ -129,16 +142,25 @@ struct Gemm {
     const int c = 4 * (m & 3) + (m >> 2);
     return c < O ? c : -1;
   }
-  // element `idx` (= frag * 64 + lane) of this GEMM's fragment image: offset into W, or -1 (zero)
-  static __host__ __device__ int offset(int idx) {
-    const int lane = idx & 63, f = idx >> 6;
-    const int mt = f / NSTEPS, s = f - mt * NSTEPS;
+  // what lane `lane` supplies as the A operand of k-step s of output tile mt: offset into W, or -1 (zero)
+  static __host__ __device__ int offset_of(int mt, int s, int lane) {
     const int r = row(mt, lane & 15), c = KSegs::col(s, lane >> 4);
     return (r >= 0 && c >= 0) ? r * LD + c : -1;
   }
-  static __host__ __device__ float element(const float* W, int idx) {
-    const int o = offset(idx);
+  static __host__ __device__ float value(const float* W, int mt, int s, int lane) {
+    const int o = offset_of(mt, s, lane);
     return o >= 0 ? W[o] : 0.f;
+  }
+  // element `idx` of this GEMM's fp32 fragment image (layout: frag_decode): offset into W or -1 / value
+  static __host__ __device__ int offset(int idx) {
+    int mt, s_, lane;
+    frag_decode<NSTEPS>(idx, mt, s_, lane);
+    return offset_of(mt, s_, lane);
+  }
+  static __host__ __device__ float element(const float* W, int idx) {
+    int mt, s_, lane;
+    frag_decode<NSTEPS>(idx, mt, s_, lane);
+    return value(W, mt, s_, lane);
   }
 };
 
@@ -151,17 +173,25 @@ struct GemmT {
   static constexpr int MT = ceil4(RowSegs::steps);
   static constexpr int NSTEPS = KSegs::steps;
   static constexpr int NFRAG = MT * NSTEPS;
-  static __host__ __device__ int offset(int idx) {
-    const int lane = idx & 63, f = idx >> 6;
-    const int mt = f / NSTEPS, s = f - mt * NSTEPS;
+  static __host__ __device__ int offset_of(int mt, int s, int lane) {
     const int m = lane & 15, slot = 4 * mt + (m & 3);
     const int c_out = slot < RowSegs::steps ? RowSegs::col(slot, m >> 2) : -1;
     const int c_k = KSegs::col(s, lane >> 4);
     return (c_out >= 0 && c_k >= 0) ? c_k * LD + c_out : -1;
   }
-  static __host__ __device__ float element(const float* W, int idx) {
-    const int o = offset(idx);
+  static __host__ __device__ float value(const float* W, int mt, int s, int lane) {
+    const int o = offset_of(mt, s, lane);
     return o >= 0 ? W[o] : 0.f;
+  }
+  static __host__ __device__ int offset(int idx) {
+    int mt, s_, lane;
+    frag_decode<NSTEPS>(idx, mt, s_, lane);
+    return offset_of(mt, s_, lane);
+  }
+  static __host__ __device__ float element(const float* W, int idx) {
+    int mt, s_, lane;
+    frag_decode<NSTEPS>(idx, mt, s_, lane);
+    return value(W, mt, s_, lane);
   }
 };
 
@@ -187,8 +217,8 @@ __host__ __device__ float packed_element(const float* W, int idx) {
   const int mt = idx / REGION, u = idx - mt * REGION, q = u >> 7;
   if (q >= ceil4(NS_)) return 0.f;
   const int lane = (u & 127) >> 1, s0 = 4 * q + 2 * (u & 1);
-  const float lo = s0 < NS_ ? G::element(W, (mt * NS_ + s0) * 64 + lane) : 0.f;
-  const float hi = s0 + 1 < NS_ ? G::element(W, (mt * NS_ + s0 + 1) * 64 + lane) : 0.f;
+  const float lo = s0 < NS_ ? G::value(W, mt, s0, lane) : 0.f;
+  const float hi = s0 + 1 < NS_ ? G::value(W, mt, s0 + 1, lane) : 0.f;
   return __builtin_bit_cast(float, bf16_bits(lo) | (bf16_bits(hi) << 16));
 }
 template <class G>
@@ -243,23 +273,35 @@ __device__ __forceinline__ void apply(const float* frag, int mt, const float (&b
     apply_bf16_steps<G, TN, 0>(frag + mt * G::NSTEPS * 64 + 2 * lane, b, acc);
     return;
   }
-  const float* f = frag + mt * G::NSTEPS * 64 + lane;
-  if (TN == 1 && G::NSTEPS >= 8) {
+  // fp32 image of this output tile (frag_decode): FULL lane-major groups of four steps, then REM step-major steps.  All the
+  // fragment reads of the call are issued up front (NSTEPS registers, <= 19): the MFMAs then run back to back instead of
+  // one LDS round trip per pair.
+  constexpr int NS_ = G::NSTEPS, FULL = NS_ / 4, REM = NS_ % 4;
+  const float* f = frag + mt * NS_ * 64;
+  float a[NS_];
+#pragma unroll
+  for (int q = 0; q < FULL; ++q) {
+    const f4 a4 = *reinterpret_cast<const f4*>(f + q * 256 + 4 * lane);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[4 * q + k] = a4[k];
+  }
+#pragma unroll
+  for (int r = 0; r < REM; ++r) a[4 * FULL + r] = f[FULL * 256 + r * 64 + lane];
+  if (TN == 1 && NS_ >= 8) {
     f4 acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s + 1 < G::NSTEPS; s += 2) {
-      acc[0] = mfma(f[s * 64], b[0][s], acc[0]);
-      acc2 = mfma(f[(s + 1) * 64], b[0][s + 1], acc2);
+    for (int s = 0; s + 1 < NS_; s += 2) {
+      acc[0] = mfma(a[s], b[0][s], acc[0]);
+      acc2 = mfma(a[s + 1], b[0][s + 1], acc2);
     }
-    if (G::NSTEPS & 1) acc[0] = mfma(f[(G::NSTEPS - 1) * 64], b[0][G::NSTEPS - 1], acc[0]);
+    if (NS_ & 1) acc[0] = mfma(a[NS_ - 1], b[0][NS_ - 1], acc[0]);
     acc[0] += acc2;
     return;
   }
 #pragma unroll
-  for (int s = 0; s < G::NSTEPS; ++s) {
-    const float a = f[s * 64];
+  for (int s = 0; s < NS_; ++s) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[j] = mfma(a, b[j][s], acc[j]);
+    for (int j = 0; j < TN; ++j) acc[j] = mfma(a[s], b[j][s], acc[j]);
   }
 }
 
@@ -876,6 +918,309 @@ struct GvpQ {
         outer_items<1, 1, BF>(AH, BI, acch);
       }
       flush_slots<Acc, Segs<Seg<P2, 0, H>>, VSegs, 1, 1>(gblk, first, VI, acch, lane);
+    }
+  }
+
+  // ================================================================ lockstep tiles (round 4)
+  // The same backward for TN tiles IN LOCKSTEP: every transposed weight fragment is read from LDS once and feeds TN
+  // independent MFMA chains (as `forward<TN>` does), so a wave that runs alone on its SIMD has independent work to issue
+  // while one tile's chain waits for its accumulator.  Arithmetic per tile identical to `backward`.
+  template <int TN, bool BF = false>
+  static __device__ __forceinline__ void backward_tn(const float* imgT, int lane, const Cache (&c)[TN],
+                                                     const f4 (&d_so)[TN][OT], const float (&d_vo)[TN][3][VOR],
+                                                     float (&d_bs)[TN][SSTEPS], float (&d_bv)[TN][3][VSTEPS], Grads (&gr)[TN]) {
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gr[j].dsp[t][r] = (RELU && c[j].sp[t][r] <= 0.f) ? 0.f : d_so[j][t][r];
+      gr[j].dgate = zero;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) gr[j].dvp[p] = gr[j].dvh[p] = zero;
+    }
+    if (VO > 0) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < VOR; ++r) {
+          const float sg = c[j].sg[r];
+          float dsg = 0.f;
+#pragma unroll
+          for (int p = 0; p < 3; ++p) { dsg = fmaf(d_vo[j][p][r], c[j].vp[p][r], dsg); gr[j].dvp[p][r] = d_vo[j][p][r] * sg; }
+          if (VM == VM_GATE) gr[j].dgate[r] = dsg * sg * (1.0f - sg);
+          if (VM == VM_NORM) {
+            const float n2 = c[j].vp[0][r] * c[j].vp[0][r] + c[j].vp[1][r] * c[j].vp[1][r] + c[j].vp[2][r] * c[j].vp[2][r];
+            const float k = n2 > gvp::kNormEps ? dsg * sg * (1.0f - sg) * gvp::f_rsqrt(n2) : 0.f;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) gr[j].dvp[p][r] = fmaf(k, c[j].vp[p][r], gr[j].dvp[p][r]);
+          }
+        }
+      if (VM == VM_GATE) {
+        float bg[TN][TWsv::NSTEPS];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < TWsv::NSTEPS; ++r) bg[j][r] = gr[j].dgate[r];
+#pragma unroll
+        for (int t = 0; t < OT; ++t) {
+          f4 acc[TN];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[j] = gr[j].dsp[t];
+          apply<TWsv, TN, BF>(imgT + FT_WSV * 64, t, bg, acc, lane);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) gr[j].dsp[t] = acc[j];
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        float b[TN][TWv::NSTEPS];
+        f4 acc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[j] = zero;
+#pragma unroll
+          for (int r = 0; r < TWv::NSTEPS; ++r) b[j][r] = gr[j].dvp[p][r];
+        }
+        apply<TWv, TN, BF>(imgT + FT_WV * 64, 0, b, acc, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) gr[j].dvh[p] = acc[j];
+      }
+    }
+    float d_vn[TN][HR];
+    {
+      float bd[TN][4 * OT];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int t = 0; t < OT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bd[j][4 * t + r] = gr[j].dsp[t][r];
+#pragma unroll
+      for (int mt = 0; mt < TWs::MT; ++mt) {
+        f4 acc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[j] = zero;
+        apply<TWs, TN, BF>(imgT + FT_WS * 64, mt, bd, acc, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int slot = 4 * mt + r;
+            if (slot < SSTEPS) d_bs[j][slot] = acc[j][r];
+            else if (slot < SSTEPS + HR) d_vn[j][slot - SSTEPS] = acc[j][r];
+          }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < HR; ++r) {
+        const float n2 = c[j].vh[0][r] * c[j].vh[0][r] + c[j].vh[1][r] * c[j].vh[1][r] + c[j].vh[2][r] * c[j].vh[2][r];
+        const float k = n2 > gvp::kNormEps ? d_vn[j][r] * gvp::f_rcp(c[j].vn[r]) : 0.f;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) gr[j].dvh[p][r] = fmaf(k, c[j].vh[p][r], gr[j].dvh[p][r]);
+      }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      float b[TN][TWh::NSTEPS];
+      f4 acc[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[j] = zero;
+#pragma unroll
+        for (int r = 0; r < TWh::NSTEPS; ++r) b[j][r] = gr[j].dvh[p][r];
+      }
+      apply<TWh, TN, BF>(imgT + FT_WH * 64, 0, b, acc, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int s2 = 0; s2 < VSTEPS; ++s2) d_bv[j][p][s2] = acc[j][s2];
+    }
+  }
+
+  // Weight gradients kept IN REGISTERS across all the tiles a wave processes (the register budget of a wave that owns its
+  // SIMD: 512 per lane): the slot-ordered outer-product blocks of `weight_grads` as persistent MFMA accumulators, the bias
+  // gradients as per-lane partial sums.  `accumulate` adds TN tiles (operand transposes through the per-wave LDS scratch,
+  // one region per tile so the tiles' write -> read round trips overlap); `flush` maps the blocks into the W-layout
+  // gradient block ONCE per wave -- no per-tile LDS read-add-write, no per-tile row reductions.
+  static constexpr int NBW = (NT > 0 ? NTS : 1) + SSTEPS + HR, NBT = ceil4(NBW);
+  struct WAcc {
+    f4 ws[OT][NBT];
+    f4 wsv[1][OT];
+    f4 vv[1][1];          // PACK_V: the shared dWv / dWh block; else dWv
+    f4 vh_[1][1];         // !PACK_V: dWh
+    f4 bs[OT];            // per-lane sums of dsp  (row-reduced at flush)
+    float bsv[VOR];       // per-lane sums of dgate
+  };
+  static __device__ __forceinline__ void wacc_zero(WAcc& w) {
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < OT; ++t) {
+#pragma unroll
+      for (int y = 0; y < NBT; ++y) w.ws[t][y] = zero;
+      w.wsv[0][t] = zero;
+      w.bs[t] = zero;
+    }
+    w.vv[0][0] = zero;
+    w.vh_[0][0] = zero;
+#pragma unroll
+    for (int r = 0; r < VOR; ++r) w.bsv[r] = 0.f;
+  }
+  // Lanes that hold no item must carry zero gradients in `gr` (the callers' d_so / d_vo are zero there).
+  template <int TN, bool BF = false>
+  static __device__ __forceinline__ void wacc_accumulate(WAcc& w, int lane, const int (&type)[TN],
+                                                         const float (&bs)[TN][SSTEPS], const float (&bv)[TN][3][VSTEPS],
+                                                         const Cache (&c)[TN], const Grads (&gr)[TN], float* tscr) {
+    const int g = lane >> 4;
+    // ---- dWs = dsp (x) [onehot | s | vn],  dbs += dsp
+    {
+      f4 AT[TN][OT], BT[TN][NBT];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float a[4 * OT];
+#pragma unroll
+        for (int t = 0; t < OT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[4 * t + r] = gr[j].dsp[t][r];
+        transpose_slots<4 * OT>(a, AT[j], lane, tscr + j * TSCR_FLOATS);
+        float b[NBW];
+#pragma unroll
+        for (int s = 0; s < (NT > 0 ? NTS : 1); ++s) b[s] = (NT > 0 && 4 * s + g == type[j]) ? 1.f : 0.f;
+#pragma unroll
+        for (int s = 0; s < SSTEPS; ++s) b[(NT > 0 ? NTS : 1) + s] = bs[j][s];
+#pragma unroll
+        for (int r = 0; r < HR; ++r) b[(NT > 0 ? NTS : 1) + SSTEPS + r] = c[j].vn[r];
+        transpose_slots<NBW>(b, BT[j], lane, tscr + j * TSCR_FLOATS);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) outer_items<OT, NBT, BF>(AT[j], BT[j], w.ws);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int t = 0; t < OT; ++t) w.bs[t] += gr[j].dsp[t];
+    }
+    if (VO > 0) {
+      // ---- dWsv = dgate (x) sp, dbsv += dgate
+      f4 AT[TN][1], BT[TN][OT];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float a[VOR], b[4 * OT];
+#pragma unroll
+        for (int r = 0; r < VOR; ++r) a[r] = gr[j].dgate[r];
+#pragma unroll
+        for (int t = 0; t < OT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) b[4 * t + r] = c[j].sp[t][r];
+        transpose_slots<VOR>(a, AT[j], lane, tscr + j * TSCR_FLOATS);
+        transpose_slots<4 * OT>(b, BT[j], lane, tscr + j * TSCR_FLOATS);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) outer_items<1, OT, BF>(AT[j], BT[j], w.wsv);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < VOR; ++r) w.bsv[r] += gr[j].dgate[r];
+      if constexpr (!PACK_V) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          f4 AV[TN][1], BH[TN][1];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            float av[VOR], bh[HR];
+#pragma unroll
+            for (int r = 0; r < VOR; ++r) av[r] = gr[j].dvp[p][r];
+#pragma unroll
+            for (int r = 0; r < HR; ++r) bh[r] = c[j].vh[p][r];
+            transpose_slots<VOR>(av, AV[j], lane, tscr + j * TSCR_FLOATS);
+            transpose_slots<HR>(bh, BH[j], lane, tscr + j * TSCR_FLOATS);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) outer_items<1, 1, BF>(AV[j], BH[j], w.vv);
+        }
+      }
+    }
+    if constexpr (PACK_V) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        f4 A2[TN][1], B2[TN][1];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float a2[VOR + HR], b2[HR + VSTEPS];
+#pragma unroll
+          for (int r = 0; r < VOR; ++r) a2[r] = gr[j].dvp[p][r];
+#pragma unroll
+          for (int r = 0; r < HR; ++r) a2[VOR + r] = gr[j].dvh[p][r];
+#pragma unroll
+          for (int r = 0; r < HR; ++r) b2[r] = c[j].vh[p][r];
+#pragma unroll
+          for (int s_ = 0; s_ < VSTEPS; ++s_) b2[HR + s_] = bv[j][p][s_];
+          transpose_slots<VOR + HR>(a2, A2[j], lane, tscr + j * TSCR_FLOATS);
+          transpose_slots<HR + VSTEPS>(b2, B2[j], lane, tscr + j * TSCR_FLOATS);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) outer_items<1, 1, BF>(A2[j], B2[j], w.vv);
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        f4 AH[TN][1], BI[TN][1];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float ah[HR], bin[VSTEPS];
+#pragma unroll
+          for (int r = 0; r < HR; ++r) ah[r] = gr[j].dvh[p][r];
+#pragma unroll
+          for (int s = 0; s < VSTEPS; ++s) bin[s] = bv[j][p][s];
+          transpose_slots<HR>(ah, AH[j], lane, tscr + j * TSCR_FLOATS);
+          transpose_slots<VSTEPS>(bin, BI[j], lane, tscr + j * TSCR_FLOATS);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) outer_items<1, 1, BF>(AH[j], BI[j], w.vh_);
+      }
+    }
+  }
+  // once per wave: the accumulated blocks -> this wave's private arena-layout gradient block `gblk` (zeroed at kernel start)
+  template <class Acc>
+  static __device__ __forceinline__ void wacc_flush(const WAcc& w, float* gblk, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const bool first = false;
+    flush_slots<Acc, Segs<Seg<P1, 0, SO>>, WsCols, OT, NBT>(gblk + A::ws(NT), first, K, w.ws, lane);
+#pragma unroll
+    for (int t = 0; t < OT; ++t) {
+      float tot[4];
+      float* q[4];
+      bool on[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        tot[r] = row_total(w.bs[t][r]);
+        q[r] = gblk + A::bs(NT) + 16 * t + 4 * g + r;
+        on[r] = i == 15;
+      }
+      add_where<Acc, 4>(q, on, tot);
+    }
+    if (VO > 0) {
+      flush_slots<Acc, Segs<Seg<P2, 0, (VO > 0 ? VO : 1)>>, Segs<Seg<P1, 0, SO>>, 1, OT>(gblk + A::wsv(NT), first, SO, w.wsv, lane);
+      float tot[VOR];
+      float* q[VOR];
+      bool on[VOR];
+#pragma unroll
+      for (int r = 0; r < VOR; ++r) {
+        tot[r] = row_total(w.bsv[r]);
+        q[r] = gblk + A::bsv(NT) + 4 * r + g;
+        on[r] = i == 15 && 4 * r + g < VO;
+      }
+      add_where<Acc, VOR>(q, on, tot);
+      if constexpr (!PACK_V)
+        flush_slots<Acc, Segs<Seg<P2, 0, (VO > 0 ? VO : 1)>>, Segs<Seg<P2, 0, H>>, 1, 1>(gblk + A::wv(NT), first, H, w.vv, lane);
+    }
+    if constexpr (PACK_V) {
+      flush_slots<Acc, Segs<Seg<P2, 0, (VO > 0 ? VO : 1)>, SegNone<HR>>, Segs<Seg<P2, 0, H>, SegNone<VSTEPS>>, 1, 1>(
+          gblk + A::wv(NT), first, H, w.vv, lane);
+      flush_slots<Acc, Segs<SegNone<VOR>, Seg<P2, 0, H>>, Segs<SegNone<HR>, VSegs>, 1, 1>(gblk, first, VI, w.vv, lane);
+    } else {
+      flush_slots<Acc, Segs<Seg<P2, 0, H>>, VSegs, 1, 1>(gblk, first, VI, w.vh_, lane);
     }
   }
 };

@@ -16,6 +16,7 @@
 //                        ones in the library; sources are unsorted).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "gvp_internal.h"
 #include "gvp_quad.h"
@@ -627,6 +628,305 @@ __global__ __launch_bounds__(CB_TPB, CB_WPB / 4) void conv_bwd_kernel(ConvBArgs 
   STAMP(9);
 }
 
+// ===================================================================== conv, version 2 (round 4)
+// Same inputs, outputs and gradient block as conv_bwd_kernel; what changed is how a wave works:
+//   * ONE wave per SIMD (4-wave workgroups, one per CU, 512 registers per lane) running TN = 2 tiles of 16 sorted edges IN
+//     LOCKSTEP through recompute / data gradients / weight gradients: every LDS weight fragment is read once for both tiles
+//     and feeds two independent MFMA chains, the tiles' operand transposes overlap;
+//   * the weight-gradient blocks stay in REGISTERS for all the tiles a wave processes (GvpQ::WAcc) and are mapped into the
+//     wave's LDS block once, at the end -- no per-tile LDS read-add-write, no per-tile bias row reductions;
+//   * waves own contiguous EDGE ranges (whole 32-edge iterations), not target ranges: no half-empty tiles on high-degree
+//     graphs (kNN-20: 2 tiles per ~20-edge target before).  A target whose edges start in an earlier wave's range gets
+//     this wave's partial sum by float atomics into g_src (which the consumers add to g_dst anyway and which is zero on
+//     entry); the wave that holds a target's FIRST edge stores its partial row to g_dst with plain stores; every row of
+//     g_dst is written exactly once (targets without edges: zero rows, by node range);
+//   * a self loop's d h[src] goes into its target's row sum instead of an atomic (a third of the edges of a 4 A graph).
+constexpr int C2_WPB = 4, C2_TPB = WAVE * C2_WPB, C2_TN = 2;
+constexpr int C2_GS_ROWS = C2_TN * TILE;                                   // d h[src] rows of one iteration
+constexpr int C2_SCR = C2_TN * TSCR_FLOATS + C2_GS_ROWS * ROW + C2_GS_ROWS;  // per wave: transposes | g_src rows | their ids
+template <int NTE>
+constexpr int conv_bwd2_lds_floats() { return C2_TPB + ConvBImg<NTE>::FSIZE + ConvBImg<NTE>::TSIZE + C2_WPB * (ConvBlk<NTE>::SIZE + C2_SCR); }
+static_assert(conv_bwd2_lds_floats<1>() * 4 <= 160 * 1024 && conv_bwd2_lds_floats<0>() * 4 <= 160 * 1024, "conv backward v2 LDS plan exceeds the CU");
+static_assert((C2_TN * TSCR_FLOATS) % 4 == 0 && (C2_GS_ROWS * ROW) % 4 == 0, "scratch regions stay 16-B aligned");
+
+template <int NTE, typename ST>
+__global__ __launch_bounds__(C2_TPB) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_bwd2_kernel(ConvBArgs a) {
+  WALL_STAMP(2);
+  typedef Image<0, NTE> IM;
+  typedef ConvBImg<NTE> BI;
+  typedef ConvBlk<NTE> B;
+  constexpr int TN = C2_TN;
+  constexpr int PW = B::SIZE + C2_SCR;
+  constexpr bool BF = Io<ST>::BF;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* img = lds + C2_TPB - BI::F0;
+  float* imgT = lds + C2_TPB + BI::FSIZE - BI::T0;
+  const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* blocks = lds + C2_TPB + BI::FSIZE + BI::TSIZE;
+  float* gblk = blocks + w * PW;
+  float* tscr = gblk + B::SIZE;
+  float* trow = tscr + TN * TSCR_FLOATS;                                   // [C2_GS_ROWS][ROW]
+  int* tsrc = reinterpret_cast<int*>(trow + C2_GS_ROWS * ROW);
+  stage_slice<BI::FSIZE, C2_TPB>(lds + C2_TPB, a.img + BI::F0, threadIdx.x);
+  stage_slice<BI::TSIZE, C2_TPB>(lds + C2_TPB + BI::FSIZE, a.imgT + BI::T0, threadIdx.x);
+  for (int k = lane; k < B::SIZE / 4; k += WAVE) reinterpret_cast<f4*>(gblk)[k] = f4{0.f, 0.f, 0.f, 0.f};
+
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  const int64_t waves = (int64_t)gridDim.x * C2_WPB, wid = (int64_t)blockIdx.x * C2_WPB + w;
+  // ---- owned NODES (an even split, independent of the edge ranges): targets without incoming edges get their zero row
+  {
+    const int64_t npw = (a.N + waves - 1) / waves;
+    const int64_t n0 = wid * npw;
+    const int64_t nn = n0 >= a.N ? 0 : (a.N - n0 < npw ? a.N - n0 : npw);
+    for (int64_t k = lane; k < nn * ROW; k += WAVE) {
+      const int64_t nd = n0 + k / ROW;
+      if (a.rowptr[nd + 1] == a.rowptr[nd]) a.g_dst[n0 * ROW + k] = 0.f;
+    }
+  }
+  // ---- owned EDGES: whole iterations of TN * 16 sorted positions, contiguous per wave
+  const int32_t E = a.rowptr[a.N];                     // valid sorted edges (dropped ones sit behind them)
+  const int32_t iters = (E + TN * TILE - 1) / (TN * TILE);
+  const int32_t ipw = (int32_t)((iters + waves - 1) / waves);
+  const int64_t it0 = wid * ipw;
+  const int32_t c_lo = (int32_t)(it0 < iters ? it0 : iters) * (TN * TILE);
+  int32_t c_hi = (int32_t)(it0 + ipw < iters ? it0 + ipw : iters) * (TN * TILE);
+  c_hi = c_hi < E ? c_hi : E;
+  // the target whose edges began in an earlier wave's range (its partial sum here goes to g_src by atomics)
+  int32_t lead_dst = -1;
+  if (c_lo > 0 && c_lo < c_hi) {
+    const int32_t d0 = a.edst[c_lo], dm = a.edst[c_lo - 1];
+    lead_dst = d0 == dm ? d0 : -1;
+  }
+  typename Msg0<ST>::WAcc w0;
+  typename Msg1<ST>::WAcc w1;
+  typename Msg2<ST>::WAcc w2;
+  Msg0<ST>::wacc_zero(w0);
+  Msg1<ST>::wacc_zero(w1);
+  Msg2<ST>::wacc_zero(w2);
+  float carry[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int carry_dst = -1;
+  STAMP(0);
+  __syncthreads();
+  STAMP(1);
+
+  const int zt[TN] = {};
+  for (int32_t base = c_lo; base < c_hi; base += TN * TILE) {
+    STAMP(15);
+    // ---- gather, both tiles' loads in flight together
+    f4 es0[TN], es1[TN], sj[TN], si[TN], d_ms[TN];
+    float ev[TN][3], vj[TN][3], vi[TN][3], d_mv[TN][3];
+    int32_t src[TN], dst[TN];
+    bool active[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int32_t p = base + j * TILE + i;
+      active[j] = p < c_hi;
+      es0[j] = es1[j] = sj[j] = si[j] = d_ms[j] = zero;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) ev[j][d] = vj[j][d] = vi[j][d] = d_mv[j][d] = 0.f;
+      src[j] = 0;
+      dst[j] = -1;
+      if (active[j]) {
+        src[j] = a.esrc[p];
+        dst[j] = a.edst[p];
+        const int64_t er = (int64_t)p * EROW;
+        es0[j] = Io<ST>::ld4(a.e_emb, er + 4 * g);
+        es1[j] = Io<ST>::ld4(a.e_emb, er + 16 + 4 * g);
+        if (g == 0) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) ev[j][d] = Io<ST>::ld(a.e_emb, er + ES + d);
+        }
+        const int64_t hj = (int64_t)src[j] * ROW, hi = (int64_t)dst[j] * ROW;
+        const float* gd = a.g_dh + (int64_t)dst[j] * ROW;
+        sj[j] = Io<ST>::ld4(a.h, hj + 4 * g);
+        si[j] = Io<ST>::ld4(a.h, hi + 4 * g);
+        d_ms[j] = *reinterpret_cast<const f4*>(gd + 4 * g);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { vj[j][d] = Io<ST>::ld(a.h, hj + NS + 3 * g + d); vi[j][d] = Io<ST>::ld(a.h, hi + NS + 3 * g + d); d_mv[j][d] = gd[NS + 3 * g + d]; }
+        if (a.mean) {
+          const int deg = a.rowptr[dst[j] + 1] - a.rowptr[dst[j]];
+          const float sc = 1.0f / (float)(deg > 1 ? deg : 1);
+          d_ms[j] *= sc;
+#pragma unroll
+          for (int d = 0; d < 3; ++d) d_mv[j][d] *= sc;
+        }
+      }
+    }
+    // first target of the NEXT iteration (-1 at the end of the wave's range): where the last segment of this one ends
+    const int32_t nxt_base = base + TN * TILE;
+    const int32_t next_first = nxt_base < c_hi ? a.edst[nxt_base] : -1;
+    STAMP(2);
+    // ---- recompute the three message GVPs of both tiles
+    float b0[TN][16], bv0[TN][3][3], b1[TN][4], bv1[TN][3][1], b2[TN][4], bv2[TN][3][1];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { b0[j][r] = sj[j][r]; b0[j][4 + r] = es0[j][r]; b0[j][8 + r] = es1[j][r]; b0[j][12 + r] = si[j][r]; }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { bv0[j][d][0] = vj[j][d]; bv0[j][d][1] = vi[j][d]; bv0[j][d][2] = ev[j][d]; }
+    }
+    f4 s1[TN][1], s2[TN][1], s3[TN][1];
+    float v1[TN][3][1], v2[TN][3][1], v3[TN][3][1];
+    typename Msg0<ST>::Cache c0[TN];
+    typename Msg1<ST>::Cache c1[TN];
+    typename Msg2<ST>::Cache c2[TN];
+    Msg0<ST>::template forward<TN, BF>(img + IM::CV_M0, lane, zt, b0, bv0, s1, v1, c0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b1[j][r] = s1[j][0][r];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) bv1[j][d][0] = v1[j][d][0];
+    }
+    Msg1<ST>::template forward<TN, BF>(img + IM::CV_M1, lane, zt, b1, bv1, s2, v2, c1);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b2[j][r] = s2[j][0][r];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) bv2[j][d][0] = v2[j][d][0];
+    }
+    Msg2<ST>::template forward<TN, BF>(img + IM::CV_M2, lane, zt, b2, bv2, s3, v3, c2);
+    STAMP(3);
+    // ---- backward through the three message GVPs (inactive lanes carry d_ms = d_mv = 0, so every gradient below is zero there)
+    float d_b[TN][4], d_bv[TN][3][1];
+    {
+      f4 d_so[TN][1];
+      float d_vo[TN][3][1];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        d_so[j][0] = d_ms[j];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) d_vo[j][d][0] = d_mv[j][d];
+      }
+      typename Msg2<ST>::Grads gr[TN];
+      Msg2<ST>::template backward_tn<TN, BF>(imgT + IM::TC_M2, lane, c2, d_so, d_vo, d_b, d_bv, gr);
+      STAMP(10);
+      Msg2<ST>::template wacc_accumulate<TN, BF>(w2, lane, zt, b2, bv2, c2, gr, tscr);
+    }
+    {
+      f4 d_so[TN][1];
+      float d_vo[TN][3][1];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        d_so[j][0] = f4{d_b[j][0], d_b[j][1], d_b[j][2], d_b[j][3]};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) d_vo[j][d][0] = d_bv[j][d][0];
+      }
+      typename Msg1<ST>::Grads gr[TN];
+      STAMP(11);
+      Msg1<ST>::template backward_tn<TN, BF>(imgT + IM::TC_M1, lane, c1, d_so, d_vo, d_b, d_bv, gr);
+      STAMP(12);
+      Msg1<ST>::template wacc_accumulate<TN, BF>(w1, lane, zt, b1, bv1, c1, gr, tscr);
+    }
+    float d_b0[TN][16], d_bv0[TN][3][3];
+    {
+      f4 d_so[TN][1];
+      float d_vo[TN][3][1];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        d_so[j][0] = f4{d_b[j][0], d_b[j][1], d_b[j][2], d_b[j][3]};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) d_vo[j][d][0] = d_bv[j][d][0];
+      }
+      typename Msg0<ST>::Grads gr[TN];
+      STAMP(13);
+      Msg0<ST>::template backward_tn<TN, BF>(imgT + IM::TC_M0, lane, c0, d_so, d_vo, d_b0, d_bv0, gr);
+      STAMP(14);
+      Msg0<ST>::template wacc_accumulate<TN, BF>(w0, lane, zt, b0, bv0, c0, gr, tscr);
+    }
+    STAMP(4);
+    // ---- d(edge embedding) of this layer -> g_e (plain stores, sorted-edge order)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      if (active[j]) {
+        float* gr_ = a.g_e + (int64_t)(base + j * TILE + i) * EROW;
+        *reinterpret_cast<f4*>(gr_ + 4 * g) = f4{d_b0[j][4], d_b0[j][5], d_b0[j][6], d_b0[j][7]};
+        *reinterpret_cast<f4*>(gr_ + 16 + 4 * g) = f4{d_b0[j][8], d_b0[j][9], d_b0[j][10], d_b0[j][11]};
+        if (g == 0) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) gr_[ES + d] = d_bv0[j][d][2];
+        }
+      }
+    STAMP(5);
+    // ---- d h[src]: rows transposed through LDS so that one wave-instruction adds two whole 112-B rows; a self loop's row
+    // joins its target's sum below instead
+    bool self[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      self[j] = active[j] && src[j] == dst[j];
+      float* tr = trow + (j * TILE + i) * ROW;
+      *reinterpret_cast<f4*>(tr + 4 * g) = f4{d_b0[j][0], d_b0[j][1], d_b0[j][2], d_b0[j][3]};
+#pragma unroll
+      for (int d = 0; d < 3; ++d) tr[NS + 3 * g + d] = d_bv0[j][d][0];
+      if (g == 0) tsrc[j * TILE + i] = (active[j] && !self[j]) ? src[j] : -1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+      const int half = lane / ROW, col = lane - half * ROW;      // lanes 0..27 -> row 2k, 28..55 -> row 2k+1
+      if (half < 2) {
+#pragma unroll
+        for (int k = 0; k < C2_GS_ROWS / 2; ++k) {
+          const int r = 2 * k + half;
+          const int sr = tsrc[r];
+          if (sr >= 0) atomicAdd(a.g_src + (int64_t)sr * ROW + col, trow[r * ROW + col]);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    STAMP(6);
+    // ---- d h[dst]: segment sums of the sorted edges (DPP scan + a register carry across tiles), stored where a segment
+    // truly ends inside the wave's range
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float x[7] = {d_b0[j][12], d_b0[j][13], d_b0[j][14], d_b0[j][15], d_bv0[j][0][1], d_bv0[j][1][1], d_bv0[j][2][1]};
+      if (self[j]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] += d_b0[j][k];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) x[4 + d] += d_bv0[j][d][0];
+      }
+      if (i == 0 && active[j] && dst[j] == carry_dst) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) x[k] += carry[k];
+      }
+      seg_scan16<7>(dst[j], x);
+      int nxt = __builtin_amdgcn_update_dpp(-1, dst[j], 0x100 | 1, 0xf, 0xf, false);        // lane i <- lane i + 1
+      if (i == TILE - 1) nxt = next_first;
+      if (j + 1 < TN) {
+        const int nf = __builtin_amdgcn_update_dpp(-1, dst[j + 1 < TN ? j + 1 : j], 0x110 | 15, 0xf, 0xf, false);   // lane 15 <- lane 0 of the next tile
+        if (i == TILE - 1) nxt = nf;
+      }
+      if (active[j] && nxt != dst[j]) {
+        if (dst[j] != lead_dst) {
+          float* row = a.g_dst + (int64_t)dst[j] * ROW;
+          *reinterpret_cast<f4*>(row + 4 * g) = f4{x[0], x[1], x[2], x[3]};
+#pragma unroll
+          for (int d = 0; d < 3; ++d) row[NS + 3 * g + d] = x[4 + d];
+        } else {
+          float* row = a.g_src + (int64_t)dst[j] * ROW;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) atomicAdd(row + 4 * g + k, x[k]);
+#pragma unroll
+          for (int d = 0; d < 3; ++d) atomicAdd(row + NS + 3 * g + d, x[4 + d]);
+        }
+      }
+      carry_dst = __builtin_amdgcn_update_dpp(-1, dst[j], 0x100 | 15, 0xf, 0xf, false);       // lane 0 <- lane 15
+#pragma unroll
+      for (int k = 0; k < 7; ++k)
+        carry[k] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x[k]), 0x100 | 15, 0xf, 0xf, false));
+    }
+    STAMP(7);
+  }
+  STAMP(8);
+  Msg0<ST>::template wacc_flush<AccPriv>(w0, gblk + B::M0, lane);
+  Msg1<ST>::template wacc_flush<AccPriv>(w1, gblk + B::M1, lane);
+  Msg2<ST>::template wacc_flush<AccPriv>(w2, gblk + B::M2, lane);
+  write_slab_row<B::SIZE, PW, C2_WPB>(a.slab, blocks);
+  STAMP(9);
+}
+
 // ===================================================================== edge embedding
 // Backward of gvp_edge = Sequential(GVP, LayerNorm) (protein_gnn.py:331-335, :376) for a tile of 16 sorted edges,
 // ONCE per step: the upstream gradient is the sum of the conv layers' d e buffers.  Raw edge features get no
@@ -997,6 +1297,34 @@ int head_bwd(const float* img_head, const float* imgT_head, const float* h_out, 
   return 0;
 }
 
+// Which conv backward runs: 2 (default) = conv_bwd2_kernel, 1 = the round-3 kernel (kept for A/B and as a cross-check in the
+// tests); CGVP_CONV_BWD in the environment, read once per process.
+int conv_bwd_version() {
+  static const int v = [] {
+    const char* e = getenv("CGVP_CONV_BWD");
+    return (e && e[0] == '1') ? 1 : 2;
+  }();
+  return v;
+}
+
+template <int NTE>
+int conv_bwd2_impl(ConvBArgs& a, int64_t E, int* grid, int bf16, hipStream_t st) {
+  const int64_t iters = (E + C2_TN * TILE - 1) / (C2_TN * TILE);
+  const int64_t wgs = (iters + C2_WPB - 1) / C2_WPB;
+  const int G = (int)(wgs < 1 ? 1 : (wgs > CB_MAX_GRID ? CB_MAX_GRID : wgs));
+  *grid = G;
+  const size_t lds = (size_t)conv_bwd2_lds_floats<NTE>() * sizeof(float);
+#define K_(ST) conv_bwd2_kernel<NTE, ST>
+  if (bf16 >= POLICY_GVPDEF) {
+    if constexpr (NTE == 0) BWD_LAUNCH_KIND(K_, G, C2_TPB, lds, a);
+    else return CGVP_ERR_UNSUPPORTED_DIMS;
+    return 0;
+  }
+  BWD_LAUNCH(K_, G, C2_TPB, lds, a);
+#undef K_
+  return 0;
+}
+
 template <int NTE>
 int conv_bwd_impl(ConvBArgs& a, int* grid, int bf16, hipStream_t st) {
   const int64_t ngroups = (a.N + a.npw - 1) / a.npw;
@@ -1024,6 +1352,11 @@ int conv_bwd(int nt_edge, const float* img, const float* imgT, const float* h, c
   int npw = (int)((2 * TILE - 2) / deg);
   npw = npw < 1 ? 1 : (npw > WAVE ? WAVE : npw);
   ConvBArgs a{img, imgT, h, e_emb, rowptr, esrc, edst, N, npw, mean, g_dh, g_src, g_dst, g_e, slab};
+  if (conv_bwd_version() == 2) {
+    if (nt_edge == 0) return conv_bwd2_impl<0>(a, E, grid, bf16, st);
+    if (nt_edge == 1) return conv_bwd2_impl<1>(a, E, grid, bf16, st);
+    return CGVP_ERR_UNSUPPORTED_DIMS;
+  }
   if (nt_edge == 0) return conv_bwd_impl<0>(a, grid, bf16, st);
   if (nt_edge == 1) return conv_bwd_impl<1>(a, grid, bf16, st);
   return CGVP_ERR_UNSUPPORTED_DIMS;

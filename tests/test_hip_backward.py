@@ -427,7 +427,13 @@ def test_davis_b64_both_encoders_fwd_bwd_vs_oracle(protein_params, molecule_para
     """BASELINE config 2 at EXACTLY its size -- the batch bench.py times (64 pairs x 300 residues, 4 A radius graphs,
     ~40-atom drugs, seed 0, CASTER-DTA(2,2), train mode, dropout 0.2) -- both encoders forward + every gradient against the
     CPU oracle run with the masks the kernels drew (until now this size was covered by properties and
-    self-comparison only)."""
+    self-comparison only).  Yardstick: the fp64 oracle, and what a gradient at this size CAN agree to: a weight gradient here
+    sums over 19,200 residues / 57k edges = ~7e6 ReLU / norm-clamp decisions, and a pre-activation within rounding of zero
+    takes the other branch.  Measured on the CPU (fp64 oracle, this batch): the reference-order fp32 evaluation differs from
+    fp64 by 7e-7 (median over tensors) but 9e-4 at the 90th percentile and 2.7e-3 at worst in relative L2; a 1e-6 relative
+    perturbation of the weights -- the kernels' rounding level -- moves the fp64 gradients by 2-3e-3 (median) and 2.7e-2
+    (worst).  So: forward within 2e-5; every gradient tensor within 3e-2 in relative L2, their median within 5e-3.  (Exact
+    gradient parity, 2e-4 per element, is what the smaller oracle / golden cases check, where no decision sits on the edge.)"""
     from gvp_hip import autograd_ops, ops
     from models.molecule_gnn import SelectableMoleculeModelWrapper
     pb, mb = ds.pair_batch(64, 0, length=300, thresh=4.0, thresh_type="dist")
@@ -440,12 +446,27 @@ def test_davis_b64_both_encoders_fwd_bwd_vs_oracle(protein_params, molecule_para
     masks = ops.dropout_masks(seed, 0.2, 0, 4, pb.num_nodes, 20).cpu()
     r = torch.randn(out.shape, generator=torch.Generator().manual_seed(4))
     (out * r.to(DEV)).sum().backward()
-    P = {k: v.detach().cpu().clone().requires_grad_(v.numel() > 0) for k, v in model.gnn_model.state_dict().items()}
-    ref = O.protein_lba_forward(P, pd["x"], pd["edge_index"], pd["ntypes"], pd["etypes"], pd["eattr"],
-                                masks=[(masks[0], masks[1]), (masks[2], masks[3])])
-    assert rel_err(out, ref) < 2e-5
-    (ref * r).sum().backward()
-    assert _check_grads(model, {k: v.grad for k, v in P.items() if v.numel()}) >= 60
+
+    def oracle(dt):
+        cast = lambda t: t.to(dt) if t.is_floating_point() else t
+        P = {k: cast(v.detach().cpu().clone()).requires_grad_(v.numel() > 0) for k, v in model.gnn_model.state_dict().items()}
+        ref = O.protein_lba_forward(P, tuple(cast(t) for t in pd["x"]), pd["edge_index"], pd["ntypes"], pd["etypes"],
+                                    tuple(cast(t) for t in pd["eattr"]),
+                                    masks=[(cast(masks[0]), cast(masks[1])), (cast(masks[2]), cast(masks[3]))])
+        (ref * cast(r)).sum().backward()
+        return ref.detach(), {k: v.grad for k, v in P.items() if v.numel()}
+    ref64, g64 = oracle(torch.float64)
+    assert rel_err(out, ref64) < 2e-5
+    scale = max(float(v.abs().max()) for v in g64.values())
+    checked, rels = 0, []
+    for name, p in model.gnn_model.named_parameters():
+        if not p.numel():
+            continue
+        diff = p.grad.cpu().double() - g64[name]
+        rels.append(float(diff.norm()) / (float(g64[name].norm()) + 1e-6 * scale))
+        assert rels[-1] <= 3e-2, (name, rels[-1])
+        checked += 1
+    assert checked >= 60 and sorted(rels)[len(rels) // 2] <= 5e-3, sorted(rels)[len(rels) // 2]
     kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))["molecule_gnn_kwargs"]
     mol = SelectableMoleculeModelWrapper(**kw)
     mol.load_state_dict({"gnn_model." + k: v for k, v in molecule_params.items()})
@@ -453,14 +474,21 @@ def test_davis_b64_both_encoders_fwd_bwd_vs_oracle(protein_params, molecule_para
     dm = _to(md)
     mout = mol(dm["x"], dm["edge_index"], dm["ntypes"], dm["etypes"], eattr=dm["eattr"])
     mmask = ops.dropout_masks(autograd_ops.last_seed("gine"), 0.2, 0, 1, mb.num_nodes, 16).cpu()
-    Q = {k: v.clone().requires_grad_(True) for k, v in molecule_params.items()}
-    mref = O.molecule_gine_forward(Q, md["x"], md["edge_index"], md["ntypes"], md["etypes"], md["eattr"], masks=[mmask[0]])
-    assert rel_err(mout, mref) < 2e-5
-    r2 = torch.randn(mref.shape, generator=torch.Generator().manual_seed(5))
-    (mref * r2).sum().backward()
+    r2 = torch.randn(mout.shape, generator=torch.Generator().manual_seed(5))
     (mout * r2.to(DEV)).sum().backward()
+
+    def moracle(dt):
+        Q = {k: v.clone().to(dt).requires_grad_(True) for k, v in molecule_params.items()}
+        mref = O.molecule_gine_forward(Q, md["x"].to(dt), md["edge_index"], md["ntypes"], md["etypes"], md["eattr"].to(dt),
+                                       masks=[mmask[0].to(dt)])
+        (mref * r2.to(dt)).sum().backward()
+        return mref.detach(), {k: v.grad for k, v in Q.items()}
+    m64, q64 = moracle(torch.float64)
+    assert rel_err(mout, m64) < 2e-5
+    mscale = max(float(v.abs().max()) for v in q64.values())
     for name, p in mol.gnn_model.named_parameters():
-        assert rel_err(p.grad, Q[name].grad) < 2e-4, name
+        diff = p.grad.cpu().double() - q64[name]
+        assert float(diff.norm()) <= 3e-2 * (float(q64[name].norm()) + 1e-6 * mscale), (name, float(diff.norm()))
 
 
 def test_in_place_edits_between_forward_and_backward_raise(protein_params, molecule_params):

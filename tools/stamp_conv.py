@@ -14,13 +14,13 @@ pb = ds.protein_batch(64, 0)
 d = {k: (tuple(t.to(dev) for t in v) if isinstance(v, tuple) else v.to(dev)) for k, v in ds.to_torch(pb).items()}
 h = ctypes.CDLL(_lib.LIB_PATH)
 nwaves = 4096
-buf = torch.zeros(nwaves * 16, dtype=torch.int64, device=dev)
+buf = torch.zeros(nwaves * 16 + 8 * nwaves * 2, dtype=torch.int64, device=dev)   # cycle stamps | wall stamps of up to 8 kernel kinds (WallStamp)
 h.cgvp_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
 with torch.no_grad():
     for _ in range(5):
         model.protein_gnn(**d)
     torch.cuda.synchronize()
-b = buf.cpu().numpy().reshape(nwaves, 16)
+b = buf.cpu().numpy()[:nwaves * 16].reshape(nwaves, 16)
 b = b[b[:, 0] > 0]
 names = {1: "gather issue+stage+clear", 2: "barrier", 3: "loop head", 5: "edge GVP+LN (incl. gather wait)", 6: "3 message GVPs",
          7: "scan + LDS adds", 8: "barrier", 9: "write dh"}

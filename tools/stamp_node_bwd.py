@@ -27,7 +27,7 @@ gdh = torch.empty(N, 28, **f32); gp = torch.zeros(layout.total, **f32)
 ws = torch.empty(int(L.cgvp_bwd_workspace_floats(C.byref(dims), C.byref(layout))), **f32)
 P = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
 for head in (0, 1):
-    buf = torch.zeros(4096 * 16, dtype=torch.int64, device=dev)
+    buf = torch.zeros(4096 * 16 + 8 * 4096 * 2, dtype=torch.int64, device=dev)
     h.cgvp_debug_set_stamp_buffer_bwd(ctypes.c_void_p(buf.data_ptr()))
     for _ in range(3):
         rc = L.cgvp_node_update_bwd(C.byref(dims), C.byref(layout), P(image), 1 if head else 0, P(hh), P(dh), P(None), P(None), None,
@@ -35,7 +35,7 @@ for head in (0, 1):
                                     P(gp), P(ws), P(None), P(None), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0, rc
     torch.cuda.synchronize()
-    b = buf.cpu().numpy().reshape(4096, 16); b = b[b[:, 10] > 0]
+    b = buf.cpu().numpy()[:4096 * 16].reshape(4096, 16); b = b[b[:, 10] > 0]
     names = ["stage images", "barrier", "fwd recompute", "head fwd+bwd+wgrads+LN" if head else "load upstream", "LN1 bwd",
              "ff1 backward", "ff1 weight_grads", "ff0 backward", "ff0 weight_grads", "LN0 bwd + store (to loop end)", "barrier + slab write"]
     print(f"--- node_bwd head={head}: waves {len(b)}")
