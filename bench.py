@@ -104,11 +104,12 @@ def parse():
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
                     help="activation storage of the protein encoder (bf16 = BASELINE config 5: bf16 storage / fp32 "
                          "accumulate; gradients and weights stay fp32; the drug encoder stays fp32 storage)")
-    ap.add_argument("--epoch", default="nominal", choices=["off", "nominal", "real"],
+    ap.add_argument("--epoch", default="both", choices=["off", "nominal", "real", "both"],
                     help="second leg (N = 1, --scope encoders, davis_b64 only): ONE EPOCH the way train_model.py:548-587 drives "
                          "the model -- 329 DIFFERENT batches of 64 pairs drawn from 442 unique proteins x 68 unique drugs (the "
                          "Davis table sizes), a new edge_index every step, eager (no HIP graph); 'nominal' = 300-residue "
-                         "proteins, 'real' = lengths drawn from the Davis sequence-length table; reported in config.epoch")
+                         "proteins, 'real' = lengths drawn from the Davis sequence-length table (mean 789), 'both' (default) = the "
+                         "nominal epoch in config.epoch and the real-length one (eager + bucketed legs) in config.epoch_real")
     ap.add_argument("--epoch-steps", type=int, default=329, help="batches in the epoch leg (Davis: 21,039 train pairs / 64)")
     ap.add_argument("--cpu-runs", type=int, default=20, help="timed CPU-baseline runs per thread count (median)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (0 = choose for ~10-30 s)")
@@ -540,10 +541,15 @@ def main():
             collate = None
             ops.CSR_CACHE_ENABLED = old_cache
 
-    epoch = None
+    epoch = epoch_real = None
     if rank == 0 and world == 1 and args.epoch != "off" and args.scope == "encoders" and args.workload == "davis_b64" \
             and args.only is None and not collectives:
-        epoch = epoch_leg(args, model, dev, train, prot_params, drug_params)
+        if args.epoch in ("real", "both"):                       # first: its fused-parameters leg (nominal only) cannot be undone
+            epoch_real = epoch_leg(args, model, dev, train, prot_params, drug_params, variant="real", light=args.epoch == "both")
+        if args.epoch in ("nominal", "both"):
+            epoch = epoch_leg(args, model, dev, train, prot_params, drug_params, variant="nominal")
+        elif args.epoch == "real":
+            epoch, epoch_real = epoch_real, None
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # a reported baseline of the N = 1 line only
@@ -576,7 +582,7 @@ def main():
                        "baseline_config": args.config, "rccl_ranks": (dist.get_world_size() if (dist is not None and not rehearsal) else 0),
                        "timed_region": ("replays of ONE captured step on one batch (CSR build, dropout draw and weight-image build "
                                         "inside every replay)" if graph is not None else "eager steps on one batch"),
-                       "collated_csr": collated, "epoch": epoch},
+                       "collated_csr": collated, "epoch": epoch, "epoch_real": epoch_real},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
@@ -584,7 +590,7 @@ def main():
         dist.destroy_process_group()
 
 
-def epoch_leg(args, model, dev, train, prot_params, drug_params):
+def epoch_leg(args, model, dev, train, prot_params, drug_params, variant="nominal", light=False):
     """BASELINE config 2 as stated ("Davis full epoch ... batch 64"): every step a DIFFERENT batch -- other proteins, other
     N / E, a new edge_index -- launched eagerly through the nn.Module API, exactly the call pattern of
     train_model.py:548-587 (forward of both encoders, backward with every weight gradient, dropout on).  The batches are
@@ -595,7 +601,7 @@ def epoch_leg(args, model, dev, train, prot_params, drug_params):
     import davis_synth as ds
     rng = np.random.default_rng(2024)
     n_prot, n_drug, B, steps = 442, 68, 64, args.epoch_steps
-    if args.epoch == "real":
+    if variant == "real":
         lengths = ds.real_lengths("davis", n_prot, seed=7)
     else:
         lengths = [300] * n_prot
@@ -622,7 +628,7 @@ def epoch_leg(args, model, dev, train, prot_params, drug_params):
                   eattr=torch.cat([D[i]["ea"] for i in di]))
         if args.dtype == "bf16":
             pd = dict(pd, x=tuple(t.bfloat16() for t in pd["x"]), eattr=tuple(t.bfloat16() for t in pd["eattr"]))
-        batches.append((pd, md, int(off[-1]), int(doff[-1])))
+        batches.append((pd, md, int(off[-1]), int(doff[-1]), torch.as_tensor(off).to(dev), torch.as_tensor(doff).to(dev)))
     maxn, maxa = max(b[2] for b in batches), max(b[3] for b in batches)
     gen = torch.Generator(device=dev).manual_seed(99)
     g_res = torch.randn(maxn, 64, device=dev, generator=gen)
@@ -633,7 +639,7 @@ def epoch_leg(args, model, dev, train, prot_params, drug_params):
     t_gen = time.perf_counter() - t_gen
     side = torch.cuda.Stream(device=dev)
 
-    def step(pd, md, n, na):
+    def step(pd, md, n, na, *_):
         main_s = torch.cuda.current_stream()
         side.wait_stream(main_s)
         residues = model.protein_gnn(**pd)
@@ -642,22 +648,31 @@ def epoch_leg(args, model, dev, train, prot_params, drug_params):
         if not train:
             main_s.wait_stream(side)
             return residues, atoms
-        gp = torch.autograd.grad([residues], prot_params, [g_res[:n]])
-        with torch.cuda.stream(side):
-            gd = torch.autograd.grad([atoms], drug_params, [g_atm[:na]])
+        # what `loss.backward()` (train_model.py:570) does to the encoders: one backward pass in ACCUMULATE mode (every
+        # parameter's .grad is set; each node runs on its forward's stream), then the reset optimizer.zero_grad() does
+        torch.autograd.backward([residues, atoms], [g_res[:n], g_atm[:na]])
         main_s.wait_stream(side)
-        return gp + gd
+        for q in enc_leaves:
+            q.grad = None
 
+    enc_leaves = list(prot_params) + list(drug_params)
+    from gvp_hip import _lib as _l
+    br = _l.bridge()
     with torch.set_grad_enabled(train):
         for b in batches[:MIN_WARMUP]:
             step(*b)
         torch.cuda.synchronize()
+        fast0 = br.fast_leaf_passes() if br is not None else 0
         t0 = time.perf_counter()
         for b in batches:
             step(*b)
         t_issue = time.perf_counter() - t0
         torch.cuda.synchronize()
         t_all = time.perf_counter() - t0
+        fast_passes = (br.fast_leaf_passes() - fast0) if br is not None else 0
+    # ---- the WHOLE model over the same epoch (encoders + cross-attention head + MSE loss, all 764k gradients):
+    # eager `loss.backward()` and shape-bucketed whole-step graphs (gvp_hip.graphed.GraphedTrainStep)
+    joint = joint_epoch(args, model, dev, batches, B, steps) if (train and args.dtype != "bf16" and not light) else None
     # ---- the same epoch replayed from shape-bucketed HIP graphs (gvp_hip.graphed): per step ONE staging launch that
     # copies the batch into the bucket's padded static buffers + one graph replay
     graphed = None
@@ -687,10 +702,11 @@ def epoch_leg(args, model, dev, train, prot_params, drug_params):
     # (JointGNN.fuse_encoder_parameters, opt-in): what the 74 per-tensor leaves cost on the host.  Last: cannot be undone.
     fused = None
     gm = model.protein_gnn.gnn_model
-    if train and args.dtype != "bf16" and getattr(gm, "_onehot_ntypes", False) and gm._onehot_etypes:
+    if train and not light and args.dtype != "bf16" and getattr(gm, "_onehot_ntypes", False) and gm._onehot_etypes:
         model.fuse_encoder_parameters()
         prot_params = [p for p in model.protein_gnn.parameters() if p.numel()]
         drug_params = [p for p in model.molecule_gnn.parameters() if p.numel()]
+        enc_leaves[:] = list(prot_params) + list(drug_params)
         with torch.set_grad_enabled(True):
             for b in batches[:MIN_WARMUP]:
                 step(*b)
@@ -706,15 +722,64 @@ def epoch_leg(args, model, dev, train, prot_params, drug_params):
                  "ms_per_step": round(t_fa / steps * 1e3, 4), "host_issue_ms_per_step": round(t_fi / steps * 1e3, 4),
                  "pairs_per_s": round(B * steps / t_fa, 1)}
     edges = [int(b[0]["edge_index"].shape[1]) for b in batches]
-    ret_extra = {"eager_fused_parameters": fused}
-    return {**_epoch_summary(args, steps, B, n_prot, n_drug, t_all, t_issue, batches, edges, t_gen, graphed), **ret_extra}
+    ret_extra = {"eager_fused_parameters": fused, "joint": joint,
+                 # backward passes of the eager leg whose node wrote the leaves' .grad itself (csrc/torch_bridge.cpp LeafScatter)
+                 "eager_backward_passes_without_leaf_tasks": int(fast_passes)}
+    return {**_epoch_summary(args, variant, steps, B, n_prot, n_drug, t_all, t_issue, batches, edges, t_gen, graphed), **ret_extra}
 
 
-def _epoch_summary(args, steps, B, n_prot, n_drug, t_all, t_issue, batches, edges, t_gen, graphed):
-    return {"what": "one epoch of DIFFERENT batches, eager (no HIP graph), nn.Module API, C++ autograd fast path" if
+def joint_epoch(args, model, dev, batches, B, steps):
+    """The loop of train_model.py:548-587 at MODEL scope over the epoch's different batches: forward of the whole JointGNN,
+    MSE loss, backward -- (a) eagerly through the nn.Module API with `loss.backward()` + the optimizer's gradient reset,
+    (b) from shape-bucketed whole-step HIP graphs (one staging launch + one replay per step)."""
+    from gvp_hip.graphed import GraphedTrainStep
+    gen = torch.Generator(device=dev).manual_seed(7)
+    target = torch.randn(B, 1, device=dev, generator=gen)
+    loss_fn = torch.nn.functional.mse_loss
+    dicts = [(dict(b[0], ptr=b[4]), dict(b[1], ptr=b[5])) for b in batches]
+
+    def eager(pd, md):
+        pred, _ = model(pd, md)
+        loss_fn(pred, target).backward()
+        model.zero_grad(set_to_none=True)
+
+    out = {}
+    with torch.enable_grad():
+        for pd, md in dicts[:MIN_WARMUP]:
+            eager(pd, md)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for pd, md in dicts:
+            eager(pd, md)
+        t_i = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t_a = time.perf_counter() - t0
+        out["eager"] = {"what": "model(pdata, mdata) -> mse_loss -> loss.backward() -> zero_grad(), every step a different batch",
+                        "ms_per_step": round(t_a / steps * 1e3, 4), "host_issue_ms_per_step": round(t_i / steps * 1e3, 4),
+                        "pairs_per_s": round(B * steps / t_a, 1)}
+        runner = GraphedTrainStep(model, loss_fn)
+        for pd, md in dicts:                                      # untimed pass: captures every bucket the epoch visits
+            runner.run(pd, md, target)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for pd, md in dicts:
+            runner.run(pd, md, target)
+        t_i = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t_a = time.perf_counter() - t0
+        out["bucketed_graphs"] = {"what": "GraphedTrainStep: one staging launch + one replay of the captured WHOLE-MODEL step of "
+                                          "the batch's shape bucket; p.grad of all parameters set per step",
+                                  "ms_per_step": round(t_a / steps * 1e3, 4), "host_issue_ms_per_step": round(t_i / steps * 1e3, 4),
+                                  "pairs_per_s": round(B * steps / t_a, 1), "buckets": len(runner.buckets)}
+    model.zero_grad(set_to_none=True)
+    return out
+
+
+def _epoch_summary(args, variant, steps, B, n_prot, n_drug, t_all, t_issue, batches, edges, t_gen, graphed):
+    return {"what": "one epoch of DIFFERENT batches, eager (no HIP graph), nn.Module API (forward, backward(), gradient reset), C++ autograd fast path" if
             __import__("gvp_hip._lib", fromlist=["bridge"]).bridge() is not None else
             "one epoch of DIFFERENT batches, eager (no HIP graph), nn.Module API, Python custom ops",
-            "variant": args.epoch, "steps": steps, "pairs_per_step": B, "unique_proteins": n_prot, "unique_drugs": n_drug,
+            "variant": variant, "steps": steps, "pairs_per_step": B, "unique_proteins": n_prot, "unique_drugs": n_drug,
             "ms_per_step": round(t_all / steps * 1e3, 4), "host_issue_ms_per_step": round(t_issue / steps * 1e3, 4),
             "pairs_per_s": round(B * steps / t_all, 1),
             "residues_per_step": [min(b[2] for b in batches), max(b[2] for b in batches)],

@@ -436,6 +436,16 @@ struct AccPriv {
   static __device__ __forceinline__ void add(float* p, float v, bool) { *p += v; }
 };
 
+// The same block when every element is written by at most ONE flush (accumulators kept in registers and flushed once per
+// wave into a zeroed block): the old value is zero by construction, so nothing is read.
+struct AccStoreOnce {
+  static constexpr bool BATCHED = true;
+  static __device__ __forceinline__ float* trash() { return AccPriv::trash(); }
+  static __device__ __forceinline__ float load(const float*, bool) { return 0.f; }
+  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ void add(float* p, float v, bool) { *p = v; }
+};
+
 // v[k] is added to p[k] by the lanes with on[k], everybody else adds into the thread's trash word:
 // N unconditional read-add-writes with the reads in flight together (bias / LayerNorm gradients,
 // which only lane i == 15 of a group row holds after row_total).

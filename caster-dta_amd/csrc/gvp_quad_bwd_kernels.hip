@@ -641,21 +641,60 @@ __global__ __launch_bounds__(CB_TPB, CB_WPB / 4) void conv_bwd_kernel(ConvBArgs 
 //     entry); the wave that holds a target's FIRST edge stores its partial row to g_dst with plain stores; every row of
 //     g_dst is written exactly once (targets without edges: zero rows, by node range);
 //   * a self loop's d h[src] goes into its target's row sum instead of an atomic (a third of the edges of a 4 A graph).
-constexpr int C2_WPB = 4, C2_TPB = WAVE * C2_WPB, C2_TN = 2;
-constexpr int C2_GS_ROWS = C2_TN * TILE;                                   // d h[src] rows of one iteration
-constexpr int C2_SCR = C2_TN * TSCR_FLOATS + C2_GS_ROWS * ROW + C2_GS_ROWS;  // per wave: transposes | g_src rows | their ids
-template <int NTE>
-constexpr int conv_bwd2_lds_floats() { return C2_TPB + ConvBImg<NTE>::FSIZE + ConvBImg<NTE>::TSIZE + C2_WPB * (ConvBlk<NTE>::SIZE + C2_SCR); }
-static_assert(conv_bwd2_lds_floats<1>() * 4 <= 160 * 1024 && conv_bwd2_lds_floats<0>() * 4 <= 160 * 1024, "conv backward v2 LDS plan exceeds the CU");
-static_assert((C2_TN * TSCR_FLOATS) % 4 == 0 && (C2_GS_ROWS * ROW) % 4 == 0, "scratch regions stay 16-B aligned");
+// Shape of a workgroup: (TN tiles in lockstep per wave, WPB waves): (2, 4) = one wave per SIMD with 512 registers (default);
+// (1, 8) = two waves per SIMD with 256 registers each, one tile per wave (the hardware interleaves the two waves' phases).
+template <int TN, int WPB>
+struct C2Shape {
+  static constexpr int TPB = WAVE * WPB, GS_ROWS = TN * TILE;               // d h[src] rows of one iteration
+  static constexpr int SCR = TN * TSCR_FLOATS + GS_ROWS * ROW + GS_ROWS;    // per wave: transposes | g_src rows | their ids
+  static_assert((TN * TSCR_FLOATS) % 4 == 0 && (GS_ROWS * ROW) % 4 == 0, "scratch regions stay 16-B aligned");
+  template <int NTE>
+  static constexpr int lds_floats() { return TPB + ConvBImg<NTE>::FSIZE + ConvBImg<NTE>::TSIZE + WPB * (ConvBlk<NTE>::SIZE + SCR); }
+};
+static_assert(C2Shape<2, 4>::lds_floats<1>() * 4 <= 160 * 1024 && C2Shape<1, 8>::lds_floats<1>() * 4 <= 160 * 1024, "conv backward v2 LDS plan exceeds the CU");
 
-template <int NTE, typename ST>
-__global__ __launch_bounds__(C2_TPB) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_bwd2_kernel(ConvBArgs a) {
+// What one lane gathers for one sorted edge.  BRANCH-FREE: every load is unconditional on a CLAMPED position (a load under a
+// per-lane branch is its own wait; unconditional ones join the others in flight and can be issued an iteration ahead);
+// lanes behind the wave's last edge read the last edge's (finite) data and get zero upstream gradients.
+struct C2Rows {
+  f4 es0, es1, sj, si, d_ms;
+  float ev[3], vj[3], vi[3], d_mv[3];
+};
+template <typename ST>
+__device__ __forceinline__ void c2_load_rows(const ConvBArgs& a, int32_t pc, int32_t src, int32_t dst, int g, C2Rows& r) {
+  const int64_t er = (int64_t)pc * EROW;
+  r.es0 = Io<ST>::ld4(a.e_emb, er + 4 * g);
+  r.es1 = Io<ST>::ld4(a.e_emb, er + 16 + 4 * g);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) r.ev[d] = Io<ST>::ld(a.e_emb, er + ES + d);
+  const int64_t hj = (int64_t)src * ROW, hi = (int64_t)dst * ROW;
+  const float* gd = a.g_dh + (int64_t)dst * ROW;
+  r.sj = Io<ST>::ld4(a.h, hj + 4 * g);
+  r.si = Io<ST>::ld4(a.h, hi + 4 * g);
+  r.d_ms = *reinterpret_cast<const f4*>(gd + 4 * g);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    r.vj[d] = Io<ST>::ld(a.h, hj + NS + 3 * g + d);
+    r.vi[d] = Io<ST>::ld(a.h, hi + NS + 3 * g + d);
+    r.d_mv[d] = gd[NS + 3 * g + d];
+  }
+  if (a.mean) {
+    const int deg = a.rowptr[dst + 1] - a.rowptr[dst];
+    const float sc = 1.0f / (float)(deg > 1 ? deg : 1);
+    r.d_ms *= sc;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) r.d_mv[d] *= sc;
+  }
+}
+
+template <int NTE, typename ST, int TN, int C2_WPB>
+__global__ __launch_bounds__(WAVE * C2_WPB) __attribute__((amdgpu_waves_per_eu(C2_WPB / 4, C2_WPB / 4))) void conv_bwd2_kernel(ConvBArgs a) {
   WALL_STAMP(2);
   typedef Image<0, NTE> IM;
   typedef ConvBImg<NTE> BI;
   typedef ConvBlk<NTE> B;
-  constexpr int TN = C2_TN;
+  typedef C2Shape<TN, C2_WPB> SH;
+  constexpr int C2_TPB = SH::TPB, C2_GS_ROWS = SH::GS_ROWS, C2_SCR = SH::SCR;
   constexpr int PW = B::SIZE + C2_SCR;
   constexpr bool BF = Io<ST>::BF;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -706,6 +745,26 @@ __global__ __launch_bounds__(C2_TPB) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   Msg2<ST>::wacc_zero(w2);
   float carry[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int carry_dst = -1;
+  // ---- the wave's first iteration: indices, then rows -- issued BEFORE the workgroup waits for its fragment images (the
+  // one exposed gather; every later one is issued an iteration ahead)
+  const int32_t p_last = c_hi - 1;                         // (only used when the range is not empty)
+  // With two waves per SIMD the partner wave covers the gather and the registers are scarce: no gather-ahead there.
+  constexpr bool PREFETCH = C2_WPB == 4;
+  int32_t csrc[TN], cdst[TN];
+  C2Rows cur[TN];
+  if (PREFETCH && c_lo < c_hi) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int32_t p = c_lo + j * TILE + i, pc = p < p_last ? p : p_last;
+      csrc[j] = a.esrc[pc];
+      cdst[j] = a.edst[pc];
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int32_t p = c_lo + j * TILE + i, pc = p < p_last ? p : p_last;
+      c2_load_rows<ST>(a, pc, csrc[j], cdst[j], g, cur[j]);
+    }
+  }
   STAMP(0);
   __syncthreads();
   STAMP(1);
@@ -713,49 +772,48 @@ __global__ __launch_bounds__(C2_TPB) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   const int zt[TN] = {};
   for (int32_t base = c_lo; base < c_hi; base += TN * TILE) {
     STAMP(15);
-    // ---- gather, both tiles' loads in flight together
+    // ---- indices of the NEXT iteration (clamped: harmless on the last one); its rows are issued after the data gradients
+    const int32_t nxt_base = base + TN * TILE;
+    int32_t nsrc[TN], ndst[TN], npc[TN];
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int32_t p = nxt_base + j * TILE + i;
+        npc[j] = p < p_last ? p : p_last;
+        nsrc[j] = a.esrc[npc[j]];
+        ndst[j] = a.edst[npc[j]];
+      }
+    } else {
+      int32_t pc[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int32_t p = base + j * TILE + i;
+        pc[j] = p < p_last ? p : p_last;
+        csrc[j] = a.esrc[pc[j]];
+        cdst[j] = a.edst[pc[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) c2_load_rows<ST>(a, pc[j], csrc[j], cdst[j], g, cur[j]);
+    }
     f4 es0[TN], es1[TN], sj[TN], si[TN], d_ms[TN];
     float ev[TN][3], vj[TN][3], vi[TN][3], d_mv[TN][3];
     int32_t src[TN], dst[TN];
     bool active[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int32_t p = base + j * TILE + i;
-      active[j] = p < c_hi;
-      es0[j] = es1[j] = sj[j] = si[j] = d_ms[j] = zero;
+      active[j] = base + j * TILE + i < c_hi;
+      src[j] = csrc[j];
+      dst[j] = active[j] ? cdst[j] : -1;
+      es0[j] = cur[j].es0; es1[j] = cur[j].es1; sj[j] = cur[j].sj; si[j] = cur[j].si;
+      d_ms[j] = active[j] ? cur[j].d_ms : zero;
 #pragma unroll
-      for (int d = 0; d < 3; ++d) ev[j][d] = vj[j][d] = vi[j][d] = d_mv[j][d] = 0.f;
-      src[j] = 0;
-      dst[j] = -1;
-      if (active[j]) {
-        src[j] = a.esrc[p];
-        dst[j] = a.edst[p];
-        const int64_t er = (int64_t)p * EROW;
-        es0[j] = Io<ST>::ld4(a.e_emb, er + 4 * g);
-        es1[j] = Io<ST>::ld4(a.e_emb, er + 16 + 4 * g);
-        if (g == 0) {
-#pragma unroll
-          for (int d = 0; d < 3; ++d) ev[j][d] = Io<ST>::ld(a.e_emb, er + ES + d);
-        }
-        const int64_t hj = (int64_t)src[j] * ROW, hi = (int64_t)dst[j] * ROW;
-        const float* gd = a.g_dh + (int64_t)dst[j] * ROW;
-        sj[j] = Io<ST>::ld4(a.h, hj + 4 * g);
-        si[j] = Io<ST>::ld4(a.h, hi + 4 * g);
-        d_ms[j] = *reinterpret_cast<const f4*>(gd + 4 * g);
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { vj[j][d] = Io<ST>::ld(a.h, hj + NS + 3 * g + d); vi[j][d] = Io<ST>::ld(a.h, hi + NS + 3 * g + d); d_mv[j][d] = gd[NS + 3 * g + d]; }
-        if (a.mean) {
-          const int deg = a.rowptr[dst[j] + 1] - a.rowptr[dst[j]];
-          const float sc = 1.0f / (float)(deg > 1 ? deg : 1);
-          d_ms[j] *= sc;
-#pragma unroll
-          for (int d = 0; d < 3; ++d) d_mv[j][d] *= sc;
-        }
+      for (int d = 0; d < 3; ++d) {
+        ev[j][d] = g == 0 ? cur[j].ev[d] : 0.f;             // the edge vector sits in group 0's k-slot only
+        vj[j][d] = cur[j].vj[d];
+        vi[j][d] = cur[j].vi[d];
+        d_mv[j][d] = active[j] ? cur[j].d_mv[d] : 0.f;
       }
     }
-    // first target of the NEXT iteration (-1 at the end of the wave's range): where the last segment of this one ends
-    const int32_t nxt_base = base + TN * TILE;
-    const int32_t next_first = nxt_base < c_hi ? a.edst[nxt_base] : -1;
     STAMP(2);
     // ---- recompute the three message GVPs of both tiles
     float b0[TN][16], bv0[TN][3][3], b1[TN][4], bv1[TN][3][1], b2[TN][4], bv2[TN][3][1];
@@ -834,8 +892,16 @@ __global__ __launch_bounds__(C2_TPB) __attribute__((amdgpu_waves_per_eu(1, 1))) 
       STAMP(13);
       Msg0<ST>::template backward_tn<TN, BF>(imgT + IM::TC_M0, lane, c0, d_so, d_vo, d_b0, d_bv0, gr);
       STAMP(14);
+      // rows of the next iteration: in flight behind the weight gradients and the tail of this one
+      if constexpr (PREFETCH) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) c2_load_rows<ST>(a, npc[j], nsrc[j], ndst[j], g, cur[j]);
+      }
       Msg0<ST>::template wacc_accumulate<TN, BF>(w0, lane, zt, b0, bv0, c0, gr, tscr);
     }
+    // first target of the next iteration (-1 at the end of the wave's range): where the last segment of this one ends
+    int32_t next_first = -1;
+    if (nxt_base < c_hi) next_first = PREFETCH ? __builtin_amdgcn_readfirstlane(ndst[0]) : a.edst[nxt_base];
     STAMP(4);
     // ---- d(edge embedding) of this layer -> g_e (plain stores, sorted-edge order)
 #pragma unroll
@@ -865,14 +931,17 @@ __global__ __launch_bounds__(C2_TPB) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     __builtin_amdgcn_wave_barrier();
     {
       const int half = lane / ROW, col = lane - half * ROW;      // lanes 0..27 -> row 2k, 28..55 -> row 2k+1
-      if (half < 2) {
+      const int hr = half & 1;                                   // (lanes 56..63 read row 2k too and add nothing)
+      int sr[C2_GS_ROWS / 2];
+      float val[C2_GS_ROWS / 2];
 #pragma unroll
-        for (int k = 0; k < C2_GS_ROWS / 2; ++k) {
-          const int r = 2 * k + half;
-          const int sr = tsrc[r];
-          if (sr >= 0) atomicAdd(a.g_src + (int64_t)sr * ROW + col, trow[r * ROW + col]);
-        }
+      for (int k = 0; k < C2_GS_ROWS / 2; ++k) {                 // all the LDS reads first: two round trips, not 32
+        sr[k] = tsrc[2 * k + hr];
+        val[k] = trow[(2 * k + hr) * ROW + (half < 2 ? col : 0)];
       }
+#pragma unroll
+      for (int k = 0; k < C2_GS_ROWS / 2; ++k)
+        if (half < 2 && sr[k] >= 0) atomicAdd(a.g_src + (int64_t)sr[k] * ROW + col, val[k]);
     }
     __builtin_amdgcn_wave_barrier();
     STAMP(6);
@@ -917,12 +986,17 @@ __global__ __launch_bounds__(C2_TPB) __attribute__((amdgpu_waves_per_eu(1, 1))) 
       for (int k = 0; k < 7; ++k)
         carry[k] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x[k]), 0x100 | 15, 0xf, 0xf, false));
     }
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) { csrc[j] = nsrc[j]; cdst[j] = ndst[j]; }
+    }
     STAMP(7);
   }
   STAMP(8);
-  Msg0<ST>::template wacc_flush<AccPriv>(w0, gblk + B::M0, lane);
-  Msg1<ST>::template wacc_flush<AccPriv>(w1, gblk + B::M1, lane);
-  Msg2<ST>::template wacc_flush<AccPriv>(w2, gblk + B::M2, lane);
+  // every element of the (zeroed) block is the target of at most one flush: plain stores, no read-add-write round trips
+  Msg0<ST>::template wacc_flush<AccStoreOnce>(w0, gblk + B::M0, lane);
+  Msg1<ST>::template wacc_flush<AccStoreOnce>(w1, gblk + B::M1, lane);
+  Msg2<ST>::template wacc_flush<AccStoreOnce>(w2, gblk + B::M2, lane);
   write_slab_row<B::SIZE, PW, C2_WPB>(a.slab, blocks);
   STAMP(9);
 }
@@ -1297,30 +1371,34 @@ int head_bwd(const float* img_head, const float* imgT_head, const float* h_out, 
   return 0;
 }
 
-// Which conv backward runs: 2 (default) = conv_bwd2_kernel, 1 = the round-3 kernel (kept for A/B and as a cross-check in the
-// tests); CGVP_CONV_BWD in the environment, read once per process.
+// Which conv backward runs (CGVP_CONV_BWD in the environment, read once per process; the tests cross-check them):
+//   3 (default)  conv_bwd2_kernel<.., TN = 1, 8 waves>: two waves per SIMD, one tile each, register-resident weight gradients,
+//                edge-balanced ranges -- measured at davis_b64 / long_graph_x64: 35.3 / 434 us per launch
+//   2            conv_bwd2_kernel<.., TN = 2, 4 waves>: one wave per SIMD, two tiles in lockstep, gather-ahead: 40.3 / 515 us
+//   1            the round-3 kernel (target ranges, per-tile LDS flushes): 42.0 / 867 us
 int conv_bwd_version() {
   static const int v = [] {
     const char* e = getenv("CGVP_CONV_BWD");
-    return (e && e[0] == '1') ? 1 : 2;
+    return (e && e[0] == '1') ? 1 : ((e && e[0] == '2') ? 2 : 3);
   }();
   return v;
 }
 
-template <int NTE>
+template <int NTE, int TN, int WPB_>
 int conv_bwd2_impl(ConvBArgs& a, int64_t E, int* grid, int bf16, hipStream_t st) {
-  const int64_t iters = (E + C2_TN * TILE - 1) / (C2_TN * TILE);
-  const int64_t wgs = (iters + C2_WPB - 1) / C2_WPB;
+  typedef C2Shape<TN, WPB_> SH;
+  const int64_t iters = (E + TN * TILE - 1) / (TN * TILE);
+  const int64_t wgs = (iters + WPB_ - 1) / WPB_;
   const int G = (int)(wgs < 1 ? 1 : (wgs > CB_MAX_GRID ? CB_MAX_GRID : wgs));
   *grid = G;
-  const size_t lds = (size_t)conv_bwd2_lds_floats<NTE>() * sizeof(float);
-#define K_(ST) conv_bwd2_kernel<NTE, ST>
+  const size_t lds = (size_t)SH::template lds_floats<NTE>() * sizeof(float);
+#define K_(ST) conv_bwd2_kernel<NTE, ST, TN, WPB_>
   if (bf16 >= POLICY_GVPDEF) {
-    if constexpr (NTE == 0) BWD_LAUNCH_KIND(K_, G, C2_TPB, lds, a);
+    if constexpr (NTE == 0) BWD_LAUNCH_KIND(K_, G, SH::TPB, lds, a);
     else return CGVP_ERR_UNSUPPORTED_DIMS;
     return 0;
   }
-  BWD_LAUNCH(K_, G, C2_TPB, lds, a);
+  BWD_LAUNCH(K_, G, SH::TPB, lds, a);
 #undef K_
   return 0;
 }
@@ -1353,8 +1431,13 @@ int conv_bwd(int nt_edge, const float* img, const float* imgT, const float* h, c
   npw = npw < 1 ? 1 : (npw > WAVE ? WAVE : npw);
   ConvBArgs a{img, imgT, h, e_emb, rowptr, esrc, edst, N, npw, mean, g_dh, g_src, g_dst, g_e, slab};
   if (conv_bwd_version() == 2) {
-    if (nt_edge == 0) return conv_bwd2_impl<0>(a, E, grid, bf16, st);
-    if (nt_edge == 1) return conv_bwd2_impl<1>(a, E, grid, bf16, st);
+    if (nt_edge == 0) return conv_bwd2_impl<0, 2, 4>(a, E, grid, bf16, st);
+    if (nt_edge == 1) return conv_bwd2_impl<1, 2, 4>(a, E, grid, bf16, st);
+    return CGVP_ERR_UNSUPPORTED_DIMS;
+  }
+  if (conv_bwd_version() == 3) {
+    if (nt_edge == 0) return conv_bwd2_impl<0, 1, 8>(a, E, grid, bf16, st);
+    if (nt_edge == 1) return conv_bwd2_impl<1, 1, 8>(a, E, grid, bf16, st);
     return CGVP_ERR_UNSUPPORTED_DIMS;
   }
   if (nt_edge == 0) return conv_bwd_impl<0>(a, grid, bf16, st);

@@ -799,6 +799,17 @@ int conv(int nt_edge, const float* img, const float* h, const float* e_s, const 
   if (deg < 1) deg = 1;
   int npw = (int)((CTN * TILE - 2) / deg);
   npw = npw < 1 ? 1 : (npw > WAVE ? WAVE : npw);
+  // Dense graphs (conv-only launches): one ~20-edge target per wave left every pass 62 % full and made 16k workgroups
+  // stage the 37 KB image for 4 targets each (long_graph_x64).  A wave walks its targets' edges 32 at a time whatever the
+  // target boundaries, so give it more targets once there are more than a few rounds of resident waves: the last pass of
+  // a wave is the only partial one.
+  if (fuse == 0) {
+    const int64_t max_waves = 4 * 2048;             // four rounds of 2 workgroups x 4 waves on 256 CUs
+    if ((N + npw - 1) / npw > max_waves) {
+      int64_t m = (N + max_waves - 1) / max_waves;
+      npw = (int)(m > WAVE ? WAVE : m);
+    }
+  }
   ConvQArgs a{img, h, e_s, e_v, etypes, rowptr, eperm, esrc, edst, N, npw, mean, dh,
               NodeQArgs{img_node, img_head, h, nullptr, N, h_out, out, mask0, mask1, rng}, e_in, e_out, E};
   const int64_t groups = (N + npw - 1) / npw;

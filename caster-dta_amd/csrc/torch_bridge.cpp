@@ -12,8 +12,11 @@
 // The torch.library custom ops (gvp_hip/autograd_ops.py) stay the path torch.compile traces; both call the same C
 // entry points, so the launch sequence lives in one place.  No arithmetic happens here.
 #include <torch/extension.h>
+#include <torch/csrc/autograd/engine.h>
 #include <torch/csrc/autograd/function.h>
+#include <torch/csrc/autograd/functions/accumulate_grad.h>
 #include <torch/csrc/autograd/functions/utils.h>
+#include <torch/csrc/autograd/graph_task.h>
 #include <torch/csrc/autograd/variable.h>
 
 #include <c10/hip/HIPStream.h>
@@ -55,6 +58,96 @@ void check(int rc, const char* what) {
 }
 
 void* current_stream(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+// ------------------------------------------------------------------ leaf gradients without one engine task per leaf
+// The encoders have 50 + 24 parameter leaves; the autograd engine spends ~3-4 us of host time per leaf (a queue hand-off
+// and an AccumulateGrad task each) whoever produces the gradients: ~0.3 ms per step for 0.25 ms of device work.  When a
+// backward pass is a plain `loss.backward()` -- ACCUMULATE mode (no `inputs=`, not torch.autograd.grad) -- and no leaf
+// carries a hook, a pass's node does what the 60 AccumulateGrad tasks would do, itself: p.grad = view of the gradient
+// arena (or p.grad += view when a gradient is already there), and takes its edges to those AccumulateGrad nodes out of
+// THIS backward (the engine skips invalid edges); an end-of-backward callback puts them back, so the graph is what it was:
+// torch.autograd.grad, backward(inputs=...), hooks (DDP, register_hook, post-accumulate hooks) and retain_graph see the
+// stock structure and take the stock path.  CGVP_EXACT_LEAVES=1 (or set_exact_leaves(True)) forces the stock path.
+bool g_exact_leaves = std::getenv("CGVP_EXACT_LEAVES") != nullptr && std::getenv("CGVP_EXACT_LEAVES")[0] == '1';
+long g_fast_leaf_passes = 0;                // diagnostics (tests): passes that took the fast path
+
+struct LeafScatter {
+  // `views[i]`: the gradient of parameter i (a view of the pass's gradient arena `garena`, arena order), for i < np.
+  // Returns true when the leaves' .grad hold the result: the caller then returns UNDEFINED outputs for [0, np).
+  static bool run(Node& node, size_t np, const std::vector<at::Tensor>& views, const at::Tensor& garena) {
+    if (g_exact_leaves || at::GradMode::is_enabled()) return false;
+    const auto* exec_info = torch::autograd::get_current_graph_task_exec_info();
+    if (exec_info && !exec_info->empty()) return false;          // autograd.grad / backward(inputs=...): captures needed
+    std::vector<torch::autograd::AccumulateGrad*> acc(np, nullptr);
+    for (size_t i = 0; i < np; ++i) {
+      const torch::autograd::Edge& e = node.next_edge(i);
+      if (!e.is_valid()) continue;                                // a frozen parameter
+      auto* a = dynamic_cast<torch::autograd::AccumulateGrad*>(e.function.get());
+      if (!a || e.input_nr != 0) return false;                    // not a leaf (a view / clone of one): stock path
+      if (!a->pre_hooks().empty() || !a->post_hooks().empty() || !a->tensor_pre_hooks().empty() ||
+          !a->retains_grad_hooks().empty() || a->tensor_post_acc_grad_hooks() != nullptr)
+        return false;                                             // somebody listens at this leaf: stock path
+      if (!views[i].defined() || a->variable.sizes() != views[i].sizes()) return false;
+      acc[i] = a;
+    }
+    // one fused add when every leaf already holds a gradient and those are consecutive views of one arena themselves
+    bool all_defined = true, none_defined = true;
+    for (size_t i = 0; i < np; ++i) {
+      if (!acc[i]) continue;
+      const bool d = acc[i]->variable.grad().defined();
+      all_defined = all_defined && d;
+      none_defined = none_defined && !d;
+    }
+    bool fused = false;
+    if (all_defined && !none_defined) {
+      const char* at_ = nullptr;
+      bool ok = true;
+      int64_t total = 0;
+      for (size_t i = 0; i < np && ok; ++i) {
+        if (!acc[i]) { ok = false; break; }
+        const at::Tensor& g = acc[i]->variable.grad();
+        ok = g.scalar_type() == at::kFloat && g.is_contiguous() && g.device() == garena.device() &&
+             (at_ == nullptr || static_cast<const char*>(g.data_ptr()) == at_);
+        at_ = static_cast<const char*>(g.data_ptr()) + g.numel() * 4;
+        total += g.numel();
+      }
+      if (ok && total == garena.numel()) {
+        at::Tensor old = at::from_blob(acc[0]->variable.grad().data_ptr(), {total}, garena.options());
+        old.add_(garena);
+        fused = true;
+      }
+    }
+    if (!fused) {
+      for (size_t i = 0; i < np; ++i) {
+        if (!acc[i]) continue;
+        at::Tensor& g = acc[i]->variable.mutable_grad();
+        if (!g.defined()) g = views[i];
+        else g.add_(views[i]);                                    // (in place, as AccumulateGrad does outside create_graph)
+      }
+    }
+    // Take the leaf edges out of this backward, and put them back when it ends.  Also what the engine does for leaf
+    // streams: the caller's stream waits for the stream this node ran on, if that is another one.
+    auto self = node.getptr();
+    auto saved = std::make_shared<torch::autograd::edge_list>(node.next_edges().begin(), node.next_edges().begin() + np);
+    for (size_t i = 0; i < np; ++i) node.next_edges()[i] = torch::autograd::Edge();
+    const c10::hip::HIPStream ran_on = c10::hip::getCurrentHIPStream(garena.device().index());
+    torch::autograd::Engine::get_default_engine().queue_callback([self, saved, np, ran_on]() {
+      for (size_t i = 0; i < np; ++i) self->next_edges()[i] = (*saved)[i];
+      // (the callback runs on the thread that called backward(), with the caller's streams current)
+      const c10::hip::HIPStream now = c10::hip::getCurrentHIPStream(ran_on.device_index());
+      if (now != ran_on) {
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+          (void)hipEventRecord(ev, ran_on.stream());
+          (void)hipStreamWaitEvent(now.stream(), ev, 0);
+          (void)hipEventDestroy(ev);
+        }
+      }
+    });
+    ++g_fast_leaf_passes;
+    return true;
+  }
+};
 
 // an activation / index buffer as the kernels want it: on the GPU, contiguous, 16-B aligned
 // What a backward node re-reads from LIVE storage (inputs; for the drug encoder also the weights -- the protein pass
@@ -190,6 +283,8 @@ struct LbaBackward : public Node {
       if (task_should_compute_output(i)) out[i] = gparams.as_strided(shapes[i], strides[i], off);
       off += numels[i];
     }
+    if (LeafScatter::run(*this, np, out, gparams))
+      for (size_t i = 0; i < np; ++i) out[i] = at::Tensor();
     if (need_x) {
       out[np] = x_dtype == at::kFloat ? g_x_s : g_x_s.to(x_dtype);
       out[np + 1] = x_dtype == at::kFloat ? g_x_v : g_x_v.to(x_dtype);
@@ -391,6 +486,8 @@ struct GineBackward : public Node {
         if (task_should_compute_output(i)) out[i] = gflat.as_strided(params[i].sizes(), c10::contiguous_strides(params[i].sizes()), off);
         off += n;
       }
+      if (LeafScatter::run(*this, np, out, gflat))
+        for (size_t i = 0; i < np; ++i) out[i] = at::Tensor();
     }
     if (need_x) out[np] = g_x;
     return out;
@@ -490,6 +587,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   // loaded at run time reports its own through cgvp_abi_version(): _lib.bridge() requires all three to agree
   m.def("abi_version", []() { return (int)CGVP_ABI_VERSION; });
   m.def("library_abi_version", []() { return (int)cgvp_abi_version(); });
+  m.def("set_exact_leaves", [](bool on) { const bool was = g_exact_leaves; g_exact_leaves = on; return was; },
+        "True: every backward hands the engine one gradient per parameter leaf (the stock autograd path); False (default): "
+        "plain loss.backward() passes write the leaves' .grad themselves (LeafScatter)");
+  m.def("fast_leaf_passes", []() { return g_fast_leaf_passes; });
   m.def("timing_report", []() {
     std::string r;
     for (auto& kv : sections())

@@ -403,6 +403,10 @@ def lba_encoder(model, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, train_dro
     br = _eager_bridge()
     if br is not None and torch.is_grad_enabled() and (e_s.requires_grad or e_v.requires_grad):
         br = None       # gradients w.r.t. the raw edge features (rare: attribution studies): the custom-op path returns them
+    if br is not None and torch.is_autocast_enabled("cuda"):
+        # train_model.py:561 runs the forward under autocast: what the custom ops' autocast rule does (float inputs in fp32;
+        # the kernels are fp32 storage / fp32 accumulate there), done here so that the eager loop keeps the C++ fast path
+        x_s, x_v, e_s, e_v = (t.float() if t.dtype in (torch.float16, torch.bfloat16) else t for t in (x_s, x_v, e_s, e_v))
     if br is not None:
         # eager mode: the C++ autograd node (csrc/torch_bridge.cpp) -- same C entry points, a fraction of the host time
         dev, N = x_s.device, x_s.shape[0]
@@ -422,16 +426,22 @@ def lba_encoder(model, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, train_dro
         if not zero_copy and not model._fused and model._onehot_ntypes and model._onehot_etypes:
             model._arena.rebuild()          # something re-materialised the parameters: re-seat them as arena views
         return out
+    # The custom-op path (torch.compile; CGVP_BRIDGE=0): the op takes the parameter ARENA as one tensor -- a 50-tensor
+    # list costs ~0.3 ms of torch.library marshalling per call (forward, and again for the split gradients), measured on
+    # the CPU.  `cat` keeps autograd's connection to the leaves: under torch.compile Inductor emits one small copy kernel
+    # and the backward's split is 50 views; in eager mode it is one extra launch.
+    params = model.op_params()
+    arena = params[0] if len(params) == 1 else torch.cat([q.reshape(-1) for q in params])
     out, _, _ = torch.ops.caster_gvp.lba_encoder(
-        model.op_params(), x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, _memo_tables(edge_index, x_s.shape[0]), cfg,
+        [arena], x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, _memo_tables(edge_index, x_s.shape[0]), cfg,
         p, save_state)
     return out
 
 
 def _eager_bridge():
-    """The C++ fast path, when it applies: eager mode (Dynamo traces the custom ops instead), MFMA kernels, no autocast
-    (the custom ops carry the autocast rule)."""
-    if torch.compiler.is_compiling() or ops.VARIANT != "mfma" or torch.is_autocast_enabled("cuda"):
+    """The C++ fast path, when it applies: eager mode (Dynamo traces the custom ops instead), MFMA kernels.  (Under autocast
+    the callers cast half-precision inputs to fp32 first, which is what the custom ops' autocast rule does.)"""
+    if torch.compiler.is_compiling() or ops.VARIANT != "mfma":
         return None
     return _lib.bridge()
 
@@ -640,6 +650,8 @@ def gine_encoder(model, x, ntypes, eattr, etypes, edge_index, slope, train_dropo
         raise NotImplementedError("gradients w.r.t. bond features are not produced by the backward kernels")
     p = float(model.dropout_rate) if train_dropout else 0.0
     br = _eager_bridge()
+    if br is not None and torch.is_autocast_enabled("cuda"):           # (as in lba_encoder: the ops' autocast rule, by hand)
+        x, eattr = (t.float() if t.dtype in (torch.float16, torch.bfloat16) else t for t in (x, eattr))
     if br is not None:
         dev, N = x.device, x.shape[0]
         csr = _memo_tables(edge_index, N)

@@ -10,8 +10,16 @@ with an autoregressive decoder) whose layers differ in `activations` / `vector_g
     LINEAR   (None, None)         False         v                           PocketMiner        protein_gnn.py:468-473
 
 The kernels are compiled for node dims (16, 4) and an edge embedding of (32, 1); a layer with FEWER edge scalars runs on
-them with zero-padded edge rows and zero weight columns (exact: the padded products are 0).  Everything else about the
-layer is the kernels' native case: 3 message GVPs, 2 feed-forward GVPs, aggregation mean / add.
+them with zero-padded edge rows and zero weight columns (exact: the padded products are 0).  A layer with MORE edge scalars
+than 32 -- the default CPD decoder: 32 + 20 (protein_gnn.py:566-570) -- runs on them FOLDED: the edge scalars enter the
+message only through message_func.0's `ws`, a linear map onto its 16 pre-activations, so
+
+    ws . [s_j | e (se) | s_i | vn]  =  ws' . [s_j | t (16) 0 (16) | s_i | vn],     t = e . ws[:, 16:16+se]^T,  ws' = ws with the edge
+                                                                                  columns replaced by [I_16 | 0]
+
+i.e. the kernels get the 16-wide projection `t` as their "edge scalars" and an identity block as those weight columns; the
+E x se x 16 projection and its gradients (d ws_e = d t^T e, d e = d t ws_e) are torch ops around them, composed by autograd.
+Everything else about the layer is the kernels' native case: 3 message GVPs, 2 feed-forward GVPs, aggregation mean / add.
 
 How a layer runs here (all through fine-grained C-ABI entry points, include/caster_gvp.h):
 
@@ -64,8 +72,8 @@ def _last_ok(g, kind):
 def conv_kind(conv):
     """Layer kind if `conv` (a GVPConv) is a case the kernels compute, else None."""
     mf = list(conv.message_func)
-    if (conv.si, conv.vi, conv.so, conv.vo) != (NS, NV, NS, NV) or conv.ve != EV or not (0 <= conv.se <= ES):
-        return None
+    if (conv.si, conv.vi, conv.so, conv.vo) != (NS, NV, NS, NV) or conv.ve != EV or conv.se < 0:
+        return None          # (any number of edge scalars: <= 32 padded, more than 32 folded through message_func.0's ws)
     if len(mf) != 3 or conv.aggr not in ("mean", "add", "sum"):
         return None
     dims = [((2 * NS + conv.se, 2 * NV + EV), (NS, NV)), ((NS, NV), (NS, NV)), ((NS, NV), (NS, NV))]
@@ -108,11 +116,20 @@ def _cfg(kind):
     return _CFG[kind]
 
 
-def _gvp_block(g, ref, pad=None):
+def folds_edges(conv):
+    """More edge scalars than the compiled width: the conv runs with the edge scalars projected by message_func.0."""
+    return conv.se > ES
+
+
+def _gvp_block(g, ref, pad=None, fold=None):
     """One GVP's arena block [wh | ws.weight | ws.bias | wv | wsv.weight | wsv.bias] (zeros for an absent gate).
-    `pad` = (first column, count): zero columns inserted into ws.weight (edge scalars padded to the compiled width)."""
+    `pad` = (first column, count): zero columns inserted into ws.weight (edge scalars padded to the compiled width);
+    `fold` = (first column, count): those columns (too many edge scalars) replaced by [I | 0] of the compiled width."""
     ws = g.ws.weight
-    if pad is not None and pad[1] > 0:
+    if fold is not None:
+        eye = torch.eye(ws.shape[0], ES, dtype=ws.dtype, device=ws.device)
+        ws = torch.cat([ws[:, :fold[0]], eye, ws[:, fold[0] + fold[1]:]], dim=1)
+    elif pad is not None and pad[1] > 0:
         ws = torch.cat([ws[:, :pad[0]], ws.new_zeros(ws.shape[0], pad[1]), ws[:, pad[0]:]], dim=1)
     parts = [g.wh.weight.reshape(-1), ws.reshape(-1), g.ws.bias, g.wv.weight.reshape(-1)]
     if g.vector_gate:
@@ -131,7 +148,10 @@ def pack_arena(kind, conv=None, layer=None):
     n_msg = 1369 + 2 * 436
     n_norm = 4 * NS
     if conv is not None:
-        parts += _gvp_block(conv.message_func[0], ref, pad=(NS + conv.se, ES - conv.se))
+        if folds_edges(conv):
+            parts += _gvp_block(conv.message_func[0], ref, fold=(NS, conv.se))
+        else:
+            parts += _gvp_block(conv.message_func[0], ref, pad=(NS + conv.se, ES - conv.se))
         parts += _gvp_block(conv.message_func[1], ref) + _gvp_block(conv.message_func[2], ref)
     else:
         parts.append(ref.new_zeros(n_msg))
@@ -163,10 +183,13 @@ def tuple_from_rows(r):
     return r[:, :NS], r[:, NS:].reshape(r.shape[0], NV, 3)
 
 
-def edge_rows(edge_attr, eperm, num_edges):
+def edge_rows(edge_attr, eperm, num_edges, conv=None):
     """Stored edge-embedding rows [E + 1][CGVP_EDGE_ROW] in sorted-edge order (32 scalars zero-padded | xyz | pad; the
-    extra last row is zeros).  Differentiable gather."""
+    extra last row is zeros).  Differentiable gather.  `conv` with more than 32 edge scalars: the scalars are replaced by
+    their projection through message_func.0's edge columns (module docstring, "FOLDED")."""
     e_s, e_v = edge_attr
+    if conv is not None and folds_edges(conv):
+        e_s = e_s @ conv.message_func[0].ws.weight[:, NS:NS + conv.se].t()
     idx = eperm[:num_edges].long().clamp_min(0)      # (-1: positions behind the last valid edge when the build dropped edges; never read)
     rows = torch.cat([e_s.index_select(0, idx), e_s.new_zeros(num_edges, ES - e_s.shape[1]),
                       e_v.index_select(0, idx).reshape(num_edges, 3), e_s.new_zeros(num_edges, EROW - ES - 3)], dim=1)
@@ -278,7 +301,7 @@ def conv_message(conv, kind, x, edge_index, edge_attr, arena=None, image=None):
         arena = pack_arena(kind, conv=conv)
         image = prepare(kind, arena)
     csr = ops.build_csr(edge_index, N)
-    e_rows = edge_rows(edge_attr, csr.eperm, E)
+    e_rows = edge_rows(edge_attr, csr.eperm, E, conv)
     return _ConvFn.apply(arena, h, e_rows, image, csr.rowptr, csr.esrc, csr.edst, kind, conv.aggr == "mean")
 
 

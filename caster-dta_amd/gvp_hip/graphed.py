@@ -20,6 +20,7 @@ step, all-reduce) before the next `run` of the same bucket.  Opt-in: the nn.Modu
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -154,3 +155,153 @@ class GraphedEncoderStep:
             t.record_stream(self.stream)
         res, atm, gp, gd = b.out
         return res[:N], atm[:Na], gp, gd
+
+
+class _TrainBucket:
+    def __init__(self, owner, key, pdata, mdata, target, sdt):
+        N, E, Na, Ea, B = key
+        dev = owner.device
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
+        ni = pdata["x"][0].shape[1], pdata["x"][1].shape[1], pdata["eattr"][0].shape[1], pdata["eattr"][1].shape[1]
+        # B real pairs + ONE padding pair that owns every padded residue / atom (never empty: the sizes are rounded up from
+        # n + 1), so that the head's per-pair pooling and attention see B + 1 well-formed pairs and the loss reads the first B
+        pptr = torch.full((B + 2,), N, dtype=torch.int64, device=dev)
+        mptr = torch.full((B + 2,), Na, dtype=torch.int64, device=dev)
+        self.p = dict(x=(z(N, ni[0], dt=sdt), z(N, ni[1], 3, dt=sdt)), edge_index=torch.full((2, E), -1, dtype=torch.int64, device=dev),
+                      ntypes=z(N, dt=torch.int64), etypes=z(E, dt=torch.int64),
+                      eattr=(z(E, ni[2], dt=sdt), z(E, ni[3], 3, dt=sdt)), ptr=pptr)
+        self.m = dict(x=z(Na, mdata["x"].shape[1]), edge_index=torch.full((2, Ea), -1, dtype=torch.int64, device=dev),
+                      ntypes=z(Na, dt=torch.int64), etypes=z(Ea, dt=torch.int64), eattr=z(Ea, mdata["eattr"].shape[1]), ptr=mptr)
+        self.target = torch.zeros((B,) + tuple(target.shape[1:]), dtype=target.dtype, device=dev)
+        self.rows_p = torch.arange(N, device=dev)
+        self.rows_m = torch.arange(Na, device=dev)
+        self.graph, self.out, self.steps = None, None, 0
+
+
+class GraphedTrainStep:
+    """The WHOLE JointGNN training step -- forward of both encoders and the head, loss, backward with all 764k gradients --
+    replayed from shape-bucketed HIP graphs, for the loop of train_model.py:548-587 that feeds a different batch every step:
+
+        step = GraphedTrainStep(model, torch.nn.functional.mse_loss)        # optional: scaler=GradScaler, autocast=dtype
+        for pdata, mdata, y in loader:            # the dicts carry 'ptr' (PyG Batch objects do)
+            loss, pred = step.run(pdata, mdata, y)                           # p.grad of every parameter is set
+            optimizer.step()
+
+    One launch stages the batch into the bucket's padded static buffers, one replay runs the step.  Padding: padded
+    residues / atoms are isolated nodes that belong to an extra (B+1)-th pair whose prediction the loss never reads, so
+    every real pair's numbers and every gradient equal those of the eager step on the unpadded batch (padded rows have
+    zero upstream gradient; tests/test_hip_models.py::test_graphed_train_step_equals_eager).  The gradients are the graph's
+    static tensors: consume them (optimizer step) before the next `run` of the same bucket."""
+
+    def __init__(self, model, loss_fn, scaler=None, autocast=None, quantum=bucket_size):
+        self.model, self.loss_fn, self.scaler, self.autocast, self.quantum = model, loss_fn, scaler, autocast, quantum
+        self.params = [p for p in model.parameters() if p.numel() and p.requires_grad]
+        self.device = self.params[0].device
+        self.buckets = {}
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.pool = None
+
+    def _step(self, b, B):
+        import contextlib
+        ctx = torch.autocast("cuda", dtype=self.autocast) if self.autocast is not None else contextlib.nullcontext()
+        # pair index of every row from the staged offsets (no host sync): rows behind the last real one -> the padding pair B
+        pd = dict(b.p, batch=self._pair_of_rows(b.p["ptr"], b.rows_p))
+        md = dict(b.m, batch=self._pair_of_rows(b.m["ptr"], b.rows_m))
+        aw = getattr(self.model, "attention_weights", None)
+        if aw is not None:
+            self.model.attention_weights = "never"      # (the padded weight tensors need a host-side maximum: not capturable)
+        try:
+            with ctx:
+                pred, _ = self.model(pd, md)
+                loss = self.loss_fn(pred[:B], b.target)
+        finally:
+            if aw is not None:
+                self.model.attention_weights = aw
+        out = self.scaler.scale(loss) if self.scaler is not None else loss
+        grads = torch.autograd.grad(out, self.params, allow_unused=True)
+        return loss.detach(), pred[:B].detach(), grads
+
+    @staticmethod
+    def _pair_of_rows(ptr, rows):
+        """pair index of every row = number of pair END offsets <= row (plain compare + sum: capturable, no host sync)"""
+        if os.environ.get("CGVP_GRAPHED_BATCH") == "searchsorted":
+            return torch.searchsorted(ptr[1:].contiguous(), rows, right=True)
+        return (rows.unsqueeze(1) >= ptr[1:].unsqueeze(0)).sum(dim=1)
+
+    def _stage(self, b, pdata, mdata, target):
+        pairs = [(b.p["x"][0], pdata["x"][0]), (b.p["x"][1], pdata["x"][1]), (b.p["ntypes"], pdata["ntypes"]),
+                 (b.p["etypes"], pdata["etypes"]), (b.p["eattr"][0], pdata["eattr"][0]), (b.p["eattr"][1], pdata["eattr"][1]),
+                 (b.m["x"], mdata["x"]), (b.m["ntypes"], mdata["ntypes"]), (b.m["etypes"], mdata["etypes"]),
+                 (b.m["eattr"], mdata["eattr"]), (b.target, target),
+                 (b.p["ptr"][:-1], pdata["ptr"]), (b.m["ptr"][:-1], mdata["ptr"])]      # (the last offset stays the padded size)
+        items = (_lib.StageItem * _lib.MAX_STAGE)()
+        keep, k = [], 0
+        for dst, src in pairs:
+            if src.dtype != dst.dtype or not src.is_contiguous():
+                src = src.to(dst.dtype).contiguous()
+                keep.append(src)
+            items[k] = _lib.StageItem(dst.data_ptr(), src.data_ptr() if src.numel() else 0, src.numel() * src.element_size(),
+                                      dst.numel() * dst.element_size(), 0)
+            k += 1
+        for dst, src in ((b.p["edge_index"], pdata["edge_index"]), (b.m["edge_index"], mdata["edge_index"])):
+            src = src.contiguous()
+            keep.append(src)
+            E, Ecap = src.shape[1], dst.shape[1]
+            for row in range(2):
+                items[k] = _lib.StageItem(dst[row].data_ptr(), src[row].data_ptr() if E else 0, E * 8, Ecap * 8, 0xFFFFFFFF)
+                k += 1
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().cgvp_stage_buffers(items, k, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       "cgvp_stage_buffers")
+        return keep
+
+    def _publish(self, b):
+        loss, pred, grads = b.out
+        for p, g in zip(self.params, grads):
+            if g is not None and p.grad is not g:
+                p.grad = g
+        return loss, pred
+
+    def run(self, pdata, mdata, target):
+        if "ptr" not in pdata or "ptr" not in mdata:
+            raise ValueError("GraphedTrainStep needs the graph offsets 'ptr' in both dicts (PyG Batch objects carry them)")
+        N, E = pdata["x"][0].shape[0], pdata["edge_index"].shape[1]
+        Na, Ea = mdata["x"].shape[0], mdata["edge_index"].shape[1]
+        B = int(pdata["ptr"].numel()) - 1
+        key = (self.quantum(N + 1), self.quantum(E), self.quantum(Na + 1), self.quantum(Ea), B)
+        sdt = torch.bfloat16 if pdata["x"][0].dtype == torch.bfloat16 else torch.float32
+        b = self.buckets.get((key, sdt))
+        if b is not None and b.graph is not None:
+            keep = self._stage(b, pdata, mdata, target)
+            b.graph.replay()
+            b.steps += 1
+            del keep
+            return self._publish(b)
+        caller = torch.cuda.current_stream()
+        self.stream.wait_stream(caller)
+        was_training = self.model.training
+        with torch.cuda.stream(self.stream), torch.enable_grad():
+            if b is None:
+                b = self.buckets[(key, sdt)] = _TrainBucket(self, key, pdata, mdata, target, sdt)
+            keep = self._stage(b, pdata, mdata, target)
+            old = ops.CSR_CACHE_ENABLED
+            ops.CSR_CACHE_ENABLED = False
+            try:
+                for _ in range(2):
+                    self._step(b, B)
+                torch.cuda.current_stream().synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.stream, pool=self.pool):
+                    b.out = self._step(b, B)
+                if self.pool is None:
+                    self.pool = g.pool()
+                b.graph = g
+            finally:
+                ops.CSR_CACHE_ENABLED = old
+            b.graph.replay()
+            b.steps += 1
+        caller.wait_stream(self.stream)
+        for t in keep:
+            t.record_stream(self.stream)
+        self.model.train(was_training)
+        return self._publish(b)

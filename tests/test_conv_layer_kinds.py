@@ -223,9 +223,45 @@ def test_cases_outside_the_compiled_set_use_the_composition(monkeypatch):
     mixed = gvp.GVPConvLayer((16, 4), (32, 1), activations=(F.relu, torch.sigmoid), vector_gate=True).to(DEV).eval()
     assert K.conv_kind(mixed.conv) is None and K.node_kind(mixed) is None         # gate fed through sigmoid: no such kernel
     assert mixed(_feats(n, (16, 4), 3), ei, _feats(e, (32, 1), 4))[0].shape == (n, 16)
-    big_edge = gvp.GVPConv((16, 4), (16, 4), (52, 1)).to(DEV).eval()
-    assert K.conv_kind(big_edge) is None
-    assert big_edge(_feats(n, (16, 4), 5), ei, _feats(e, (52, 1), 6))[0].shape == (n, 16)
+    wide_vec = gvp.GVPConv((16, 4), (16, 4), (32, 2)).to(DEV).eval()              # two edge vector channels
+    assert K.conv_kind(wide_vec) is None
+    assert wide_vec(_feats(n, (16, 4), 5), ei, _feats(e, (32, 2), 6))[0].shape == (n, 16)
+
+
+@pytest.mark.parametrize("se", [52, 40, 64])
+@pytest.mark.parametrize("kind", ["gated", "gvpdef", "linear"])
+def test_more_than_32_edge_scalars_run_folded_on_the_kernels(kind, se, monkeypatch):
+    """Round 4 (survey f-4): an edge embedding wider than the compiled 32 scalars -- the default CPD decoder's 32 + 20
+    (protein_gnn.py:566-570) -- runs on the conv kernels with the edge scalars folded through message_func.0's `ws`
+    (gvp_hip/conv_layer_ops.py, "FOLDED").  Messages and every gradient (weights, node features, edge features) against
+    the tensor-op composition of the same module."""
+    import models.gvp_layers as gvp
+    from gvp_hip import conv_layer_ops as K
+    acts = {"gated": dict(activations=(F.relu, None), vector_gate=True), "gvpdef": dict(activations=(F.relu, torch.sigmoid)),
+            "linear": dict(activations=(None, None))}[kind]
+    torch.manual_seed(7)
+    conv = gvp.GVPConv((16, 4), (16, 4), (se, 1), aggr="mean", **acts).to(DEV)
+    assert K.conv_kind(conv) is not None and K.folds_edges(conv)
+    n, e = 150, 1100
+    ei = _graph(n, e, 9, isolated=3)
+    calls = []
+    conv_message = K.conv_message
+    monkeypatch.setattr(K, "conv_message", lambda *a, **k: (calls.append(1), conv_message(*a, **k))[1])
+    res = {}
+    for tag, on in (("kernels", True), ("composition", False)):
+        monkeypatch.setattr(K, "ENABLED", on)
+        x = tuple(t.clone().requires_grad_() for t in _feats(n, (16, 4), 1))
+        ea = tuple(t.clone().requires_grad_() for t in _feats(e, (se, 1), 2))
+        conv.zero_grad(set_to_none=True)
+        out = conv(x, ei, ea)
+        r = _feats(n, (16, 4), 3)
+        ((out[0] * r[0]).sum() + (out[1] * r[1]).sum()).backward()
+        res[tag] = ([out[0].detach(), out[1].detach(), x[0].grad, x[1].grad, ea[0].grad, ea[1].grad]
+                    + [p.grad.clone() for p in conv.parameters() if p.numel()])
+    assert len(calls) == 1                                       # the kernel path ran once, the composition never reached it
+    scale = max(float(t.abs().max()) for t in res["composition"][6:])
+    for a, b in zip(res["kernels"], res["composition"]):
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 2e-6 * scale
 
 
 def test_layer_kind_is_rejected_where_the_library_has_no_such_kernel():

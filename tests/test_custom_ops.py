@@ -159,8 +159,11 @@ def test_compiled_equals_eager_bitwise(protein_params, molecule_params, backend)
                         [q.grad.clone() for q in list(prot.parameters()) + list(mol.parameters()) if q.numel()])
         assert torch.equal(got["eager"][0], got["compiled"][0]) and torch.equal(got["eager"][1], got["compiled"][1])
         # weight gradients below the last conv layer pass through float atomics (d h[src]): equal to rounding
+        # (floor tied to the global gradient scale: analytically-zero gradients -- gvp_edge's gate weights, ~1e-8 -- are pure
+        # rounding noise that the atomics reorder)
+        scale = max(float(a.abs().max()) for a in got["eager"][2])
         for a, b in zip(got["eager"][2], got["compiled"][2]):
-            assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-9
+            assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-7 * scale
     with torch.no_grad():                                    # inference launch sequence under compile
         assert torch.equal(cprot(**pd), prot(**pd))
 

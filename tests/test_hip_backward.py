@@ -131,9 +131,13 @@ def test_weights_only_and_accumulation(protein_params):
     g2 = {n: p.grad.clone() for n, p in model.gnn_model.named_parameters() if p.numel()}
     model.zero_grad()
     model(d["x"], d["edge_index"], d["ntypes"], d["etypes"], eattr=d["eattr"]).square().mean().backward()
+    # (relative to the tensor's own maximum, with a floor tied to the global gradient scale: gradients that are analytically
+    # zero -- gvp_edge.0.wsv at ~1e-11 -- are rounding noise that the d h[src] float atomics reorder from run to run)
+    scale = max(float(p.grad.abs().max()) for p in model.gnn_model.parameters() if p.numel())
     for n, p in model.gnn_model.named_parameters():
         if p.numel():
-            assert rel_err(g2[n], 2 * p.grad) < 1e-5, n
+            err = float((g2[n] - 2 * p.grad).abs().max())
+            assert err <= 1e-5 * float((2 * p.grad).abs().max()) + 1e-7 * scale, (n, err)
 
 
 def test_training_dropout_with_pinned_masks(protein_params, monkeypatch):

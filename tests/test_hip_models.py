@@ -631,3 +631,141 @@ def test_two_lane_head_without_cross_attention_and_without_ptr(pretrained):
     assert len(got) == len(ref)
     for a, b in zip(got, ref):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 2e-7 * scale
+
+
+def test_backward_writes_leaf_grads_without_engine_tasks_and_keeps_autograd_semantics(pretrained):
+    """Round 4: a plain `loss.backward()` lets each encoder's node write its parameters' .grad itself (LeafScatter in
+    csrc/torch_bridge.cpp) instead of handing the engine one task per leaf.  Everything autograd promises must still hold:
+    same gradients as the stock path, accumulation into existing .grad, frozen parameters, torch.autograd.grad and
+    backward(inputs=...) on the same graph, tensor hooks and post-accumulate hooks (which switch that pass to the stock path)."""
+    from gvp_hip import _lib
+    from models.joint_gnn import JointGNN
+    bridge = _lib.bridge()
+    if bridge is None:
+        pytest.skip("C++ bridge not in use")
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))
+    model = JointGNN(protein_gnn_kwargs=kw["protein_gnn_kwargs"], molecule_gnn_kwargs=kw["molecule_gnn_kwargs"],
+                     **kw["joint_gnn_kwargs"])
+    model.load_state_dict(pretrained, strict=True)
+    model.to(DEV).eval()
+    p, m = ds.pair_batch(6, 21)
+    pd, md = _to(ds.to_torch(p)), _to(ds.to_torch(m))
+    enc = [(n, q) for n, q in model.named_parameters() if q.numel() and (n.startswith("protein_gnn") or n.startswith("molecule_gnn"))]
+    params = [q for _, q in enc]
+    target = torch.randn(6, 1, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+
+    gscale = [1.0]
+
+    def same(x, y):            # (the backward's d h[src] float atomics make two runs differ in the last bits; analytically-zero
+        return float((x - y).abs().max()) <= 2e-5 * float(y.abs().max()) + 1e-6 * gscale[0]      # gradients are pure noise)
+
+    def loss_of():
+        pred, _ = model(pd, md)
+        return torch.nn.functional.mse_loss(pred, target)
+
+    def grads_after_backward(scale=1.0):
+        (loss_of() * scale).backward()
+        return [q.grad.detach().clone() for q in params]
+
+    was = bridge.set_exact_leaves(True)
+    try:
+        model.zero_grad(set_to_none=True)
+        ref = grads_after_backward()
+        gscale[0] = max(float(g.abs().max()) for g in ref)
+        ref2 = grads_after_backward(0.5)                       # accumulated on top, the stock way
+        bridge.set_exact_leaves(False)
+        n0 = bridge.fast_leaf_passes()
+        model.zero_grad(set_to_none=True)
+        got = grads_after_backward()
+        assert bridge.fast_leaf_passes() == n0 + 2             # both encoders took the fast path
+        for a, b, (name, _) in zip(got, ref, enc):
+            assert same(a, b), name
+        got2 = grads_after_backward(0.5)                       # p.grad += : ONE fused add per encoder
+        for a, b, (name, _) in zip(got2, ref2, enc):
+            assert same(a, b), name
+        # a mixed state: some leaves hold a gradient, others were reset
+        for q in params[::3]:
+            q.grad = None
+        mixed = grads_after_backward()
+        for k, (a, (name, _)) in enumerate(zip(mixed, enc)):
+            want = ref[k] if k % 3 == 0 else got2[k] + ref[k]
+            assert same(a, want), name
+        # the functional API on a graph of its own, and on a graph that a fast backward has already walked (retain_graph)
+        model.zero_grad(set_to_none=True)
+        fg = torch.autograd.grad(loss_of(), params)
+        for a, b, (name, _) in zip(fg, ref, enc):
+            assert same(a, b), name
+        loss = loss_of()
+        loss.backward(retain_graph=True)
+        n1 = bridge.fast_leaf_passes()
+        fg2 = torch.autograd.grad(loss, params)                # the edges to the leaves are back
+        assert bridge.fast_leaf_passes() == n1
+        for a, b, (name, _) in zip(fg2, ref, enc):
+            assert same(a, b), name
+        model.zero_grad(set_to_none=True)
+        loss_of().backward(inputs=params[:5])                  # backward(inputs=...): stock path, only those leaves
+        assert all(q.grad is not None for q in params[:5]) and all(q.grad is None for q in params[5:])
+        for a, b in zip(params[:5], ref[:5]):
+            assert same(a.grad, b)
+        # hooks: a tensor hook and a post-accumulate hook each see their gradient; those passes take the stock path
+        model.zero_grad(set_to_none=True)
+        seen = {}
+        h1 = params[3].register_hook(lambda g: seen.__setitem__("pre", g.detach().clone()))
+        h2 = params[-2].register_post_accumulate_grad_hook(lambda q: seen.__setitem__("post", q.grad.detach().clone()))
+        n2 = bridge.fast_leaf_passes()
+        hooked = grads_after_backward()
+        assert bridge.fast_leaf_passes() == n2                  # both encoders had a listener: no fast pass
+        assert same(seen["pre"], ref[3]) and same(seen["post"], ref[-2])
+        for a, b, (name, _) in zip(hooked, ref, enc):
+            assert same(a, b), name
+        h1.remove(), h2.remove()
+        # frozen parameters: no gradient appears there, the others are unchanged
+        model.zero_grad(set_to_none=True)
+        params[0].requires_grad_(False), params[-1].requires_grad_(False)
+        frozen = None
+        try:
+            loss_of().backward()
+            assert params[0].grad is None and params[-1].grad is None
+            for q, b, (name, _) in list(zip(params, ref, enc))[1:-1]:
+                assert same(q.grad, b), name
+        finally:
+            params[0].requires_grad_(True), params[-1].requires_grad_(True)
+        # an optimizer step driven by the fast path moves the weights exactly as one driven by the stock path
+        model.zero_grad(set_to_none=True)
+    finally:
+        bridge.set_exact_leaves(was)
+
+
+def test_graphed_train_step_equals_eager(pretrained):
+    """gvp_hip.graphed.GraphedTrainStep: the whole JointGNN training step from shape-bucketed HIP graphs.  Batches of
+    different sizes (two of them share a bucket, so the second one is a pure stage + replay): loss, predictions and every
+    one of the 764k gradients equal the eager step on the UNPADDED batch; p.grad holds the result."""
+    from gvp_hip.graphed import GraphedTrainStep
+    from models.joint_gnn import JointGNN
+    kw = json.load(open(os.path.join(GOLDEN, "model_kwargs.json")))
+    model = JointGNN(protein_gnn_kwargs=kw["protein_gnn_kwargs"], molecule_gnn_kwargs=kw["molecule_gnn_kwargs"],
+                     **kw["joint_gnn_kwargs"])
+    model.load_state_dict(pretrained, strict=True)
+    model.to(DEV).eval()                                   # no dropout: the two runs see the same numbers
+    params = [q for q in model.parameters() if q.numel()]
+    runner = GraphedTrainStep(model, torch.nn.functional.mse_loss)
+    seen = set()
+    for seed, lengths in ((1, [120, 80, 95, 130, 60, 101]), (2, [118, 83, 95, 128, 62, 100]), (3, [200, 150, 170, 90, 60, 210])):
+        p, m = ds.pair_batch(6, seed, lengths=lengths)
+        pd, md = _to(ds.to_torch(p)), _to(ds.to_torch(m))
+        pd["ptr"], md["ptr"] = torch.as_tensor(p.ptr).to(DEV), torch.as_tensor(m.ptr).to(DEV)
+        target = torch.randn(6, 1, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed))
+        pred, _ = model(pd, md)
+        loss = torch.nn.functional.mse_loss(pred, target)
+        ref = torch.autograd.grad(loss, params)
+        model.zero_grad(set_to_none=True)
+        gl, gp = runner.run(pd, md, target)
+        torch.cuda.synchronize()
+        assert float((gl - loss).abs()) <= 1e-5 * float(loss.abs())
+        assert float((gp - pred).abs().max()) <= 1e-5 * float(pred.abs().max())
+        scale = max(float(g.abs().max()) for g in ref)
+        for q, g in zip(params, ref):
+            assert q.grad is not None
+            assert float((q.grad - g).abs().max()) <= 2e-5 * float(g.abs().max()) + 2e-7 * scale
+        seen.add(len(runner.buckets))
+    assert 1 <= len(runner.buckets) <= 3 and sum(b.steps for b in runner.buckets.values()) == 3

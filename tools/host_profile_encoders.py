@@ -15,10 +15,12 @@ pp = [p for p in model.protein_gnn.parameters() if p.numel()]
 mp = [p for p in model.molecule_gnn.parameters() if p.numel()]
 g_res, g_atm = torch.randn(pb.num_nodes, 64, device=dev), torch.randn(mb.num_nodes, 64, device=dev)
 
-def step():
+def step():                       # what loss.backward() does to the encoders: accumulate mode, then the optimizer's reset
     res = model.protein_gnn(**pd)
     atm = model.molecule_gnn(**md)
-    return torch.autograd.grad([res, atm], pp + mp, [g_res, g_atm])
+    torch.autograd.backward([res, atm], [g_res, g_atm])
+    for q in pp + mp:
+        q.grad = None
 
 for _ in range(5):
     step()
