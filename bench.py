@@ -154,7 +154,7 @@ def committed_traffic(workload, kernel, dtype="f32"):
     gfx950 correction applied: tools/pmc_summarise.py).  Only reported when the file was measured on the SAME
     kernel sources and workload; otherwise null (a stale number is worse than none)."""
     tag = workload if dtype == "f32" else f"{workload}_{dtype}"
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(REPO, "profiles", rnd, f"pmc_traffic_{tag}.json")
         if not os.path.exists(path) and workload == "davis_b64":
             path = os.path.join(REPO, "profiles", rnd, "pmc_traffic.json")
@@ -478,7 +478,7 @@ def main():
                 nbytes = conv_bytes * (2 if name == "conv_bwd" else 1)
                 avg = sum(times) / len(times)
                 kname = {"conv_fwd": "conv_quad_kernel" if ops.VARIANT == "mfma" else "conv_fwd_kernel",
-                         "conv_bwd": "conv_bwd_kernel"}[name]
+                         "conv_bwd": "conv_bwd_kernel" if os.environ.get("CGVP_CONV_BWD") == "1" else "conv_bwd2_kernel"}[name]
                 hbm = dict(achieved=round(nbytes / avg / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                            frac=round(nbytes / avg / 1e9 / PEAK_HBM_GBS, 4), floor_us=round(nbytes / PEAK_HBM_GBS / 1e3, 2),
                            device_copy_gbs=measured_copy_gbs(dev))      # the box's own copy bandwidth, for context

@@ -172,6 +172,45 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int32_t* __restrict__ cn
   if (t == 0) rowptr[N] = carry;
 }
 
+// The same scan for SHORT tables (N <= SCAN_SMALL: the drug graphs of a batch, ~2.6k atoms) as ONE 256-thread workgroup
+// with 32 KB of static LDS.  Why a second kernel: the drug encoder runs on a side stream beside the protein encoder, whose
+// forward kernels leave every CU holding one or two 4-wave workgroups of ~244 VGPRs; the 1024-thread / 77-VGPR scan above
+// needs 4 waves per SIMD and found no CU to start on until the protein forward had drained (59 us gap in the round-4 step
+// trace, the drug chain then ended 47 us after the protein chain).  One wave per SIMD fits beside them.
+constexpr int SCAN_SMALL = 8192, SCAN_SMALL_T = 256;
+__global__ __launch_bounds__(SCAN_SMALL_T) void csr_scan_small_kernel(int32_t* __restrict__ cnt, int32_t N,
+                                                                      int32_t* __restrict__ rowptr) {
+  __shared__ int32_t sbuf[SCAN_SMALL];
+  __shared__ int32_t part[8];
+  const int t = threadIdx.x;
+  for (int i = t; i < N; i += SCAN_SMALL_T) sbuf[i] = cnt[i];
+  __syncthreads();
+  const int chunk = (N + SCAN_SMALL_T - 1) / SCAN_SMALL_T;
+  const int lo = t * chunk < N ? t * chunk : N, hi = lo + chunk < N ? lo + chunk : N;
+  int32_t sum = 0;
+  for (int i = lo; i < hi; ++i) sum += sbuf[i];
+  int32_t inc = sum;
+#pragma unroll
+  for (int off = 1; off < WAVE; off <<= 1) {
+    const int32_t u = __shfl_up(inc, off);
+    if ((t & (WAVE - 1)) >= off) inc += u;
+  }
+  if ((t & (WAVE - 1)) == WAVE - 1) part[t >> 6] = inc;
+  __syncthreads();
+  int32_t wave_base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_SMALL_T / WAVE; ++w) {
+    const int32_t v = part[w];
+    if (w < (t >> 6)) wave_base += v;
+    total += v;
+  }
+  int32_t run = wave_base + inc - sum;             // exclusive prefix of this thread's chunk
+  for (int i = lo; i < hi; ++i) { const int32_t c = sbuf[i]; sbuf[i] = run; run += c; }
+  __syncthreads();
+  for (int i = t; i < N; i += SCAN_SMALL_T) { const int32_t x = sbuf[i]; rowptr[i] = x; cnt[i] = x; }
+  if (t == 0) rowptr[N] = total;
+}
+
 __global__ void csr_fill_kernel(const int64_t* __restrict__ ei, int64_t N, int64_t E,
                                 int32_t* __restrict__ cursor, int32_t* __restrict__ tmp, int32_t* __restrict__ edst) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -655,8 +694,12 @@ int csr_build(const int64_t* edge_index, int64_t N, int64_t E, int32_t* rowptr, 
     hipLaunchKernelGGL(csr_count_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, work, rng_state, rng_out);
   else if (rng_state)
     hipLaunchKernelGGL(rng_next_kernel, dim3(1), dim3(1), 0, s, rng_state, rng_out);
-  const int64_t tile = N < SCAN_LDS ? (N + 3) / 4 * 4 : SCAN_LDS;
-  hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), (size_t)(tile + 1024 + 32) * sizeof(int32_t), s, work, N, rowptr);
+  if (N <= SCAN_SMALL) {
+    hipLaunchKernelGGL(csr_scan_small_kernel, dim3(1), dim3(SCAN_SMALL_T), 0, s, work, (int32_t)N, rowptr);
+  } else {
+    const int64_t tile = N < SCAN_LDS ? (N + 3) / 4 * 4 : SCAN_LDS;
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), (size_t)(tile + 1024 + 32) * sizeof(int32_t), s, work, N, rowptr);
+  }
   if (E > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, work, tmp, edst);
   const int64_t span = E > counters ? E : counters;
   hipLaunchKernelGGL(csr_rank_kernel, dim3((unsigned)((span + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, counters, rowptr, tmp,

@@ -23,10 +23,11 @@
 // therefore chain GEMM -> elementwise -> GEMM with no LDS round trip and no
 // cross-lane traffic; only LayerNorm statistics cross the 4 lanes of an item.
 //
-// Weight fragments are built once per parameter update by a tiny prep kernel
-// (cgvp_lba_prepare) into an "image" in global memory; each workgroup copies its
-// slice into LDS with straight float4 loads and then every MFMA's A operand is
-// one conflict-free ds_read_b32 (address = fragment base + lane).
+// Weight fragments are built by a tiny prep step (cgvp_lba_prepare / the first launch of a
+// pass) into an "image" in global memory; each workgroup copies its slice into LDS with
+// straight float4 loads.  Inside a GEMM's region the k-steps are grouped by four,
+// lane-major (frag_decode below): one conflict-free ds_read_b128 at 16 B x lane fetches the A
+// operands of four MFMAs (the last steps % 4: one ds_read_b32 each, step-major).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -928,6 +929,28 @@ struct GvpQ {
         outer_items<1, 1, BF>(AH, BI, acch);
       }
       flush_slots<Acc, Segs<Seg<P2, 0, H>>, VSegs, 1, 1>(gblk, first, VI, acch, lane);
+    }
+  }
+
+  // The outputs `forward` returned, re-derived from its cache (so = act(sp), vo = vp * sg): lets a caller that is short of
+  // registers drop a GVP's outputs after the next GVP consumed them and rebuild them where its weight gradients need them as
+  // the next GVP's inputs.  The asm statements hide the cache values' identity from common-subexpression elimination, which
+  // would otherwise keep the first copy alive instead.
+  static __device__ __forceinline__ void outputs_from_cache(const Cache& c, float (&so)[4 * OT], float (&vo)[3][VOR]) {
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = c.sp[t][r];
+        asm volatile("" : "+v"(x));
+        so[4 * t + r] = RELU ? gvp::f_max(x, 0.f) : x;
+      }
+#pragma unroll
+    for (int r = 0; r < VOR; ++r) {
+      float g_ = c.sg[r];
+      asm volatile("" : "+v"(g_));
+#pragma unroll
+      for (int p = 0; p < 3; ++p) vo[p][r] = c.vp[p][r] * g_;
     }
   }
 

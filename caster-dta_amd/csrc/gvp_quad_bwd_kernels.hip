@@ -8,9 +8,12 @@
 //                        the forward (tile mt, register r <-> forward k-slot);
 //   * weight gradients : dW = sum_items dY (x) X as MFMA outer products whose
 //                        operands are transposed through a per-wave LDS scratch;
-//                        every wave accumulates an arena-layout block of its own in
-//                        LDS (no atomics), the workgroup sums its waves' blocks into
-//                        one slab row, one reduce launch sums the rows in a fixed order;
+//                        every wave accumulates an arena-layout block of its own (no
+//                        atomics) -- in LDS with a read-add-write per tile (node / head /
+//                        embed / edge kernels), in REGISTERS for all of a wave's tiles in
+//                        the conv backward (conv_bwd2_kernel, GvpQ::WAcc) -- the workgroup
+//                        sums its waves' blocks into one slab row, one reduce launch sums
+//                        the rows in a fixed order;
 //   * d h[dst]         : in-register segmented scan over the sorted edges (owned
 //                        rows, plain stores);  d h[src]: float atomics (the only
 //                        ones in the library; sources are unsorted).
@@ -861,7 +864,14 @@ __global__ __launch_bounds__(WAVE * C2_WPB) __attribute__((amdgpu_waves_per_eu(C
       typename Msg2<ST>::Grads gr[TN];
       Msg2<ST>::template backward_tn<TN, BF>(imgT + IM::TC_M2, lane, c2, d_so, d_vo, d_b, d_bv, gr);
       STAMP(10);
-      Msg2<ST>::template wacc_accumulate<TN, BF>(w2, lane, zt, b2, bv2, c2, gr, tscr);
+      if constexpr (!PREFETCH) {            // two waves per SIMD: b2 / bv2 were dropped after the forward, rebuilt from msg1's cache
+        float b2r[TN][4], bv2r[TN][3][1];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Msg1<ST>::outputs_from_cache(c1[j], b2r[j], bv2r[j]);
+        Msg2<ST>::template wacc_accumulate<TN, BF>(w2, lane, zt, b2r, bv2r, c2, gr, tscr);
+      } else {
+        Msg2<ST>::template wacc_accumulate<TN, BF>(w2, lane, zt, b2, bv2, c2, gr, tscr);
+      }
     }
     {
       f4 d_so[TN][1];
@@ -876,7 +886,14 @@ __global__ __launch_bounds__(WAVE * C2_WPB) __attribute__((amdgpu_waves_per_eu(C
       STAMP(11);
       Msg1<ST>::template backward_tn<TN, BF>(imgT + IM::TC_M1, lane, c1, d_so, d_vo, d_b, d_bv, gr);
       STAMP(12);
-      Msg1<ST>::template wacc_accumulate<TN, BF>(w1, lane, zt, b1, bv1, c1, gr, tscr);
+      if constexpr (!PREFETCH) {
+        float b1r[TN][4], bv1r[TN][3][1];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Msg0<ST>::outputs_from_cache(c0[j], b1r[j], bv1r[j]);
+        Msg1<ST>::template wacc_accumulate<TN, BF>(w1, lane, zt, b1r, bv1r, c1, gr, tscr);
+      } else {
+        Msg1<ST>::template wacc_accumulate<TN, BF>(w1, lane, zt, b1, bv1, c1, gr, tscr);
+      }
     }
     float d_b0[TN][16], d_bv0[TN][3][3];
     {

@@ -178,6 +178,16 @@ at::Tensor ready(const at::Tensor& t, const char* name, c10::optional<at::Scalar
   return r;
 }
 void* ptr(const at::Tensor& t) { return (t.defined() && t.numel() > 0) ? t.data_ptr() : nullptr; }
+
+// A contiguous [sizes] view of the flat gradient arena at element `offset`, built directly (a TensorImpl on the arena's
+// storage): at::as_strided through the dispatcher costs ~1.3 us per call, and a backward pass hands out 50 + 24 of them.
+inline at::Tensor arena_view(const at::Tensor& arena, c10::IntArrayRef sizes, c10::IntArrayRef strides, int64_t offset) {
+  auto impl = c10::make_intrusive<c10::TensorImpl>(c10::TensorImpl::VIEW, c10::Storage(arena.storage()), arena.key_set(),
+                                                   arena.dtype());
+  impl->set_sizes_and_strides(sizes, strides);
+  impl->set_storage_offset(arena.storage_offset() + offset);
+  return at::Tensor(std::move(impl));
+}
 void* ptr(const c10::optional<at::Tensor>& t) { return t ? ptr(*t) : nullptr; }
 
 struct LbaCfg {
@@ -280,7 +290,7 @@ struct LbaBackward : public Node {
     Tic tic_v("lba_bwd.views");
     int64_t off = 0;
     for (size_t i = 0; i < np; ++i) {      // one view op per parameter (as_strided), not narrow + view
-      if (task_should_compute_output(i)) out[i] = gparams.as_strided(shapes[i], strides[i], off);
+      if (task_should_compute_output(i)) out[i] = arena_view(gparams, shapes[i], strides[i], off);
       off += numels[i];
     }
     if (LeafScatter::run(*this, np, out, gparams))
@@ -483,7 +493,7 @@ struct GineBackward : public Node {
       int64_t off = 0;
       for (size_t i = 0; i < np; ++i) {
         const int64_t n = params[i].numel();
-        if (task_should_compute_output(i)) out[i] = gflat.as_strided(params[i].sizes(), c10::contiguous_strides(params[i].sizes()), off);
+        if (task_should_compute_output(i)) out[i] = arena_view(gflat, params[i].sizes(), c10::contiguous_strides(params[i].sizes()), off);
         off += n;
       }
       if (LeafScatter::run(*this, np, out, gflat))
@@ -587,6 +597,21 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   // loaded at run time reports its own through cgvp_abi_version(): _lib.bridge() requires all three to agree
   m.def("abi_version", []() { return (int)CGVP_ABI_VERSION; });
   m.def("library_abi_version", []() { return (int)cgvp_abi_version(); });
+  m.def("stale_grad_accumulators", [](std::vector<at::Tensor> params) {
+          // A leaf's AccumulateGrad node remembers the stream that was current when it was CREATED, and lives as long as any
+          // autograd graph points at it.  A backward pass inside a stream capture then makes that other stream wait for an
+          // event of the capturing stream: it joins the capture, is never joined back, and hipStreamEndCapture crashes
+          // (segmentation fault on this ROCm build).  Count the leaves whose live accumulator belongs to another stream.
+          int64_t n = 0;
+          for (const at::Tensor& p : params) {
+            if (!p.defined() || !p.requires_grad() || !p.is_leaf() || !p.is_cuda()) continue;
+            auto acc = torch::autograd::impl::try_get_grad_accumulator(p);
+            if (!acc) continue;
+            const auto st = acc->stream();
+            if (st && *st != c10::Stream(c10::hip::getCurrentHIPStream(p.device().index()))) ++n;
+          }
+          return n;
+        }, "leaves whose live AccumulateGrad node was created under another stream than the current one");
   m.def("set_exact_leaves", [](bool on) { const bool was = g_exact_leaves; g_exact_leaves = on; return was; },
         "True: every backward hands the engine one gradient per parameter leaf (the stock autograd path); False (default): "
         "plain loss.backward() passes write the leaves' .grad themselves (LeafScatter)");

@@ -417,8 +417,9 @@ def lba_encoder(model, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, train_dro
                 masks = PINNED_MASKS(2 * model.num_convs, N, MROW, p, dev)
             else:
                 draw = True
+        params = model.op_params()
         with torch.cuda.device(dev):
-            out, ws, zero_copy = br.lba_encoder(model.op_params(), x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, csr, cfg, p,
+            out, ws, zero_copy = br.lba_encoder(params, x_s, x_v, ntypes, e_s, e_v, etypes, edge_index, csr, cfg, p,
                                                 save_state, masks, rng_state("lba", dev) if draw else None,
                                                 None if csr else ops.csr_counters(dev, N), ops.FUSE_LAYER)
         if draw:
@@ -456,6 +457,24 @@ def _gine_cfg(widths, num_ntypes, num_etypes, edge_dim, slope):
         raise NotImplementedError(f"the GINE pass supports 1..{_lib.GINE_MAX_LAYERS} layers")
     w = (C.c_int32 * (_lib.GINE_MAX_LAYERS + 1))(*([int(v) for v in widths] + [0] * (_lib.GINE_MAX_LAYERS - nl)))
     return _lib.GineCfg(nl, w, int(num_ntypes), int(num_etypes), int(edge_dim), float(slope))
+
+
+def _gine_split(flat, widths, num_ntypes, num_etypes, edge_dim):
+    """The 7 L kernel tensors as views of ONE flat tensor laid out in _GINE_KEYS order per layer (what the dispatcher
+    passes under torch.compile: a one-element parameter list costs a fraction of a 14-tensor list in torch.library)."""
+    ke = num_etypes + edge_dim
+    out, off = [], 0
+    for l in range(len(widths) - 1):
+        cin, ch = widths[l], widths[l + 1]
+        for shape in ((1,), (ch, cin), (ch,), (ch, ch), (ch,), (cin, ke), (cin,)):
+            n = 1
+            for v in shape:
+                n *= v
+            out.append(flat[off:off + n].view(shape))
+            off += n
+    if off != flat.numel():
+        raise RuntimeError(f"flat GINE parameter tensor has {flat.numel()} floats, the layers need {off}")
+    return out
 
 
 def _gine_weights(params, nl):
@@ -507,6 +526,8 @@ def gine_forward(params, x, ntypes, eattr, etypes, edge_index, csr, widths, num_
     if x.shape[1] != widths[0] - num_ntypes:
         raise ValueError(f"x has {x.shape[1]} columns, expected {widths[0] - num_ntypes}")
     cfg = _gine_cfg(widths, num_ntypes, num_etypes, edge_dim, slope)
+    if len(params) == 1 and 7 * nl > 1:
+        params = _gine_split(_f32(params[0], "weights"), widths, num_ntypes, num_etypes, edge_dim)
     warr, keep = _gine_weights(params, nl)
     nt = _i64(ntypes, "ntypes") if num_ntypes > 0 else None
     et = _i64(etypes, "etypes") if num_etypes > 0 else None
@@ -567,6 +588,8 @@ def gine_backward(g_out, params, x, ntypes, eattr, etypes, edge_index, csr, ws, 
     N, E, dev = int(x.shape[0]), int(edge_index.shape[1]), x.device
     f32 = dict(dtype=torch.float32, device=dev)
     cfg = _gine_cfg(widths, num_ntypes, num_etypes, int(eattr.shape[1]), slope)
+    if len(params) == 1 and 7 * nl > 1:
+        params = _gine_split(_f32(params[0], "weights"), widths, num_ntypes, num_etypes, int(eattr.shape[1]))
     warr, keep = _gine_weights(params, nl)
     nt = _i64(ntypes, "ntypes") if num_ntypes > 0 else None
     et = _i64(etypes, "etypes") if num_etypes > 0 else None
@@ -662,8 +685,9 @@ def gine_encoder(model, x, ntypes, eattr, etypes, edge_index, slope, train_dropo
                 masks = [PINNED_MASKS(1, N, widths[l + 1], p, dev)[0].contiguous() for l in range(len(widths) - 2)]
             else:
                 draw = True
+        params = gine_params(model, one_leaf_ok=True)
         with torch.cuda.device(dev):
-            out, ws = br.gine_encoder(gine_params(model, one_leaf_ok=True), x, ntypes, eattr, etypes, edge_index, csr, widths,
+            out, ws = br.gine_encoder(params, x, ntypes, eattr, etypes, edge_index, csr, widths,
                                       model.num_ntypes if model._onehot_ntypes else 0,
                                       model.num_etypes, float(slope), p, save_state, masks,
                                       rng_state("gine", dev) if draw else None, None if csr else ops.csr_counters(dev, N),
@@ -671,7 +695,10 @@ def gine_encoder(model, x, ntypes, eattr, etypes, edge_index, slope, train_dropo
         if draw:
             _LAST_WS["gine"] = (ws, 0)
         return out
+    # custom-op path (torch.compile; CGVP_BRIDGE=0): the kernel weights as ONE tensor (see lba_encoder)
+    params = gine_params(model)
+    flat = params[0] if len(params) == 1 else torch.cat([q.reshape(-1) for q in params])
     out, _, _ = torch.ops.caster_gvp.gine_encoder(
-        gine_params(model), x, ntypes, eattr, etypes, edge_index, _memo_tables(edge_index, x.shape[0]), list(model._widths),
+        [flat], x, ntypes, eattr, etypes, edge_index, _memo_tables(edge_index, x.shape[0]), list(model._widths),
         model.num_ntypes if model._onehot_ntypes else 0, model.num_etypes, float(slope), p, save_state)
     return out

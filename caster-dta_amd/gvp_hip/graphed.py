@@ -157,6 +157,24 @@ class GraphedEncoderStep:
         return res[:N], atm[:Na], gp, gd
 
 
+def _check_no_foreign_graph(params):
+    """Observed on this ROCm / PyTorch build (tools/debug_graphed.py, 15 runs): capturing the WHOLE-MODEL backward while an
+    autograd graph of an earlier eager step on another stream is still alive (its `pred` / `loss` held somewhere) ends in
+    a segmentation fault inside hipStreamEndCapture, every time; with that graph dropped, or no eager step before, never.
+    What such a graph keeps alive are the leaves' AccumulateGrad nodes, which remember the stream they were created under
+    (csrc/torch_bridge.cpp, stale_grad_accumulators); the engine synchronises gradient hand-offs with that stream.  The
+    encoder-only captures of GraphedEncoderStep never showed it.  Refuse with a message instead of crashing."""
+    br = _lib.bridge()
+    if br is None:
+        return
+    n = int(br.stale_grad_accumulators(list(params)))
+    if n:
+        raise RuntimeError(
+            f"{n} parameters are still referenced by an autograd graph that was built on another stream (an output or loss "
+            "of an earlier eager step is alive): capturing a backward pass now would pull that stream into the capture. "
+            "Drop those tensors first (`del loss, pred`), or run the eager step after the captured one.")
+
+
 class _TrainBucket:
     def __init__(self, owner, key, pdata, mdata, target, sdt):
         N, E, Na, Ea, B = key
@@ -198,7 +216,7 @@ class GraphedTrainStep:
         self.params = [p for p in model.parameters() if p.numel() and p.requires_grad]
         self.device = self.params[0].device
         self.buckets = {}
-        self.stream = torch.cuda.Stream(device=self.device)
+        self.stream = None                      # capture + replay stream, created at the first capture
         self.pool = None
 
     def _step(self, b, B):
@@ -278,9 +296,12 @@ class GraphedTrainStep:
             del keep
             return self._publish(b)
         caller = torch.cuda.current_stream()
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=self.device)
         self.stream.wait_stream(caller)
         was_training = self.model.training
         with torch.cuda.stream(self.stream), torch.enable_grad():
+            _check_no_foreign_graph(self.params)
             if b is None:
                 b = self.buckets[(key, sdt)] = _TrainBucket(self, key, pdata, mdata, target, sdt)
             keep = self._stage(b, pdata, mdata, target)

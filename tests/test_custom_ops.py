@@ -231,6 +231,7 @@ def test_autocast_and_gradscaler_equal_the_fp32_step(protein_params, molecule_pa
 
     a, b = step(False), step(True)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    scale = max(float(ga.abs().max()) for ga in a[2])
     for ga, gb_ in zip(a[2], b[2]):
         assert torch.isfinite(gb_).all()
-        assert float((ga - gb_).abs().max()) <= 1e-5 * float(ga.abs().max()) + 1e-9
+        assert float((ga - gb_).abs().max()) <= 1e-5 * float(ga.abs().max()) + 1e-7 * scale

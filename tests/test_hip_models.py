@@ -757,8 +757,12 @@ def test_graphed_train_step_equals_eager(pretrained):
         target = torch.randn(6, 1, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed))
         pred, _ = model(pd, md)
         loss = torch.nn.functional.mse_loss(pred, target)
-        ref = torch.autograd.grad(loss, params)
+        ref = torch.autograd.grad(loss, params, retain_graph=True)
         model.zero_grad(set_to_none=True)
+        if seed == 1:            # an eager graph built on ANOTHER stream is still alive: capturing now would pull that stream in
+            with pytest.raises(RuntimeError, match="built on another stream"):
+                runner.run(pd, md, target)
+        pred, loss = pred.detach().clone(), loss.detach().clone()        # (drops the eager graph)
         gl, gp = runner.run(pd, md, target)
         torch.cuda.synchronize()
         assert float((gl - loss).abs()) <= 1e-5 * float(loss.abs())

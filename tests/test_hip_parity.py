@@ -252,8 +252,9 @@ def test_feature_table_wire_format(protein_params):
     finally:
         ops.CSR_CACHE_ENABLED = old
     assert torch.equal(out, ref)                              # same kernels, same per-edge arithmetic, same order
-    for a, b in zip(g_out, g_ref):
-        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9
+    scale = max(float(b.abs().max()) for b in g_ref)           # (analytically-zero gradients are rounding noise that the
+    for a, b in zip(g_out, g_ref):                              # backward's d h[src] atomics reorder: floor tied to the scale)
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-7 * scale
 
 
 def test_csr_build_with_dirty_counters_stays_inside_its_tables():

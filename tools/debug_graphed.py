@@ -22,7 +22,19 @@ pd, md = to(ds.to_torch(p)), to(ds.to_torch(m))
 pd["ptr"], md["ptr"] = torch.as_tensor(p.ptr).to("cuda:0"), torch.as_tensor(m.ptr).to("cuda:0")
 target = torch.randn(pairs, 1, device="cuda:0")
 runner = GraphedTrainStep(model, torch.nn.functional.mse_loss)
-print("start", mode, pairs, length, flush=True)
+pre = sys.argv[4] if len(sys.argv) > 4 else "none"
+params = [q for q in model.parameters() if q.numel()]
+if pre in ("fwd", "grad", "grad_sync", "backward"):
+    pred, _ = model(pd, md)
+    loss = torch.nn.functional.mse_loss(pred, target)
+    if pre in ("grad", "grad_sync"):
+        ref = torch.autograd.grad(loss, params)
+    if pre == "backward":
+        loss.backward()
+    if pre == "grad_sync":
+        torch.cuda.synchronize()
+    model.zero_grad(set_to_none=True)
+print("start", mode, pairs, length, pre, flush=True)
 loss, pred = runner.run(pd, md, target)
 torch.cuda.synchronize()
 print("ok", float(loss), flush=True)
