@@ -92,6 +92,7 @@ struct GineQArgs {
   const float* eps; const float* we; const float* be; const float* w0; const float* b0;
   const float* w1; const float* b1; float slope;
   const float* mask; gvp::RngArgs rng; const float* g_out; float* g_x; float* slab;
+  const float* agg_in; const uint16_t* pos_in;       // SAVED instantiation: the forward's aggregates [N][CINP] and ReLU patterns
 };
 
 // dropout factors of channels 16 mt + 4 g .. + 3 of atom n (given mask row of width COUT, or regenerated)
@@ -243,6 +244,25 @@ __device__ __forceinline__ void edge_inputs(const ArgsT& a, int32_t eid, int32_t
       xj[mt][r] = active ? v : 0.f;
     }
 }
+//   k-slots [onehot(bond type) | bond features] of edge `eid` alone (the backward from saved aggregates needs no source row)
+template <class Q, int NET, int ED, typename ArgsT>
+__device__ __forceinline__ void edge_features(const ArgsT& a, int32_t eid, int32_t et, bool active, int g, float (&fs)[4]) {
+  constexpr int KE = Q::KE;
+  const int64_t er = (int64_t)(active ? eid : 0) * ED;
+  float f[4];
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) {
+    int col = 4 * s_ + g - NET;
+    col = col < 0 ? 0 : (col >= ED ? ED - 1 : col);
+    f[s_] = a.eattr[er + col];
+  }
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) {
+    const int idx = 4 * s_ + g;
+    const float v = idx < NET ? (et == idx ? 1.f : 0.f) : (idx < KE ? f[s_] : 0.f);
+    fs[s_] = active ? v : 0.f;
+  }
+}
 //   the (typed) feature row of atom n0 + i of the tile (zeros for the lanes behind the last atom)
 template <class Q, int CIN, int NT, bool PIN, typename ArgsT>
 __device__ __forceinline__ void node_inputs(const ArgsT& a, int64_t n, bool valid, int64_t n0, int g, f4 (&xi)[Q::MI]) {
@@ -297,7 +317,11 @@ __device__ __forceinline__ void dw1_band(const f4 (&AT)[Q::MO], const f4 (&BT)[Q
   }
 }
 
-template <int CIN, int CHID, int COUT, int NT, int NET, int ED>
+// SAVED: the forward pass of the same step stored the aggregated messages and every message's ReLU pattern
+// (cgvp_gine_fwd_ws.agg / .pos): phase A -- the gather of the source rows (CIN floats per edge), W_e e, ReLU and the segmented
+// sum, 48 % of a tile's cycles in the round-3 stamps -- is replaced by one row load per atom, and the edge phase reads 8 bytes
+// of pattern per edge instead of recomputing the messages.  !SAVED: the fine-grained entry point (no forward workspace).
+template <int CIN, int CHID, int COUT, int NT, int NET, int ED, bool SAVED>
 __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) void gine_quad_bwd_kernel(GineQArgs a) {
   typedef GineQ<CIN, CHID, COUT, NT, NET, ED> Q;
   constexpr int GQ_WPB = Q::WPB, GQ_TPB = Q::TPB;
@@ -339,7 +363,7 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
     int32_t c_src[NTL], c_dst[NTL];
     float c_fs[NTL][1][4];
     unsigned c_pos[NTL];                                   // bit 4 mt + r: message channel passed the ReLU
-    const bool single = e1 - e0 <= NTL * TILE;
+    const bool single = !SAVED && e1 - e0 <= NTL * TILE;
 
     auto load_chunk = [&](int32_t c0, int lane, f4 (&xj)[NTL][MI]) {
       const int i = lane & 15, g = lane >> 4;
@@ -373,8 +397,8 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
       c_pos[t] = pos;
     };
 
-    // ---- A. aggregate relu(x_src + e) over the incoming edges of the owned atoms
-    for (int32_t c0 = e0; c0 < e1; c0 += NTL * TILE) {
+    // ---- A. aggregate relu(x_src + e) over the incoming edges of the owned atoms (SAVED: read in phase B instead)
+    for (int32_t c0 = e0; !SAVED && c0 < e1; c0 += NTL * TILE) {
       const int lane = opaque_lane(lane0), i = lane & 15, g = lane >> 4;
       f4 xj[NTL][MI];
       GSTAMP(8);
@@ -415,7 +439,13 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
       node_inputs<Q, CIN, NT, G_PIN>(a, n, valid, n0, g, xi);
 #pragma unroll
       for (int mt = 0; mt < MI; ++mt) {
-        const f4 ag = *reinterpret_cast<const f4*>(rows + i * CINP + 16 * mt + 4 * g);
+        f4 ag;
+        if (SAVED) {
+          ag = *reinterpret_cast<const f4*>(a.agg_in + (valid ? n : n0) * CINP + 16 * mt + 4 * g);
+          if (!valid) ag = zero;
+        } else {
+          ag = *reinterpret_cast<const f4*>(rows + i * CINP + 16 * mt + 4 * g);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[mt][r] = fmaf(eps1, xi[mt][r], ag[r]);
       }
@@ -534,7 +564,21 @@ __global__ __launch_bounds__((WAVE * GineQ<CIN, CHID, COUT, NT, NET, ED>::WPB)) 
     // ---- C. edges again: d message -> sources, lin weight gradients
     for (int32_t c0 = e0; c0 < e1; c0 += NTL * TILE) {
       const int lane = opaque_lane(lane0), i = lane & 15, g = lane >> 4;
-      if (!single) {                               // more than one chunk: its registers were overwritten
+      if (SAVED) {                                 // metadata, bond features and the saved ReLU patterns: no source rows
+        int32_t m_eid, m_src, m_dst, m_et;
+        chunk_meta<NET>(a, c0, e1, lane, m_eid, m_src, m_dst, m_et);
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+          const int sl = 16 * t + i;
+          const int32_t eid = __shfl(m_eid, sl), et = __shfl(m_et, sl);
+          c_src[t] = __shfl(m_src, sl);
+          c_dst[t] = __shfl(m_dst, sl);
+          edge_features<Q, NET, ED>(a, eid, et, c_dst[t] >= 0, g, c_fs[t][0]);
+          const int32_t p = c0 + sl;
+          const unsigned bits = a.pos_in[(int64_t)(p < e1 ? p : e1 - 1) * 4 + g];
+          c_pos[t] = c_dst[t] >= 0 ? bits : 0u;
+        }
+      } else if (!single) {                        // more than one chunk: its registers were overwritten
         f4 xj[NTL][MI];
         load_chunk(c0, lane, xj);
 #pragma unroll
@@ -613,6 +657,7 @@ struct GineFArgs {
   const int32_t* rowptr; const int32_t* eperm; const int32_t* esrc; const int32_t* edst; int64_t N;
   const float* eps; const float* we; const float* be; const float* w0; const float* b0;
   const float* w1; const float* b1; float slope; const float* mask; gvp::RngArgs rng; float* out;
+  float* agg_out; uint16_t* pos_out;                 // training passes: saved for the backward (may be null)
 };
 // Waves per workgroup of the forward kernel.  Same A/B: 4 waves (40 workgroups at davis_b64) -> drug chain alone 163 us,
 // step with both encoders 266-270 us; 8 waves (20 workgroups) -> 171 us alone, 260 us with both: fewer CUs are taken
@@ -666,6 +711,7 @@ __global__ __launch_bounds__(GF_TPB) void gine_quad_fwd_kernel(GineFArgs a) {
       for (int t = 0; t < NTL; ++t) {
         if (c0 + t * TILE >= e1) break;
         float xs[4 * MI];
+        unsigned pos = 0u;
 #pragma unroll
         for (int mt = 0; mt < MI; ++mt) {
           f4 acc[1] = {*reinterpret_cast<const f4*>(frag + VBE + 16 * mt + 4 * g)};
@@ -673,9 +719,13 @@ __global__ __launch_bounds__(GF_TPB) void gine_quad_fwd_kernel(GineFArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float mj = xj[t][mt][r] + acc[0][r];
-            xs[4 * mt + r] = (c_dst[t] >= 0 && mj > 0.f) ? mj : 0.f;
+            const bool on = c_dst[t] >= 0 && mj > 0.f;
+            xs[4 * mt + r] = on ? mj : 0.f;
+            pos |= on ? (1u << (4 * mt + r)) : 0u;
           }
         }
+        if (a.pos_out && c_dst[t] >= 0)               // the message's ReLU pattern, for the backward of this step
+          a.pos_out[(int64_t)(c0 + 16 * t + i) * 4 + g] = (uint16_t)pos;
         const int32_t dst = c_dst[t];
         seg_scan16<4 * MI>(dst, xs);
         const int nxt = __builtin_amdgcn_update_dpp(-1, dst, 0x100 | 1, 0xf, 0xf, false);
@@ -701,6 +751,7 @@ __global__ __launch_bounds__(GF_TPB) void gine_quad_fwd_kernel(GineFArgs a) {
 #pragma unroll
       for (int mt = 0; mt < MI; ++mt) {
         const f4 ag = *reinterpret_cast<const f4*>(rows + i * CINP + 16 * mt + 4 * g);
+        if (a.agg_out && valid) *reinterpret_cast<f4*>(a.agg_out + n * CINP + 16 * mt + 4 * g) = ag;
 #pragma unroll
         for (int r = 0; r < 4; ++r) bh[0][4 * mt + r] = fmaf(eps1, xi[mt][r], ag[r]);
       }
@@ -752,8 +803,13 @@ int launch(GineQArgs& a, int cap, int* rows, int* row_len, hipStream_t st) {
   int64_t wgs = (tiles + GQ_WPB - 1) / GQ_WPB;
   const int G = (int)(wgs < 1 ? 1 : (wgs > cap ? cap : wgs));
   const size_t lds = (size_t)Q::LDS_FLOATS * sizeof(float);
-  CGVP_SET_DYN_LDS_ONCE((gine_quad_bwd_kernel<CIN, CHID, COUT, NT, NET, ED>), lds);
-  hipLaunchKernelGGL((gine_quad_bwd_kernel<CIN, CHID, COUT, NT, NET, ED>), dim3(G), dim3(GQ_TPB), lds, st, a);
+  if (a.agg_in && a.pos_in) {
+    CGVP_SET_DYN_LDS_ONCE((gine_quad_bwd_kernel<CIN, CHID, COUT, NT, NET, ED, true>), lds);
+    hipLaunchKernelGGL((gine_quad_bwd_kernel<CIN, CHID, COUT, NT, NET, ED, true>), dim3(G), dim3(GQ_TPB), lds, st, a);
+  } else {
+    CGVP_SET_DYN_LDS_ONCE((gine_quad_bwd_kernel<CIN, CHID, COUT, NT, NET, ED, false>), lds);
+    hipLaunchKernelGGL((gine_quad_bwd_kernel<CIN, CHID, COUT, NT, NET, ED, false>), dim3(G), dim3(GQ_TPB), lds, st, a);
+  }
   *rows = G;
   *row_len = Q::L_SIZE;
   return 0;
@@ -767,10 +823,11 @@ int gine_bwd(int cin, int chid, int cout, int nt, int net, int ed, const float* 
              const float* eattr, const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,
              const int32_t* esrc, const int32_t* edst, int64_t N, const cgvp_gine_w* w, float slope,
              const float* mask, gvp::RngArgs rng, const float* g_out, float* g_x, float* slab, int max_workgroups,
-             int* rows, int* row_len, hipStream_t st) {
+             int* rows, int* row_len, hipStream_t st, const float* agg_in, const uint16_t* pos_in) {
   const int cap = max_workgroups <= 0 ? kGineBwdDefaultGrid : (max_workgroups > kGineBwdMaxGrid ? kGineBwdMaxGrid : max_workgroups);
+  if (((uintptr_t)agg_in & 15) || ((uintptr_t)pos_in & 1)) return CGVP_ERR_BAD_ARG;
   GineQArgs a{x, ntypes, eattr, etypes, rowptr, eperm, esrc, edst, N, w->eps, w->we, w->be, w->w0, w->b0,
-              w->w1, w->b1, slope, mask, rng, g_out, g_x, slab};
+              w->w1, w->b1, slope, mask, rng, g_out, g_x, slab, agg_in, pos_in};
   // compiled for the layer shapes of HomoMoleculeGNN_GINE in CASTER-DTA (molecule_gnn.py:240-250)
   if (cin == 52 && chid == 16 && cout == 16 && nt == 11 && net == 5 && ed == 9) return launch<52, 16, 16, 11, 5, 9>(a, cap, rows, row_len, st);
   if (cin == 52 && chid == 16 && cout == 16 && nt == 0 && net == 5 && ed == 9) return launch<52, 16, 16, 0, 5, 9>(a, cap, rows, row_len, st);   // nn.Embedding atom types (11-wide), materialised by the host
@@ -784,9 +841,10 @@ int gine_bwd(int cin, int chid, int cout, int nt, int net, int ed, const float* 
 int gine_fwd(int cin, int chid, int cout, int nt, int net, int ed, const float* x, const int64_t* ntypes,
              const float* eattr, const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,
              const int32_t* esrc, const int32_t* edst, int64_t N, const cgvp_gine_w* w, float slope,
-             const float* mask, gvp::RngArgs rng, float* out, hipStream_t st) {
+             const float* mask, gvp::RngArgs rng, float* out, float* agg_out, uint16_t* pos_out, hipStream_t st) {
+  if ((uintptr_t)agg_out & 15) return CGVP_ERR_BAD_ARG;
   GineFArgs a{x, ntypes, eattr, etypes, rowptr, eperm, esrc, edst, N, w->eps, w->we, w->be, w->w0, w->b0,
-              w->w1, w->b1, slope, mask, rng, out};
+              w->w1, w->b1, slope, mask, rng, out, agg_out, pos_out};
   if (cin == 52 && chid == 16 && cout == 16 && nt == 11 && net == 5 && ed == 9) return launch_fwd<52, 16, 16, 11, 5, 9>(a, st);
   if (cin == 52 && chid == 16 && cout == 16 && nt == 0 && net == 5 && ed == 9) return launch_fwd<52, 16, 16, 0, 5, 9>(a, st);
   if (cin == 16 && chid == 64 && cout == 64 && nt == 0 && net == 5 && ed == 9) return launch_fwd<16, 64, 64, 0, 5, 9>(a, st);

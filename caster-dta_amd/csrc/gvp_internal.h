@@ -84,11 +84,11 @@ int gine_bwd(int cin, int chid, int cout, int nt, int net, int ed, const float* 
              const float* eattr, const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,
              const int32_t* esrc, const int32_t* edst, int64_t N, const cgvp_gine_w* w, float slope,
              const float* mask, gvp::RngArgs rng, const float* g_out, float* g_x, float* slab, int max_workgroups, int* rows,
-             int* row_len, hipStream_t st);
+             int* row_len, hipStream_t st, const float* agg_in = nullptr, const uint16_t* pos_in = nullptr);
 int gine_fwd(int cin, int chid, int cout, int nt, int net, int ed, const float* x, const int64_t* ntypes,
              const float* eattr, const int64_t* etypes, const int32_t* rowptr, const int32_t* eperm,
              const int32_t* esrc, const int32_t* edst, int64_t N, const cgvp_gine_w* w, float slope,
-             const float* mask, gvp::RngArgs rng, float* out, hipStream_t st);
+             const float* mask, gvp::RngArgs rng, float* out, float* agg_out, uint16_t* pos_out, hipStream_t st);
 int reduce_slab(const float* slab, int rows, int stride, int col0, int len, float* dst, hipStream_t st);
 int reduce_segments(const cgvp_segment* segs, int nsegs, float* grad_params, hipStream_t st, int overwrite = 0);
 int bwd_block_sizes(int nt_node, int nt_edge, int* emb, int* conv_edge, int* conv_total, int* node, int* head);

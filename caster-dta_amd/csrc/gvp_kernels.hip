@@ -1068,7 +1068,7 @@ int cgvp_gine_conv_fwd(const float* x, const int64_t* ntypes, int32_t num_ntypes
   // out / mask); variant 1 or any other shape: generic one-wave-per-atom kernel
   if (variant == 0 && edst && !((uintptr_t)out & 15) && !((uintptr_t)mask & 15)) {
     const int rc = quad::gine_fwd(cin, chid, cout, num_ntypes, num_etypes, edge_dim, x, ntypes, eattr, etypes, rowptr,
-                                  eperm, esrc, edst, N, w, act_slope, mask, ra, out, (hipStream_t)stream);
+                                  eperm, esrc, edst, N, w, act_slope, mask, ra, out, nullptr, nullptr, (hipStream_t)stream);
     if (rc <= 0) return rc < 0 ? rc : launch_status();
   }
   GineArgs a{x, ntypes, num_ntypes, eattr, etypes, num_etypes, edge_dim, rowptr, eperm, esrc, N, cin,

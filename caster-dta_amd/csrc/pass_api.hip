@@ -11,6 +11,7 @@
 // points (which validate their arguments) or the quad:: launchers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <atomic>
 #include <mutex>
@@ -48,6 +49,12 @@ constexpr int EROW = CGVP_EDGE_ROW;
 constexpr int MROW = 20;                // dropout mask row: 16 scalar + 4 vector-channel factors
 
 inline int64_t up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+// A/B switch (environment, read once): CGVP_GINE_RECOMPUTE=1 makes the drug backward recompute its aggregates as it did
+// until round 3 instead of reading what the forward saved (the forward then saves nothing).
+inline bool gine_recompute() {
+  static const bool v = [] { const char* e = getenv("CGVP_GINE_RECOMPUTE"); return e && e[0] == '1'; }();
+  return v;
+}
 inline int num_convs_of(const cgvp_layout& l) { return l.conv_stride > 0 ? (l.ln_out - l.conv0) / l.conv_stride : 0; }
 inline int esize(const cgvp_dims* d) { return d->storage == CGVP_BF16 ? 2 : 4; }
 inline int launch_status() {
@@ -381,9 +388,13 @@ int cgvp_gine_fwd_workspace(const cgvp_gine_cfg* cfg, int64_t N, int64_t E, int3
   const int L = cfg->num_layers;
   Bump b;
   out->seed = b.take(16);
-  for (int l = 0; l < CGVP_GINE_MAX_LAYERS; ++l) out->hidden[l] = 0;
+  for (int l = 0; l < CGVP_GINE_MAX_LAYERS; ++l) out->hidden[l] = out->agg[l] = out->pos[l] = 0;
   if (save_state) {
     for (int l = 0; l < L - 1; ++l) out->hidden[l] = b.take(N * cfg->widths[l + 1] * 4);
+    for (int l = 0; l < L; ++l) {
+      out->agg[l] = b.take(N * ((cfg->widths[l] + 15) / 16 * 16) * 4);
+      out->pos[l] = b.take((E > 0 ? E : 1) * 8);
+    }
   } else {                                              // inference: two ping-pong buffers of the widest hidden layer
     int maxw = 1;
     for (int l = 1; l < L; ++l) maxw = cfg->widths[l] > maxw ? cfg->widths[l] : maxw;
@@ -439,11 +450,29 @@ int cgvp_gine_forward_pass(const cgvp_gine_cfg* cfg, const cgvp_gine_w* w, const
     float* y = lastl ? out : at<float>(workspace, ws.hidden[l]);
     cgvp_rng rng{draw ? seed : nullptr, dropout_p, l};
     const bool dl = drop && !lastl;
-    if (int rc = cgvp_gine_conv_fwd(x, first ? batch->ntypes : nullptr, first ? cfg->num_ntypes : 0, batch->eattr, batch->etypes,
-                                    cfg->num_etypes, cfg->edge_dim, rowptr, eperm, esrc, edst, N, E, cfg->widths[l],
-                                    cfg->widths[l + 1], cfg->widths[l + 1], w + l, cfg->act_slope,
-                                    (dl && masks) ? masks[l] : nullptr, (dl && draw) ? &rng : nullptr, variant, y, stream))
-      return rc;
+    bool done = false;
+    if (save_state) {
+      // training pass: the tile kernels (whatever `variant` says), which also SAVE the aggregated messages and their ReLU
+      // patterns for the backward (cgvp_gine_fwd_ws.agg / .pos); a width they are not compiled for takes the generic
+      // kernel below -- and has no backward kernel either
+      if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return CGVP_ERR_BAD_ARG;
+      gvp::RngArgs ra{(dl && draw) ? reinterpret_cast<const unsigned long long*>(seed) : nullptr, dropout_p, l};
+      if (!(dl && draw)) ra = gvp::RngArgs{nullptr, 0.f, 0};
+      const int rc = quad::gine_fwd(cfg->widths[l], cfg->widths[l + 1], cfg->widths[l + 1], first ? cfg->num_ntypes : 0,
+                                    cfg->num_etypes, cfg->edge_dim, x, first ? batch->ntypes : nullptr, batch->eattr,
+                                    batch->etypes, rowptr, eperm, esrc, edst, N, w + l, cfg->act_slope,
+                                    (dl && masks) ? masks[l] : nullptr, ra, y,
+                                    gine_recompute() ? nullptr : at<float>(workspace, ws.agg[l]),
+                                    gine_recompute() ? nullptr : at<uint16_t>(workspace, ws.pos[l]), st);
+      if (rc < 0 || rc > 1) return rc;
+      done = rc == 0;
+    }
+    if (!done)
+      if (int rc = cgvp_gine_conv_fwd(x, first ? batch->ntypes : nullptr, first ? cfg->num_ntypes : 0, batch->eattr, batch->etypes,
+                                      cfg->num_etypes, cfg->edge_dim, rowptr, eperm, esrc, edst, N, E, cfg->widths[l],
+                                      cfg->widths[l + 1], cfg->widths[l + 1], w + l, cfg->act_slope,
+                                      (dl && masks) ? masks[l] : nullptr, (dl && draw) ? &rng : nullptr, variant, y, stream))
+        return rc;
     x = y;
   }
   return launch_status();
@@ -507,7 +536,8 @@ int cgvp_gine_backward_pass(const cgvp_gine_cfg* cfg, const cgvp_gine_w* w, cons
     if (int rc = quad::gine_bwd(cfg->widths[l], cfg->widths[l + 1], cfg->widths[l + 1], first ? cfg->num_ntypes : 0,
                                 cfg->num_etypes, cfg->edge_dim, x, first ? batch->ntypes : nullptr, batch->eattr, batch->etypes,
                                 rowptr, eperm, esrc, edst, N, w + l, cfg->act_slope, mask, ra, g, gxl, slab, max_workgroups,
-                                &rows, &row_len, st))
+                                &rows, &row_len, st, gine_recompute() ? nullptr : at<float>(fwd_workspace, ws.agg[l]),
+                                gine_recompute() ? nullptr : at<uint16_t>(fwd_workspace, ws.pos[l])))
       return rc;
     segs[l] = cgvp_segment{slab, rows, row_len, 0,
                            gine_layer_floats(cfg->widths[l], cfg->widths[l + 1], cfg->widths[l + 1], ke), loff[l]};

@@ -15,11 +15,11 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CGVP_LIB_PATH: A/B builds of the same ABI (diagnostics); the default is the in-tree library
 LIB_PATH = os.environ.get("CGVP_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libcaster_gvp.so")
-ABI_VERSION = 28
+ABI_VERSION = 29
 # sha256 of include/caster_gvp.h with comments, blank space and the CGVP_ABI_VERSION line removed, as
 # `abi_header_digest()` computes it.  tests/test_abi.py fails when the header's declarations change
 # without CGVP_ABI_VERSION, ABI_VERSION and this digest being updated together.
-ABI_HEADER_SHA256 = "1eed80772966b9bacdc7fe690477bba4b8e1ada1e5b03f566031727b31e48534"
+ABI_HEADER_SHA256 = "362eacc64a468f7a3f91503a8f667d128e3a4dbc6a5b29f605a976517cde6195"
 
 
 class HipLibraryError(RuntimeError):
@@ -95,7 +95,8 @@ class GineBatch(C.Structure):
 
 
 class GineFwdWs(C.Structure):
-    _fields_ = [("seed", C.c_int64), ("hidden", C.c_int64 * GINE_MAX_LAYERS)] + [(n, C.c_int64) for n in (
+    _fields_ = [("seed", C.c_int64), ("hidden", C.c_int64 * GINE_MAX_LAYERS), ("agg", C.c_int64 * GINE_MAX_LAYERS),
+                ("pos", C.c_int64 * GINE_MAX_LAYERS)] + [(n, C.c_int64) for n in (
         "rowptr", "eperm", "esrc", "edst", "saved", "ids_scratch", "total")]
 
 

@@ -151,6 +151,8 @@ def gine_fwd_ws_bytes(N, E, widths, save_state, saved_only=False):
     e1 = E if E > 0 else 1
     if save_state:
         hidden = sum(_up(N * widths[l + 1] * 4) for l in range(L - 1))
+        # + per layer: the aggregated messages [N][ceil16(width)] fp32 and 8 B of ReLU pattern per sorted edge (ABI v29)
+        hidden += sum(_up(N * ((widths[l] + 15) // 16 * 16) * 4) + _up(e1 * 8) for l in range(L))
     else:
         hidden = 2 * _up(N * max([1] + list(widths[1:L])) * 4)
     return _up(16) + hidden + _up((N + 1) * 4) + (3 if saved_only else 4) * _up(e1 * 4)

@@ -1,4 +1,4 @@
-# models/_caster_gvp.py -- ctypes binding of libcaster_gvp.so (C ABI v28): the protein encoder forward
+# models/_caster_gvp.py -- ctypes binding of libcaster_gvp.so (C ABI v29): the protein encoder forward
 # (VectorProteinGNN_LBAModel.forward, protein_gnn.py:361-388) on the MFMA kernels, nothing but torch + ctypes.
 import ctypes as C
 import torch                                           # import torch first: it provides the HIP runtime
@@ -29,7 +29,7 @@ class ProteinEncoder:
         """state_dict: the `protein_gnn.gnn_model.*` slice of a CASTER-DTA checkpoint (keys without that prefix)."""
         self.lib = lib = C.CDLL(lib_path)
         lib.cgvp_lba_image_floats.restype = C.c_int64
-        assert lib.cgvp_abi_version() == 28
+        assert lib.cgvp_abi_version() == 29
         self.num_convs = num_convs
         self.dims, self.lay = Dims(17, 3, 32, 1, 16, 4, 32, 1, 64, 0, 0), Layout()     # storage 0 = fp32 activations, 1 = bf16
         check(lib.cgvp_lba_layout(C.byref(self.dims), num_ntypes, num_etypes, num_convs, C.byref(self.lay)), "cgvp_lba_layout")

@@ -1,4 +1,4 @@
-# models/_caster_gvp_pass.py -- ctypes binding of the WHOLE-PASS entry points of libcaster_gvp.so (C ABI v28): one call
+# models/_caster_gvp_pass.py -- ctypes binding of the WHOLE-PASS entry points of libcaster_gvp.so (C ABI v29): one call
 # runs VectorProteinGNN_LBAModel.forward (protein_gnn.py:361-388), one call its backward -- the production path.
 # Nothing but torch + ctypes; every buffer is the caller's.
 import ctypes as C
@@ -40,7 +40,7 @@ class ProteinEncoder:
         self.lib = lib = C.CDLL(lib_path)
         lib.cgvp_lba_bwd_workspace_bytes.restype = C.c_int64
         lib.cgvp_lba_bwd_workspace_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
-        assert lib.cgvp_abi_version() == 28
+        assert lib.cgvp_abi_version() == 29
         self.dims, self.lay = Dims(17, 3, 32, 1, 16, 4, 32, 1, 64, 0, 0), Layout()
         check(lib.cgvp_lba_layout(C.byref(self.dims), num_ntypes, num_etypes, num_convs, C.byref(self.lay)), "cgvp_lba_layout")
         # ONE fp32 arena with the weights in state_dict order (zero-size dummy_params skipped); gradients come back the same way

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CGVP_ABI_VERSION 28
+#define CGVP_ABI_VERSION 29
 #define CGVP_ERR_BAD_ARG (-1)
 #define CGVP_ERR_UNSUPPORTED_DIMS (-2)
 
@@ -520,6 +520,12 @@ typedef struct {
 typedef struct {
   int64_t seed;                                /* uint64[2]                                                            */
   int64_t hidden[CGVP_GINE_MAX_LAYERS];        /* hidden[l]: output of layer l, l < L - 1 ([N][widths[l + 1]] fp32)     */
+  /* training passes only (save_state): what the backward of layer l would otherwise recompute from the gathered source
+   * rows -- agg[l]: the aggregated messages sum_j relu(x_j + W_e e_ji + b) per atom, [N][ceil16(widths[l])] fp32;
+   * pos[l]: the ReLU pattern of every message, 4 x uint16 per SORTED edge position (bit 4 mt + r of word g <-> channel
+   * 16 mt + 4 g + r); 0 when not saved */
+  int64_t agg[CGVP_GINE_MAX_LAYERS];
+  int64_t pos[CGVP_GINE_MAX_LAYERS];
   int64_t rowptr, eperm, esrc, edst;
   int64_t saved;                               /* the backward pass reads bytes [0, saved) only                        */
   int64_t ids_scratch;                         /* forward-only scratch behind them                                      */
