@@ -17,6 +17,7 @@
 // the plain nn.Linear weights while staging them into LDS (the matrices are tiny), so GINE needs
 // no fragment image.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "gvp_internal.h"
@@ -785,10 +786,12 @@ int launch_fwd(GineFArgs& a, hipStream_t st) {
   typedef GineQ<CIN, CHID, COUT, NT, NET, ED> Q;
   const int64_t tiles = (a.N + TILE - 1) / TILE;
   int64_t wgs = (tiles + GF_WPB - 1) / GF_WPB;
-#ifndef CGVP_GINE_FWD_MAX_WGS
-#define CGVP_GINE_FWD_MAX_WGS 1024
-#endif
-  const int G = (int)(wgs < 1 ? 1 : (wgs > CGVP_GINE_FWD_MAX_WGS ? CGVP_GINE_FWD_MAX_WGS : wgs));
+  static const int cap = [] {                  // CGVP_GINE_FWD_WGS=<n>: workgroup cap of the forward (A/B knob, read once)
+    const char* e = getenv("CGVP_GINE_FWD_WGS");
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 ? v : 1024;
+  }();
+  const int G = (int)(wgs < 1 ? 1 : (wgs > cap ? cap : wgs));
   const size_t lds = (size_t)((Q::GE::NFRAG + Q::G0::NFRAG + Q::G1::NFRAG) * 64 + Q::CINP + CHID + COUT + GF_WPB * Q::ROWS) * sizeof(float);
   CGVP_SET_DYN_LDS_ONCE((gine_quad_fwd_kernel<CIN, CHID, COUT, NT, NET, ED>), lds);
   hipLaunchKernelGGL((gine_quad_fwd_kernel<CIN, CHID, COUT, NT, NET, ED>), dim3(G), dim3(GF_TPB), lds, st, a);

@@ -65,6 +65,11 @@ int node_update_bwd(const float* img_node, const float* imgT_node, const float* 
                     int bf16, hipStream_t st);
 int head_bwd(const float* img_head, const float* imgT_head, const float* h_out, const float* g_out, int64_t N,
              float* g_h_out, float* slab, int* grid, int bf16, hipStream_t st);
+// head_bwd + node_update_bwd of the last layer as ONE launch (g_h_out doubles as the node stage's upstream gradient)
+int node_head_bwd(const float* img_head, const float* imgT_head, const float* h_out, const float* g_out, float* g_h_out,
+                  float* head_slab, const float* img_node, const float* imgT_node, const float* h, const float* dh,
+                  const float* mask0, const float* mask1, gvp::RngArgs rng, int64_t N, float* g_dh, float* g_h,
+                  float* zero_rows, float* slab, int* grid, int bf16, hipStream_t st);
 int conv_bwd(int nt_edge, const float* img, const float* imgT, const float* h, const float* e_emb,
              const int32_t* rowptr, const int32_t* esrc, const int32_t* edst, int64_t N, int64_t E, int mean,
              const float* g_dh, float* g_src, float* g_dst, float* g_e, float* slab, int* grid, int bf16, hipStream_t st);
@@ -72,6 +77,18 @@ int conv_bwd(int nt_edge, const float* img, const float* imgT, const float* h, c
 int edge_embed_bwd(int nt_edge, const float* img, const float* imgT, const float* e_s, const float* e_v,
                    const int64_t* etypes, const int32_t* eperm, int64_t E, const float* const* g_e, int n_g,
                    float* g_e_s, float* g_e_v, float* slab, int* grid, int bf16, hipStream_t st);
+// edge_embed_bwd + node_embed_bwd in one launch (no raw edge-feature gradients); both slabs get `*grid` rows
+int embed_tail_bwd(int nt_node, int nt_edge, const float* img_edge, const float* imgT_edge, const float* e_s,
+                   const float* e_v, const int64_t* etypes, const int32_t* eperm, int64_t E, const float* const* g_e,
+                   int n_g, float* edge_slab, const float* img_node, const float* imgT_node, const float* x_s,
+                   const float* x_v, const int64_t* ntypes, int64_t N, const float* g_up0, const float* g_up1,
+                   const float* g_up2, float* g_x_s, float* g_x_v, float* node_slab, int* grid, int bf16, hipStream_t st);
+// the same behind the checks of cgvp_edge_embed_bwd / cgvp_node_embed_bwd, for the whole-pass backward (gvp_kernels.hip)
+int lba_embed_tail_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image, const float* x_s,
+                       const float* x_v, const int64_t* ntypes, int64_t N, const float* g_up0, const float* g_up1,
+                       const float* g_up2, float* g_x_s, float* g_x_v, const float* e_s, const float* e_v,
+                       const int64_t* etypes, const int32_t* eperm, int64_t E, const float* const* g_e, int32_t num_g,
+                       float* node_ws, float* edge_ws, cgvp_segment* segs, int32_t* nsegs, hipStream_t st);
 constexpr int kEdgeRow = 36;              // floats per edge of the stored edge embedding: [e_s 32 | e_v 3 | pad]
 int node_embed_bwd(int nt_node, const float* img, const float* imgT, const float* x_s, const float* x_v,
                    const int64_t* ntypes, int64_t N, const float* g_up0, const float* g_up1, const float* g_up2,

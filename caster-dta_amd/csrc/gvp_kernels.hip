@@ -11,6 +11,7 @@
 //   * node kernels: row-per-lane, outputs transposed through LDS so global
 //     stores are contiguous.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "gvp_internal.h"
@@ -61,8 +62,10 @@ inline int launch_status() {
 // ------------------------------------------------------------------ CSR build
 // Stable counting sort of the edges by target in four launches:
 //   count  : cnt[dst] += 1                                     (int atomics, one thread per edge)
-//   scan   : exclusive scan of cnt -> rowptr; cnt becomes the per-target cursor   (ONE block, LDS tiles with a carry)
-//   fill   : pos = cursor[dst]++ -> tmp[pos] = edge id, edst[pos] = dst          (arrival order inside a segment)
+//   scan   : exclusive scan of cnt -> rowptr; cnt is left as it is     (N <= 64k: independent 1024-entry workgroups, each
+//            sums the counts before its chunk itself; longer tables: ONE block, LDS tiles with a carry)
+//   fill   : pos = rowptr[dst] + --cnt[dst] -> tmp[pos] = edge id, edst[pos] = dst   (reverse arrival order inside a
+//            segment; the counters count back down to the all-zero state the next call expects)
 //   rank   : every position ranks its edge id inside its segment (deg reads, all independent) and writes
 //            eperm / esrc at the ranked position: segments end up ordered by edge id = the reference's index_add
 //            order, run-to-run reproducible; the same launch zeroes the counters again for the next call.
@@ -95,11 +98,11 @@ __global__ void csr_count_kernel(const int64_t* __restrict__ ei, int64_t N, int6
   atomicAdd(&cnt[d], 1);
 }
 
-// Exclusive scan of cnt[0..N) by ONE 1024-thread block; rowptr[N] = total; cnt is rewritten with the scan so the
-// fill kernel can use it as a cursor.  The table goes through LDS in tiles of SCAN_LDS entries (coalesced global
-// traffic both ways) with a running carry, so long tables cost tiles x the short-table time, not a strided crawl.
+// Exclusive scan of cnt[0..N) by ONE 1024-thread block; rowptr[N] = total.  The table goes through LDS in tiles of
+// SCAN_LDS entries (coalesced global traffic both ways) with a running carry, so long tables cost tiles x the
+// short-table time, not a strided crawl.  Tables of at most SCAN_MULTI_MAX entries take csr_scan_multi_kernel below.
 constexpr int SCAN_LDS = 36 * 1024;   // 144 KB of the 160 KB LDS
-__global__ __launch_bounds__(1024) void csr_scan_kernel(int32_t* __restrict__ cnt, int64_t N,
+__global__ __launch_bounds__(1024) void csr_scan_kernel(const int32_t* __restrict__ cnt, int64_t N,
                                                         int32_t* __restrict__ rowptr) {
   extern __shared__ int32_t sbuf[];             // [tile][1024 partials + 32]
   const int t = threadIdx.x;
@@ -159,11 +162,10 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int32_t* __restrict__ cn
       for (int q = t; q < n4; q += 1024) {
         const int4 x = reinterpret_cast<const int4*>(sbuf)[q];
         reinterpret_cast<int4*>(rowptr + base)[q] = x;
-        reinterpret_cast<int4*>(cnt + base)[q] = x;
       }
-      if (t < (n & 3)) { const int32_t x = sbuf[(n4 << 2) + t]; rowptr[base + (n4 << 2) + t] = x; cnt[base + (n4 << 2) + t] = x; }
+      if (t < (n & 3)) rowptr[base + (n4 << 2) + t] = sbuf[(n4 << 2) + t];
     } else {
-      for (int i = t; i < n; i += 1024) { const int32_t x = sbuf[i]; rowptr[base + i] = x; cnt[base + i] = x; }
+      for (int i = t; i < n; i += 1024) rowptr[base + i] = sbuf[i];
     }
     carry += total;
     __syncthreads();
@@ -172,52 +174,58 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int32_t* __restrict__ cn
   if (t == 0) rowptr[N] = carry;
 }
 
-// The same scan for SHORT tables (N <= SCAN_SMALL: the drug graphs of a batch, ~2.6k atoms) as ONE 256-thread workgroup
-// with 32 KB of static LDS.  Why a second kernel: the drug encoder runs on a side stream beside the protein encoder, whose
-// forward kernels leave every CU holding one or two 4-wave workgroups of ~244 VGPRs; the 1024-thread / 77-VGPR scan above
-// needs 4 waves per SIMD and found no CU to start on until the protein forward had drained (59 us gap in the round-4 step
-// trace, the drug chain then ended 47 us after the protein chain).  One wave per SIMD fits beside them.
-constexpr int SCAN_SMALL = 8192, SCAN_SMALL_T = 256;
-__global__ __launch_bounds__(SCAN_SMALL_T) void csr_scan_small_kernel(int32_t* __restrict__ cnt, int32_t N,
-                                                                      int32_t* __restrict__ rowptr) {
-  __shared__ int32_t sbuf[SCAN_SMALL];
-  __shared__ int32_t part[8];
-  const int t = threadIdx.x;
-  for (int i = t; i < N; i += SCAN_SMALL_T) sbuf[i] = cnt[i];
-  __syncthreads();
-  const int chunk = (N + SCAN_SMALL_T - 1) / SCAN_SMALL_T;
-  const int lo = t * chunk < N ? t * chunk : N, hi = lo + chunk < N ? lo + chunk : N;
-  int32_t sum = 0;
-  for (int i = lo; i < hi; ++i) sum += sbuf[i];
+// The scan for tables of at most SCAN_MULTI_MAX entries (every batch of the benchmark configs but the long-graph one):
+// workgroup b owns entries [1024 b, 1024 b + 1024) and gets the sum of everything before them by reading those counts
+// itself (<= 64 int4 per thread, all L2 hits) -- no carry chain between workgroups, no second launch, ~1/1024 of the
+// quadratic cost.  256-thread workgroups on purpose: the drug encoder's build runs on a side stream beside the protein
+// encoder's CU-filling kernels, and a 1024-thread / 4-waves-per-SIMD block found no CU to start on until those had
+// drained (59 us gap in the first round-4 step trace); one wave per SIMD fits beside them.
+// `cnt` holds `counters` (a multiple of 64, > N) zero-initialised words: entries N.. are zero, so rowptr[N] = total
+// falls out of the same exclusive scan.
+constexpr int SCAN_MULTI_MAX = 65536, SCAN_MULTI_T = 256, SCAN_MULTI_CHUNK = 4 * SCAN_MULTI_T;
+__global__ __launch_bounds__(SCAN_MULTI_T) void csr_scan_multi_kernel(const int32_t* __restrict__ cnt, int32_t N,
+                                                                      int32_t counters, int32_t* __restrict__ rowptr) {
+  __shared__ int32_t part[2 * (SCAN_MULTI_T / WAVE)];
+  const int t = threadIdx.x, wv = t >> 6;
+  const int4* c4 = reinterpret_cast<const int4*>(cnt);             // `work` is 16-B aligned (csr_build checks)
+  int32_t pre = 0;
+  for (int q = t; q < (int)blockIdx.x * SCAN_MULTI_T; q += SCAN_MULTI_T) {
+    const int4 v = c4[q];
+    pre += (v.x + v.y) + (v.z + v.w);
+  }
+  const int i0 = (int)blockIdx.x * SCAN_MULTI_CHUNK + 4 * t;
+  const int4 v = i0 < counters ? c4[i0 >> 2] : make_int4(0, 0, 0, 0);
+  const int32_t sum = (v.x + v.y) + (v.z + v.w);
   int32_t inc = sum;
 #pragma unroll
   for (int off = 1; off < WAVE; off <<= 1) {
     const int32_t u = __shfl_up(inc, off);
     if ((t & (WAVE - 1)) >= off) inc += u;
+    pre += __shfl_xor(pre, off);
   }
-  if ((t & (WAVE - 1)) == WAVE - 1) part[t >> 6] = inc;
+  if ((t & (WAVE - 1)) == WAVE - 1) { part[wv] = inc; part[SCAN_MULTI_T / WAVE + wv] = pre; }
   __syncthreads();
-  int32_t wave_base = 0, total = 0;
+  int32_t run = inc - sum;                         // exclusive prefix of this thread's four entries
 #pragma unroll
-  for (int w = 0; w < SCAN_SMALL_T / WAVE; ++w) {
-    const int32_t v = part[w];
-    if (w < (t >> 6)) wave_base += v;
-    total += v;
+  for (int w = 0; w < SCAN_MULTI_T / WAVE; ++w) {
+    run += part[SCAN_MULTI_T / WAVE + w];
+    if (w < wv) run += part[w];
   }
-  int32_t run = wave_base + inc - sum;             // exclusive prefix of this thread's chunk
-  for (int i = lo; i < hi; ++i) { const int32_t c = sbuf[i]; sbuf[i] = run; run += c; }
-  __syncthreads();
-  for (int i = t; i < N; i += SCAN_SMALL_T) { const int32_t x = sbuf[i]; rowptr[i] = x; cnt[i] = x; }
-  if (t == 0) rowptr[N] = total;
+  const int32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (i0 + k <= N) rowptr[i0 + k] = run;
+    run += x[k];
+  }
 }
 
-__global__ void csr_fill_kernel(const int64_t* __restrict__ ei, int64_t N, int64_t E,
-                                int32_t* __restrict__ cursor, int32_t* __restrict__ tmp, int32_t* __restrict__ edst) {
+__global__ void csr_fill_kernel(const int64_t* __restrict__ ei, int64_t N, int64_t E, const int32_t* __restrict__ rowptr,
+                                int32_t* __restrict__ cnt, int32_t* __restrict__ tmp, int32_t* __restrict__ edst) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   int64_t s = ei[e], d = ei[E + e];
   if (s < 0 || s >= N || d < 0 || d >= N) return;
-  int32_t pos = atomicAdd(&cursor[d], 1);
+  int32_t pos = rowptr[d] + atomicSub(&cnt[d], 1) - 1;
   // pos < E always holds when the counters were zero on entry (the contract).  The guard makes a violated contract a wrong
   // table instead of a wild write: round 2's recorded GPU fault ("write access to a read-only page" on replay of a captured
   // step) was exactly this store -- the counters were then zero-filled by a captured hipMemsetAsync, which zeroes only
@@ -694,13 +702,14 @@ int csr_build(const int64_t* edge_index, int64_t N, int64_t E, int32_t* rowptr, 
     hipLaunchKernelGGL(csr_count_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, work, rng_state, rng_out);
   else if (rng_state)
     hipLaunchKernelGGL(rng_next_kernel, dim3(1), dim3(1), 0, s, rng_state, rng_out);
-  if (N <= SCAN_SMALL) {
-    hipLaunchKernelGGL(csr_scan_small_kernel, dim3(1), dim3(SCAN_SMALL_T), 0, s, work, (int32_t)N, rowptr);
+  if (N < SCAN_MULTI_MAX) {
+    hipLaunchKernelGGL(csr_scan_multi_kernel, dim3((unsigned)((N + 1 + SCAN_MULTI_CHUNK - 1) / SCAN_MULTI_CHUNK)),
+                       dim3(SCAN_MULTI_T), 0, s, work, (int32_t)N, (int32_t)counters, rowptr);
   } else {
     const int64_t tile = N < SCAN_LDS ? (N + 3) / 4 * 4 : SCAN_LDS;
     hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), (size_t)(tile + 1024 + 32) * sizeof(int32_t), s, work, N, rowptr);
   }
-  if (E > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, work, tmp, edst);
+  if (E > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((E + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, rowptr, work, tmp, edst);
   const int64_t span = E > counters ? E : counters;
   hipLaunchKernelGGL(csr_rank_kernel, dim3((unsigned)((span + B - 1) / B)), dim3(B), 0, s, edge_index, N, E, counters, rowptr, tmp,
                      edst, eperm, esrc, work);
@@ -769,6 +778,7 @@ int cgvp_lba_pass_begin(const cgvp_dims* dims, const cgvp_layout* layout, const 
                                 edge_index, E, csr_counters, (hipStream_t)stream)) return rc;
   return launch_status();
 }
+
 
 int cgvp_node_embed_fwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* params,
                         const float* image, const float* x_s, const float* x_v, const int64_t* ntypes,
@@ -947,14 +957,24 @@ int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const
   if (int rc = quad::bwd_block_sizes(layout->nt_node, layout->nt_edge, &emb, &ce, &ct, &nd, &hd)) return rc;
   hipStream_t st = (hipStream_t)stream;
   float* head_slab = workspace + (size_t)kBwdMaxGrid * nd;
+  // CGVP_SPLIT_HEAD_BWD=1 keeps the head stage in a launch of its own (A/B switch; the results are the same)
+  static const bool split_head = [] { const char* e = getenv("CGVP_SPLIT_HEAD_BWD"); return e && e[0] == '1'; }();
+  if (with_head && !split_head) {
+    // the head's d h_out lands in g_dh and is consumed in place as the node stage's upstream, inside ONE launch
+    if (int rc = quad::node_head_bwd(image + o.head, image + o.headT, h_out, g_out, g_dh, head_slab,
+                                     image + o.node0 + layer * o.layer_stride, image + o.nodeT0 + layer * o.layerT_stride,
+                                     h, dh, mask0, mask1, rng_args(rng, 2 * layer), N, g_dh, g_h, zero_out, workspace, &grid,
+                                     policy_of(dims), st)) return rc;
+    hgrid = grid;
+  } else {
   if (with_head) {
-    // the head's d h_out lands in g_dh and is consumed in place as the node stage's upstream
     if (int rc = quad::head_bwd(image + o.head, image + o.headT, h_out, g_out, N, g_dh, head_slab, &hgrid, policy_of(dims), st)) return rc;
     g_up0 = g_dh; g_up1 = nullptr; g_up2 = nullptr;
   }
   if (int rc = quad::node_update_bwd(image + o.node0 + layer * o.layer_stride, image + o.nodeT0 + layer * o.layerT_stride,
                                      h, dh, mask0, mask1, rng_args(rng, 2 * layer), g_up0, g_up1, g_up2, N, g_dh, g_h, zero_out,
                                      workspace, &grid, policy_of(dims), st)) return rc;
+  }
   const int node_len = conv_ff1() + LFf1::size(0) - conv_ln0();          // norm.0 .. end of ff_func.1
   cgvp_segment sg[2] = {{workspace, grid, nd, 0, node_len, layout->conv0 + layer * layout->conv_stride + conv_ln0()},
                         {head_slab, hgrid, hd, 0, layout->total - layout->ln_out, layout->ln_out}};
@@ -1048,6 +1068,39 @@ int cgvp_node_embed_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
   else quad::reduce_segments(sg, 1, grad_params, st);
   return launch_status();
 }
+
+}  // extern "C"
+
+namespace quad {
+// cgvp_edge_embed_bwd (without raw-feature gradients) + cgvp_node_embed_bwd as ONE launch for the whole-pass backward;
+// two segments (edge stage first), same argument rules as the two entry points
+int lba_embed_tail_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image, const float* x_s,
+                       const float* x_v, const int64_t* ntypes, int64_t N, const float* g_up0, const float* g_up1,
+                       const float* g_up2, float* g_x_s, float* g_x_v, const float* e_s, const float* e_v,
+                       const int64_t* etypes, const int32_t* eperm, int64_t E, const float* const* g_e, int32_t num_g,
+                       float* node_ws, float* edge_ws, cgvp_segment* segs, int32_t* nsegs, hipStream_t st) {
+  if (int rc = check_dims_gated(dims)) return rc;
+  if (N <= 0 || E <= 0 || !layout || !image || !node_ws || !edge_ws || !g_e || num_g < 1 || !segs || !nsegs) return CGVP_ERR_BAD_ARG;
+  if (!x_s || !x_v || (layout->nt_node > 0 && !ntypes) || ((g_x_s == nullptr) != (g_x_v == nullptr))) return CGVP_ERR_BAD_ARG;
+  if (!e_s || !e_v || !eperm || (layout->nt_edge > 0 && !etypes)) return CGVP_ERR_BAD_ARG;
+  const void* al[] = {g_up0, g_up1, g_up2, e_s};
+  for (const void* q : al) if ((uintptr_t)q & 15) return CGVP_ERR_BAD_ARG;
+  for (int l = 0; l < num_g; ++l) if (!g_e[l] || ((uintptr_t)g_e[l] & 15)) return CGVP_ERR_BAD_ARG;
+  QuadOffsets o;
+  if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
+  int emb, ce, ct, nd, hd, grid = 0;
+  if (int rc = quad::bwd_block_sizes(layout->nt_node, layout->nt_edge, &emb, &ce, &ct, &nd, &hd)) return rc;
+  if (int rc = quad::embed_tail_bwd(layout->nt_node, layout->nt_edge, image + o.conv0, image + o.convT0, e_s, e_v, etypes,
+                                    eperm, E, g_e, num_g, edge_ws, image + o.emb, image + o.embT, x_s, x_v, ntypes, N,
+                                    g_up0, g_up1, g_up2, g_x_s, g_x_v, node_ws, &grid, policy_of(dims), st)) return rc;
+  segs[0] = cgvp_segment{edge_ws, grid, ce, 0, layout->conv0 - layout->edge_gvp, layout->edge_gvp};
+  segs[1] = cgvp_segment{node_ws, grid, emb, 0, layout->edge_gvp - layout->node_gvp, layout->node_gvp};
+  *nsegs = 2;
+  return launch_status();
+}
+}  // namespace quad
+
+extern "C" {
 
 int cgvp_gine_conv_fwd(const float* x, const int64_t* ntypes, int32_t num_ntypes, const float* eattr,
                        const int64_t* etypes, int32_t num_etypes, int32_t edge_dim,

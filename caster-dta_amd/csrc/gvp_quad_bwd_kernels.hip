@@ -89,9 +89,9 @@ __device__ __forceinline__ void zero_block(float* gblk, int lane) {
 }
 // slab row of this workgroup = sum of its waves' private blocks (stride PW floats apart)
 template <int BLK, int PW, int WPB_ = 8>
-__device__ __forceinline__ void write_slab_row(float* slab, const float* blocks) {
+__device__ __forceinline__ void write_slab_row(float* slab, const float* blocks, int row = blockIdx.x) {
   __syncthreads();
-  float* out = slab + (size_t)blockIdx.x * BLK;
+  float* out = slab + (size_t)row * BLK;
   for (int k = threadIdx.x; k < BLK; k += WAVE * WPB_) {
     float t = 0.f;
 #pragma unroll
@@ -172,10 +172,8 @@ static_assert(node_bwd_lds_floats() * 4 <= 160 * 1024, "node backward LDS plan e
 // g_up0 may alias g_dh (the head backward leaves d h_out there): a tile's rows are read
 // by the same lanes that overwrite them at the end of the tile.
 template <typename ST>
-__global__ __launch_bounds__(BW_TPB, 2) void node_bwd_kernel(NodeBArgs a) {
-  WALL_STAMP(0);
+__device__ __forceinline__ void node_bwd_body(const NodeBArgs& a, float* lds) {
   typedef Image<0, 0> IM;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
   float* f_node = lds + BW_TPB;                                     // lds[0..BW_TPB): AccPriv::trash()
   float* t_node = f_node + IM::ND_SIZE;
   float* blocks = t_node + IM::TN_SIZE;
@@ -309,6 +307,12 @@ __global__ __launch_bounds__(BW_TPB, 2) void node_bwd_kernel(NodeBArgs a) {
   write_slab_row<NODE_GB, NODE_GB>(a.slab, blocks);
   STAMP(10);
 }
+template <typename ST>
+__global__ __launch_bounds__(BW_TPB, 2) void node_bwd_kernel(NodeBArgs a) {
+  WALL_STAMP(0);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  node_bwd_body<ST>(a, lds);
+}
 
 // ===================================================================== output head
 // gvp_norm_before_scalar + gvp_to_scalar (protein_gnn.py:385-386) on h_out, the saved output of
@@ -320,10 +324,8 @@ struct HeadBArgs {
 constexpr int head_bwd_lds_floats() { return BW_TPB + Image<0, 0>::HD_SIZE + Image<0, 0>::TH_SIZE + BW_WPB * (HEAD_GB + TSCR_FLOATS); }
 
 template <typename ST>
-__global__ __launch_bounds__(BW_TPB, 2) void head_bwd_kernel(HeadBArgs a) {
-  WALL_STAMP(1);
+__device__ __forceinline__ void head_bwd_body(const HeadBArgs& a, float* lds) {
   typedef Image<0, 0> IM;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
   float* f_head = lds + BW_TPB;
   float* t_head = f_head + IM::HD_SIZE;
   float* blocks = t_head + IM::TH_SIZE;
@@ -383,6 +385,26 @@ __global__ __launch_bounds__(BW_TPB, 2) void head_bwd_kernel(HeadBArgs a) {
     }
   }
   write_slab_row<HEAD_GB, HEAD_GB>(a.slab, blocks);
+}
+template <typename ST>
+__global__ __launch_bounds__(BW_TPB, 2) void head_bwd_kernel(HeadBArgs a) {
+  WALL_STAMP(1);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  head_bwd_body<ST>(a, lds);
+}
+
+// The last layer's node stage with the output head in front of it, ONE launch: both stages give tile t to the same
+// wave (w * grid + block), and lane (i, g) of the node stage reads exactly the words of d h_out that the same lane
+// of the head stage wrote (g_h_out = the node stage's g_up0), so the hand-over needs no grid-wide ordering -- only a
+// workgroup barrier before the node stage reuses the head stage's LDS.  Saves a launch, its ramp and its drain on
+// the backward's critical path (round 4: head_bwd alone was 10.4 us at davis_b64 for ~3 us of tile work).
+template <typename ST>
+__global__ __launch_bounds__(BW_TPB, 2) void node_head_bwd_kernel(HeadBArgs hd, NodeBArgs a) {
+  WALL_STAMP(0);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  head_bwd_body<ST>(hd, lds);
+  __syncthreads();
+  node_bwd_body<ST>(a, lds);
 }
 
 // ===================================================================== conv
@@ -1037,13 +1059,11 @@ struct EdgeBArgs {
 template <int NTE>
 constexpr int edge_bwd_lds_floats() { return BW_TPB + Image<0, NTE>::CV_M0 + Image<0, NTE>::TC_M0 + BW_WPB * (EdgeBlk<NTE>::SIZE + TSCR_FLOATS); }
 
-template <int NTE, typename ST, bool DX = false>
-__global__ __launch_bounds__(BW_TPB, 2) void edge_bwd_kernel(EdgeBArgs a) {
-  WALL_STAMP(3);
+template <int NTE, typename ST, bool DX>
+__device__ __forceinline__ void edge_bwd_body(const EdgeBArgs& a, float* lds, int bid, int nblk) {
   typedef Image<0, NTE> IM;
   typedef EdgeBlk<NTE> B;
   constexpr int PW = B::SIZE + TSCR_FLOATS;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
   float* img = lds + BW_TPB;                      // [QEdge | edge LN]  (= the first CV_M0 floats of the conv slice)
   float* imgT = img + IM::CV_M0;                  // QEdge transposed  (= the first TC_M0 floats of the convT slice)
   const int lane0 = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1057,7 +1077,7 @@ __global__ __launch_bounds__(BW_TPB, 2) void edge_bwd_kernel(EdgeBArgs a) {
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
   const bool first = false;
   const int64_t tiles = (a.E + TILE - 1) / TILE;
-  for (int64_t t = (int64_t)w * gridDim.x + blockIdx.x; t < tiles; t += (int64_t)gridDim.x * BW_WPB) {
+  for (int64_t t = (int64_t)w * nblk + bid; t < tiles; t += (int64_t)nblk * BW_WPB) {
     const int lane = opaque_lane(lane0), i = lane & 15, g = lane >> 4;
     const int64_t p = t * TILE + i;
     // positions behind the last VALID edge hold eperm = -1 (edges with out-of-range endpoints are dropped by the CSR
@@ -1117,7 +1137,13 @@ __global__ __launch_bounds__(BW_TPB, 2) void edge_bwd_kernel(EdgeBArgs a) {
     }
     QEdge<NTE>::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::GVP, first, lane, et[0], active, bse[0], bve[0], ce[0], gr, tscr);
   }
-  write_slab_row<B::SIZE, PW>(a.slab, blocks);
+  write_slab_row<B::SIZE, PW>(a.slab, blocks, bid);
+}
+template <int NTE, typename ST, bool DX = false>
+__global__ __launch_bounds__(BW_TPB, 2) void edge_bwd_kernel(EdgeBArgs a) {
+  WALL_STAMP(3);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  edge_bwd_body<NTE, ST, DX>(a, lds, blockIdx.x, gridDim.x);
 }
 
 // ===================================================================== node embed
@@ -1135,12 +1161,10 @@ template <int NTN>
 constexpr int embed_bwd_lds_floats() { return BW_TPB + Image<NTN, 0>::EMB_SIZE + Image<NTN, 0>::TE_SIZE + BW_WPB * (EmbBlk<NTN>::SIZE + TSCR_FLOATS); }
 
 template <int NTN, typename ST>
-__global__ __launch_bounds__(BW_TPB, 2) void embed_bwd_kernel(EmbBArgs a) {
-  WALL_STAMP(4);
+__device__ __forceinline__ void embed_bwd_body(const EmbBArgs& a, float* lds, int bid, int nblk) {
   typedef Image<NTN, 0> IM;
   typedef QNode<NTN> Q;
   typedef EmbBlk<NTN> B;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
   float* img = lds + BW_TPB;
   float* imgT = img + IM::EMB_SIZE;
   float* blocks = imgT + IM::TE_SIZE;
@@ -1155,7 +1179,7 @@ __global__ __launch_bounds__(BW_TPB, 2) void embed_bwd_kernel(EmbBArgs a) {
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
   const int64_t ntiles = (a.N + TILE - 1) / TILE;
   const bool first = false;
-  for (int64_t tile = (int64_t)w * gridDim.x + blockIdx.x; tile < ntiles; tile += (int64_t)gridDim.x * BW_WPB) {
+  for (int64_t tile = (int64_t)w * nblk + bid; tile < ntiles; tile += (int64_t)nblk * BW_WPB) {
     const int64_t n = tile * TILE + i;
     const bool active = n < a.N;
     float bs[1][Q::SSTEPS], bv[1][3][1];
@@ -1207,7 +1231,27 @@ __global__ __launch_bounds__(BW_TPB, 2) void embed_bwd_kernel(EmbBArgs a) {
       }
     }
   }
-  write_slab_row<B::SIZE, B::SIZE>(a.slab, blocks);
+  write_slab_row<B::SIZE, B::SIZE>(a.slab, blocks, bid);
+}
+template <int NTN, typename ST>
+__global__ __launch_bounds__(BW_TPB, 2) void embed_bwd_kernel(EmbBArgs a) {
+  WALL_STAMP(4);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  embed_bwd_body<NTN, ST>(a, lds, blockIdx.x, gridDim.x);
+}
+
+// The two embedding stages as ONE launch at the end of the backward chain: every workgroup runs its edge tiles, writes
+// its edge slab row, then (same LDS) its share of the node tiles and its node slab row.  The stages are independent
+// of each other; as launches of their own each paid the launch ramp / image staging / drain for ~one tile of work
+// per wave (round 4, davis_b64: 8.8 + 19.7 us).  Four waves per SIMD (two workgroups per CU, as the edge kernel
+// alone): the node stage alone would take ~160 VGPRs and spills a few here.
+template <int NTN, int NTE, typename ST>
+__global__ __launch_bounds__(BW_TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void tail_bwd_kernel(EdgeBArgs e, EmbBArgs m) {
+  WALL_STAMP(3);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  edge_bwd_body<NTE, ST, false>(e, lds, blockIdx.x, gridDim.x);
+  __syncthreads();
+  embed_bwd_body<NTN, ST>(m, lds, blockIdx.x, gridDim.x);
 }
 
 // dst[j] += sum_r slab[r][col0 + j], j < len.  A block owns 64 columns; its 16
@@ -1289,8 +1333,24 @@ __global__ __launch_bounds__(256) void reduce_segments_rows_kernel(SegTable t, f
   else atomicAdd(grad + sg.dst + j, s);
 }
 
+// Workgroup cap of the backward kernels.  BW_MAX_GRID (240: slab rows are sized for it) when the launch is
+// throughput-bound; 8 fewer when `units` (tiles, or pairs of tiles for the conv backward) fit the smaller grid's waves
+// anyway -- the launch is then bound by ONE wave's latency, the spare CUs cost nothing and the drug encoder's kernels on
+// the side stream find room (davis_b64: 0.2353 -> 0.2320 ms per step, long_graph_x64 unchanged).
+// CGVP_BWD_GRID=<n> in the environment (read once) overrides both: an A/B knob.
+inline int bwd_grid_cap(int64_t units) {
+  static const int forced = [] {
+    const char* e = getenv("CGVP_BWD_GRID");
+    const int v = e ? atoi(e) : 0;
+    return (v >= 1 && v <= BW_MAX_GRID) ? v : 0;
+  }();
+  if (forced) return forced;
+  constexpr int SMALL = BW_MAX_GRID - 8;
+  return units <= (int64_t)SMALL * BW_WPB ? SMALL : BW_MAX_GRID;
+}
 inline int grid_for(int64_t tiles) {          // workgroups = slab rows; tiles go round-robin over them
-  return (int)(tiles < 1 ? 1 : (tiles > BW_MAX_GRID ? BW_MAX_GRID : tiles));
+  const int cap = bwd_grid_cap(tiles);
+  return (int)(tiles < 1 ? 1 : (tiles > cap ? cap : tiles));
 }
 
 }  // namespace
@@ -1337,28 +1397,28 @@ int reduce_slab(const float* slab, int rows, int stride, int col0, int len, floa
 }
 
 // one launch of a backward kernel in the requested activation storage type
-#define BWD_LAUNCH(KERNEL, G, TPB_, LDS_, ARGS)                                                                               \
+#define BWD_LAUNCH(KERNEL, G, TPB_, LDS_, ...)                                                                              \
   do {                                                                                                                        \
     if (bf16) {                                                                                                               \
       CGVP_SET_DYN_LDS_ONCE(KERNEL(bf16s), LDS_);                                                                             \
-      hipLaunchKernelGGL((KERNEL(bf16s)), dim3(G), dim3(TPB_), (LDS_), st, ARGS);                                             \
+      hipLaunchKernelGGL((KERNEL(bf16s)), dim3(G), dim3(TPB_), (LDS_), st, __VA_ARGS__);                                            \
     } else {                                                                                                                  \
       CGVP_SET_DYN_LDS_ONCE(KERNEL(float), LDS_);                                                                             \
-      hipLaunchKernelGGL((KERNEL(float)), dim3(G), dim3(TPB_), (LDS_), st, ARGS);                                             \
+      hipLaunchKernelGGL((KERNEL(float)), dim3(G), dim3(TPB_), (LDS_), st, __VA_ARGS__);                                            \
     }                                                                                                                         \
   } while (0)
 
 // the same for the two kernels that exist for every layer kind (`bf16` = tile policy index, gvp_internal.h)
-#define BWD_LAUNCH_KIND(KERNEL, G, TPB_, LDS_, ARGS)                                                                          \
+#define BWD_LAUNCH_KIND(KERNEL, G, TPB_, LDS_, ...)                                                                         \
   do {                                                                                                                        \
     if (bf16 == POLICY_GVPDEF) {                                                                                              \
       CGVP_SET_DYN_LDS_ONCE(KERNEL(f32_gvpdef), LDS_);                                                                        \
-      hipLaunchKernelGGL((KERNEL(f32_gvpdef)), dim3(G), dim3(TPB_), (LDS_), st, ARGS);                                        \
+      hipLaunchKernelGGL((KERNEL(f32_gvpdef)), dim3(G), dim3(TPB_), (LDS_), st, __VA_ARGS__);                                       \
     } else if (bf16 == POLICY_LINEAR) {                                                                                       \
       CGVP_SET_DYN_LDS_ONCE(KERNEL(f32_linear), LDS_);                                                                        \
-      hipLaunchKernelGGL((KERNEL(f32_linear)), dim3(G), dim3(TPB_), (LDS_), st, ARGS);                                        \
+      hipLaunchKernelGGL((KERNEL(f32_linear)), dim3(G), dim3(TPB_), (LDS_), st, __VA_ARGS__);                                       \
     } else {                                                                                                                  \
-      BWD_LAUNCH(KERNEL, G, TPB_, LDS_, ARGS);                                                                                \
+      BWD_LAUNCH(KERNEL, G, TPB_, LDS_, __VA_ARGS__);                                                                         \
     }                                                                                                                         \
   } while (0)
 
@@ -1372,6 +1432,23 @@ int node_update_bwd(const float* img_node, const float* imgT_node, const float* 
   const size_t lds = (size_t)node_bwd_lds_floats() * sizeof(float);
 #define K_(ST) node_bwd_kernel<ST>
   BWD_LAUNCH_KIND(K_, G, BW_TPB, lds, a);
+#undef K_
+  return 0;
+}
+
+// head + node stage of the last layer in one launch (see node_head_bwd_kernel); g_h_out must be the node stage's g_up0
+int node_head_bwd(const float* img_head, const float* imgT_head, const float* h_out, const float* g_out, float* g_h_out,
+                  float* head_slab, const float* img_node, const float* imgT_node, const float* h, const float* dh,
+                  const float* mask0, const float* mask1, gvp::RngArgs rng, int64_t N, float* g_dh, float* g_h,
+                  float* zero_rows, float* slab, int* grid, int bf16, hipStream_t st) {
+  HeadBArgs hd{img_head, imgT_head, h_out, g_out, N, g_h_out, head_slab};
+  NodeBArgs a{img_node, imgT_node, h, dh, mask0, mask1, rng, g_h_out, nullptr, nullptr, N, g_dh, g_h, zero_rows, slab};
+  const int G = grid_for((N + TILE - 1) / TILE);
+  *grid = G;
+  const int f = node_bwd_lds_floats() > head_bwd_lds_floats() ? node_bwd_lds_floats() : head_bwd_lds_floats();
+  const size_t lds = (size_t)f * sizeof(float);
+#define K_(ST) node_head_bwd_kernel<ST>
+  BWD_LAUNCH(K_, G, BW_TPB, lds, hd, a);
 #undef K_
   return 0;
 }
@@ -1406,7 +1483,8 @@ int conv_bwd2_impl(ConvBArgs& a, int64_t E, int* grid, int bf16, hipStream_t st)
   typedef C2Shape<TN, WPB_> SH;
   const int64_t iters = (E + TN * TILE - 1) / (TN * TILE);
   const int64_t wgs = (iters + WPB_ - 1) / WPB_;
-  const int G = (int)(wgs < 1 ? 1 : (wgs > CB_MAX_GRID ? CB_MAX_GRID : wgs));
+  const int cap = bwd_grid_cap(((E + TILE - 1) / TILE + 1) / 2);       // two tiles per wave are this kernel's normal load
+  const int G = (int)(wgs < 1 ? 1 : (wgs > cap ? cap : wgs));
   *grid = G;
   const size_t lds = (size_t)SH::template lds_floats<NTE>() * sizeof(float);
 #define K_(ST) conv_bwd2_kernel<NTE, ST, TN, WPB_>
@@ -1424,7 +1502,8 @@ template <int NTE>
 int conv_bwd_impl(ConvBArgs& a, int* grid, int bf16, hipStream_t st) {
   const int64_t ngroups = (a.N + a.npw - 1) / a.npw;
   const int64_t wgs = (ngroups + CB_WPB - 1) / CB_WPB;
-  const int G = (int)(wgs < 1 ? 1 : (wgs > CB_MAX_GRID ? CB_MAX_GRID : wgs));
+  const int cap = bwd_grid_cap(ngroups);
+  const int G = (int)(wgs < 1 ? 1 : (wgs > cap ? cap : wgs));
   *grid = G;
   const size_t lds = (size_t)conv_bwd_lds_floats<NTE>() * sizeof(float);
 #define K_(ST) conv_bwd_kernel<NTE, ST>
@@ -1466,7 +1545,7 @@ template <int NTE>
 int edge_bwd_impl(EdgeBArgs& a, int* grid, int bf16, hipStream_t st) {
   // 66 KB of LDS and ~115 VGPRs per workgroup: TWO workgroups share a CU (4 waves per SIMD), so up to 2 x 240 slab rows
   const int64_t tiles = (a.E + TILE - 1) / TILE;
-  const int G = (int)(tiles < 1 ? 1 : (tiles > 2 * BW_MAX_GRID ? 2 * BW_MAX_GRID : tiles));
+  const int G = (int)(tiles < 1 ? 1 : (tiles > 2 * bwd_grid_cap((tiles + 1) / 2) ? 2 * bwd_grid_cap((tiles + 1) / 2) : tiles));
   *grid = G;
   const size_t lds = (size_t)edge_bwd_lds_floats<NTE>() * sizeof(float);
   if (a.g_e_s) {
@@ -1511,6 +1590,37 @@ int node_embed_bwd(int nt_node, const float* img, const float* imgT, const float
   if (nt_node == 0) return embed_bwd_impl<0>(a, grid, bf16, st);
   if (nt_node == 20) return embed_bwd_impl<20>(a, grid, bf16, st);
   if (nt_node == 21) return embed_bwd_impl<21>(a, grid, bf16, st);
+  return CGVP_ERR_UNSUPPORTED_DIMS;
+}
+
+
+template <int NTN, int NTE>
+int tail_bwd_impl(EdgeBArgs& e, EmbBArgs& m, int* grid, int bf16, hipStream_t st) {
+  const int64_t tiles = (e.E + TILE - 1) / TILE;
+  const int G = (int)(tiles < 1 ? 1 : (tiles > 2 * bwd_grid_cap((tiles + 1) / 2) ? 2 * bwd_grid_cap((tiles + 1) / 2) : tiles));
+  *grid = G;
+  constexpr int F = cmax(edge_bwd_lds_floats<NTE>(), embed_bwd_lds_floats<NTN>());
+  static_assert(F * 4 <= 80 * 1024, "two workgroups of the tail kernel share a CU's LDS");
+  const size_t lds = (size_t)F * sizeof(float);
+#define K_(ST) tail_bwd_kernel<NTN, NTE, ST>
+  BWD_LAUNCH(K_, G, BW_TPB, lds, e, m);
+#undef K_
+  return 0;
+}
+
+// edge_embed_bwd + node_embed_bwd in one launch (no gradients of the raw edge features); both slabs get `*grid` rows
+int embed_tail_bwd(int nt_node, int nt_edge, const float* img_edge, const float* imgT_edge, const float* e_s,
+                   const float* e_v, const int64_t* etypes, const int32_t* eperm, int64_t E, const float* const* g_e,
+                   int n_g, float* edge_slab, const float* img_node, const float* imgT_node, const float* x_s,
+                   const float* x_v, const int64_t* ntypes, int64_t N, const float* g_up0, const float* g_up1,
+                   const float* g_up2, float* g_x_s, float* g_x_v, float* node_slab, int* grid, int bf16, hipStream_t st) {
+  if (n_g < 1 || n_g > EB_MAX_LAYERS) return CGVP_ERR_BAD_ARG;
+  EdgeBArgs e{img_edge, imgT_edge, e_s, e_v, etypes, eperm, E, {}, n_g, edge_slab, nullptr, nullptr};
+  for (int l = 0; l < n_g; ++l) e.g_e[l] = g_e[l];
+  EmbBArgs m{img_node, imgT_node, x_s, x_v, ntypes, N, g_up0, g_up1, g_up2, g_x_s, g_x_v, node_slab};
+#define T_(NTN_, NTE_) if (nt_node == NTN_ && nt_edge == NTE_) return tail_bwd_impl<NTN_, NTE_>(e, m, grid, bf16, st)
+  T_(0, 0); T_(20, 0); T_(21, 0); T_(0, 1); T_(20, 1); T_(21, 1);
+#undef T_
   return CGVP_ERR_UNSUPPORTED_DIMS;
 }
 

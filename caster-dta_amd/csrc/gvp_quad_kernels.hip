@@ -9,6 +9,7 @@
 //                        target nodes (LDS, no atomics) -> dh
 //   node_quad_kernel     residual + LN, 2-GVP feed-forward, residual + LN (+ head)
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "gvp_internal.h"
@@ -47,6 +48,7 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 constexpr int WAVE = 64;
 constexpr int WPB = 4;                 // waves per workgroup
 constexpr int TPB = WAVE * WPB;
+constexpr int gq_fwd_tpb = TPB;
 constexpr int TILE = 16;
 
 // Workgroup-cooperative copy of an image slice (NFLOATS, multiple of 4) into LDS:
@@ -74,7 +76,7 @@ __device__ __forceinline__ void stage_slice(float* lds, const float* __restrict_
 // Up to three slices (from three places of the image) into consecutive LDS: ALL global loads are issued before the
 // first LDS store, so the copies cost one memory latency together instead of one each (the fused conv + node update
 // (+ head) kernel stages 68-74 KB per workgroup).  A size of 0 skips a slice.
-template <int N0, int N1, int N2>
+template <int N0, int N1, int N2, int TPB = gq_fwd_tpb>
 __device__ __forceinline__ void stage_slices(float* lds, const float* __restrict__ s0, const float* __restrict__ s1,
                                              const float* __restrict__ s2, int tid) {
   static_assert(N0 % 4 == 0 && N1 % 4 == 0 && N2 % 4 == 0, "image slices are whole float4s");
@@ -571,8 +573,13 @@ __device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, i
 // segment total into the wave's private LDS accumulator.  Ownership makes the
 // result independent of scheduling: no atomics on HBM, bitwise reproducible.
 // FUSE: 0 = conv only; 1 = + node update; 2 = + node update with the output head
-template <int NTE, int FUSE, int EMODE, typename ST>
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_quad_kernel(ConvQArgs a) {
+// CW = waves per workgroup: 8 (default) = ONE workgroup per CU, so a launch of <= 240 workgroups leaves whole CUs free
+// for the drug encoder's kernels on the side stream (with 4-wave workgroups the dispatcher spread 480 of them over all
+// 256 CUs and the drug forward found no CU to start on until both conv launches had drained: 54 us late in the round-4
+// step trace); 4 = the round-1..3 shape (CGVP_CONV_FWD_WAVES=4, A/B).
+template <int NTE, int FUSE, int EMODE, typename ST, int CW = 4>
+__global__ __launch_bounds__(WAVE * CW) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_quad_kernel(ConvQArgs a) {
+  constexpr int WPB = CW, TPB = WAVE * CW;
   typedef Image<0, NTE> IM;
   typedef Image<0, 0> IMN;
   constexpr int ACC = WAVE * ROW;
@@ -593,7 +600,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   conv_gather<NTE, EMODE, ST>(a, e0, e1, lane, in);
   if (EMODE == 1 && blockIdx.x == 0 && threadIdx.x < EROW / 4)        // the store's spare row is always all zeros
     Io<ST>::st4(a.e_out, a.E * EROW + 4 * threadIdx.x, f4{0.f, 0.f, 0.f, 0.f});
-  stage_slices<IM::CV_SIZE, (FUSE > 0 ? IMN::ND_SIZE : 0), (FUSE == 2 ? IMN::HD_SIZE : 0)>(
+  stage_slices<IM::CV_SIZE, (FUSE > 0 ? IMN::ND_SIZE : 0), (FUSE == 2 ? IMN::HD_SIZE : 0), TPB>(
       img, a.img, a.node.img_node, a.node.img_head, threadIdx.x);      // nd_img = img + CV_SIZE, the head slice behind it
   for (int k = lane; k < nn * ROW; k += WAVE) acc[k] = 0.f;
   STAMP(1);
@@ -759,23 +766,32 @@ int pass_begin(const EncLayout& L, int num_convs, int bf16, const float* params,
   return 0;
 }
 
-template <int NTE, int FUSE, int EMODE, typename ST>
-int conv_launch_e(const ConvQArgs& a, dim3 grid, hipStream_t st) {
+inline int conv_fwd_waves() {
+  static const int w = [] { const char* e = getenv("CGVP_CONV_FWD_WAVES"); return (e && e[0] == '4') ? 4 : 8; }();
+  return w;
+}
+template <int NTE, int FUSE, int EMODE, typename ST, int CW>
+int conv_launch_w(const ConvQArgs& a, int64_t groups, hipStream_t st) {
   const size_t lds = (size_t)(Image<0, NTE>::CV_SIZE + (FUSE == 0 ? 0 : Image<0, 0>::ND_SIZE + (FUSE == 2 ? Image<0, 0>::HD_SIZE : 0)) +
-                              WPB * WAVE * ROW) * sizeof(float);
-  if (lds > 64 * 1024) CGVP_SET_DYN_LDS_ONCE((conv_quad_kernel<NTE, FUSE, EMODE, ST>), lds);      // once per kernel and device; an error is returned
-  hipLaunchKernelGGL((conv_quad_kernel<NTE, FUSE, EMODE, ST>), grid, dim3(TPB), lds, st, a);
+                              CW * WAVE * ROW) * sizeof(float);
+  if (lds > 64 * 1024) CGVP_SET_DYN_LDS_ONCE((conv_quad_kernel<NTE, FUSE, EMODE, ST, CW>), lds);      // once per kernel and device; an error is returned
+  hipLaunchKernelGGL((conv_quad_kernel<NTE, FUSE, EMODE, ST, CW>), dim3((unsigned)((groups + CW - 1) / CW)), dim3(WAVE * CW), lds, st, a);
   return 0;
 }
+template <int NTE, int FUSE, int EMODE, typename ST>
+int conv_launch_e(const ConvQArgs& a, int64_t groups, hipStream_t st) {
+  if (conv_fwd_waves() == 4) return conv_launch_w<NTE, FUSE, EMODE, ST, 4>(a, groups, st);
+  return conv_launch_w<NTE, FUSE, EMODE, ST, 8>(a, groups, st);
+}
 template <int NTE, int FUSE, typename ST>
-int conv_launch_s(const ConvQArgs& a, dim3 grid, hipStream_t st) {
+int conv_launch_s(const ConvQArgs& a, int64_t grid, hipStream_t st) {
   if (a.e_in) return conv_launch_e<NTE, FUSE, 2, ST>(a, grid, st);
   if (a.e_out) return conv_launch_e<NTE, FUSE, 1, ST>(a, grid, st);
   return conv_launch_e<NTE, FUSE, 0, ST>(a, grid, st);
 }
 // `bf16` below is the tile policy index (gvp_internal.h, POLICY_*): 0 float, 1 bf16s, 2 f32_gvpdef, 3 f32_linear
 template <int NTE, int FUSE>
-int conv_launch(const ConvQArgs& a, dim3 grid, int bf16, hipStream_t st) {
+int conv_launch(const ConvQArgs& a, int64_t grid, int bf16, hipStream_t st) {
   if (bf16 >= POLICY_GVPDEF) {      // the other layer kinds: stand-alone layers (stored edge embedding, no type columns, two launches)
     if constexpr (NTE == 0 && FUSE == 0) {
       if (!a.e_in) return CGVP_ERR_UNSUPPORTED_DIMS;
@@ -813,7 +829,7 @@ int conv(int nt_edge, const float* img, const float* h, const float* e_s, const 
   ConvQArgs a{img, h, e_s, e_v, etypes, rowptr, eperm, esrc, edst, N, npw, mean, dh,
               NodeQArgs{img_node, img_head, h, nullptr, N, h_out, out, mask0, mask1, rng}, e_in, e_out, E};
   const int64_t groups = (N + npw - 1) / npw;
-  const dim3 grid((unsigned)((groups + WPB - 1) / WPB));
+  const int64_t grid = groups;                 // waves; conv_launch_w turns them into workgroups
   if (nt_edge != 0 && nt_edge != 1) return CGVP_ERR_UNSUPPORTED_DIMS;
   if (fuse < 0 || fuse > 2) return CGVP_ERR_BAD_ARG;
   if (nt_edge == 0) {

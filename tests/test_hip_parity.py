@@ -33,8 +33,9 @@ def _csr_numpy(ei, n):
     return np.cumsum(rowptr), order, ei[0][order], dst[order]
 
 
-@pytest.mark.parametrize("case", ["davis", "knn", "ragged", "empty_edges", "isolated"])
+@pytest.mark.parametrize("case", ["davis", "knn", "ragged", "empty_edges", "isolated", "crowded", "large"])
 def test_csr_from_coo(case):
+    """Tables of fewer than 64k targets take the multi-workgroup scan; "large" (70k targets) the one-block tile scan."""
     if case == "davis":
         gb = ds.protein_batch(4, 3)
     elif case == "knn":
@@ -48,6 +49,14 @@ def test_csr_from_coo(case):
         rng = np.random.default_rng(0)
         n = 1000
         ei = np.stack([rng.integers(0, n, 5000), rng.integers(0, n // 2, 5000)])
+    if case == "crowded":                       # ~67 edges per target
+        rng = np.random.default_rng(1)
+        n = 300
+        ei = np.stack([rng.integers(0, n, 20000), rng.integers(0, n, 20000)])
+    if case == "large":
+        rng = np.random.default_rng(2)
+        n = 70000
+        ei = np.stack([rng.integers(0, n, 140000), rng.integers(0, n, 140000)])
     csr = ops.build_csr(torch.from_numpy(ei).to(DEV), n)
     rp, perm, src, dst = _csr_numpy(ei, n)
     E = ei.shape[1]
