@@ -77,18 +77,6 @@ int conv_bwd(int nt_edge, const float* img, const float* imgT, const float* h, c
 int edge_embed_bwd(int nt_edge, const float* img, const float* imgT, const float* e_s, const float* e_v,
                    const int64_t* etypes, const int32_t* eperm, int64_t E, const float* const* g_e, int n_g,
                    float* g_e_s, float* g_e_v, float* slab, int* grid, int bf16, hipStream_t st);
-// edge_embed_bwd + node_embed_bwd in one launch (no raw edge-feature gradients); both slabs get `*grid` rows
-int embed_tail_bwd(int nt_node, int nt_edge, const float* img_edge, const float* imgT_edge, const float* e_s,
-                   const float* e_v, const int64_t* etypes, const int32_t* eperm, int64_t E, const float* const* g_e,
-                   int n_g, float* edge_slab, const float* img_node, const float* imgT_node, const float* x_s,
-                   const float* x_v, const int64_t* ntypes, int64_t N, const float* g_up0, const float* g_up1,
-                   const float* g_up2, float* g_x_s, float* g_x_v, float* node_slab, int* grid, int bf16, hipStream_t st);
-// the same behind the checks of cgvp_edge_embed_bwd / cgvp_node_embed_bwd, for the whole-pass backward (gvp_kernels.hip)
-int lba_embed_tail_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image, const float* x_s,
-                       const float* x_v, const int64_t* ntypes, int64_t N, const float* g_up0, const float* g_up1,
-                       const float* g_up2, float* g_x_s, float* g_x_v, const float* e_s, const float* e_v,
-                       const int64_t* etypes, const int32_t* eperm, int64_t E, const float* const* g_e, int32_t num_g,
-                       float* node_ws, float* edge_ws, cgvp_segment* segs, int32_t* nsegs, hipStream_t st);
 constexpr int kEdgeRow = 36;              // floats per edge of the stored edge embedding: [e_s 32 | e_v 3 | pad]
 int node_embed_bwd(int nt_node, const float* img, const float* imgT, const float* x_s, const float* x_v,
                    const int64_t* ntypes, int64_t N, const float* g_up0, const float* g_up1, const float* g_up2,

@@ -1069,39 +1069,6 @@ int cgvp_node_embed_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const 
   return launch_status();
 }
 
-}  // extern "C"
-
-namespace quad {
-// cgvp_edge_embed_bwd (without raw-feature gradients) + cgvp_node_embed_bwd as ONE launch for the whole-pass backward;
-// two segments (edge stage first), same argument rules as the two entry points
-int lba_embed_tail_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image, const float* x_s,
-                       const float* x_v, const int64_t* ntypes, int64_t N, const float* g_up0, const float* g_up1,
-                       const float* g_up2, float* g_x_s, float* g_x_v, const float* e_s, const float* e_v,
-                       const int64_t* etypes, const int32_t* eperm, int64_t E, const float* const* g_e, int32_t num_g,
-                       float* node_ws, float* edge_ws, cgvp_segment* segs, int32_t* nsegs, hipStream_t st) {
-  if (int rc = check_dims_gated(dims)) return rc;
-  if (N <= 0 || E <= 0 || !layout || !image || !node_ws || !edge_ws || !g_e || num_g < 1 || !segs || !nsegs) return CGVP_ERR_BAD_ARG;
-  if (!x_s || !x_v || (layout->nt_node > 0 && !ntypes) || ((g_x_s == nullptr) != (g_x_v == nullptr))) return CGVP_ERR_BAD_ARG;
-  if (!e_s || !e_v || !eperm || (layout->nt_edge > 0 && !etypes)) return CGVP_ERR_BAD_ARG;
-  const void* al[] = {g_up0, g_up1, g_up2, e_s};
-  for (const void* q : al) if ((uintptr_t)q & 15) return CGVP_ERR_BAD_ARG;
-  for (int l = 0; l < num_g; ++l) if (!g_e[l] || ((uintptr_t)g_e[l] & 15)) return CGVP_ERR_BAD_ARG;
-  QuadOffsets o;
-  if (int rc = quad::offsets(layout->nt_node, layout->nt_edge, num_convs_of(*layout), &o)) return rc;
-  int emb, ce, ct, nd, hd, grid = 0;
-  if (int rc = quad::bwd_block_sizes(layout->nt_node, layout->nt_edge, &emb, &ce, &ct, &nd, &hd)) return rc;
-  if (int rc = quad::embed_tail_bwd(layout->nt_node, layout->nt_edge, image + o.conv0, image + o.convT0, e_s, e_v, etypes,
-                                    eperm, E, g_e, num_g, edge_ws, image + o.emb, image + o.embT, x_s, x_v, ntypes, N,
-                                    g_up0, g_up1, g_up2, g_x_s, g_x_v, node_ws, &grid, policy_of(dims), st)) return rc;
-  segs[0] = cgvp_segment{edge_ws, grid, ce, 0, layout->conv0 - layout->edge_gvp, layout->edge_gvp};
-  segs[1] = cgvp_segment{node_ws, grid, emb, 0, layout->edge_gvp - layout->node_gvp, layout->node_gvp};
-  *nsegs = 2;
-  return launch_status();
-}
-}  // namespace quad
-
-extern "C" {
-
 int cgvp_gine_conv_fwd(const float* x, const int64_t* ntypes, int32_t num_ntypes, const float* eattr,
                        const int64_t* etypes, int32_t num_etypes, int32_t edge_dim,
                        const int32_t* rowptr, const int32_t* eperm, const int32_t* esrc, const int32_t* edst,

@@ -410,7 +410,7 @@ __global__ __launch_bounds__(BW_TPB, 2) void node_head_bwd_kernel(HeadBArgs hd, 
 // ===================================================================== conv
 // The edge embedding (gvp_edge + LayerNorm, protein_gnn.py:376) is NOT part of this kernel: the first conv layer's
 // forward stored it in sorted-edge order (EROW floats per edge), this kernel reads it as an input of message_func.0
-// and writes its gradient d e to `g_e` (same layout); edge_bwd_kernel below back-propagates the SUM of the layers'
+// and writes its gradient d e to `g_e` (same layout, same storage type); edge_bwd_kernel below back-propagates the SUM of the layers'
 // d e through LayerNorm and gvp_edge once per step.  (Round 1 recomputed the embedding and ran its backward and
 // weight gradients inside every conv layer's backward: 32 + ~70 of that kernel's 319 MFMAs per 16 edges, a
 // 4.8 KB slice of every wave's private gradient block and 14.6 KB of LDS images.)
@@ -581,12 +581,12 @@ __global__ __launch_bounds__(CB_TPB, CB_WPB / 4) void conv_bwd_kernel(ConvBArgs 
       STAMP(4);
       // ---- d(edge embedding) of this layer -> g_e (plain stores, sorted-edge order)
       if (active) {
-        float* gr_ = a.g_e + (int64_t)p * EROW;
-        *reinterpret_cast<f4*>(gr_ + 4 * g) = f4{d_b0[4], d_b0[5], d_b0[6], d_b0[7]};
-        *reinterpret_cast<f4*>(gr_ + 16 + 4 * g) = f4{d_b0[8], d_b0[9], d_b0[10], d_b0[11]};
+        const int64_t gr_ = (int64_t)p * EROW;
+        Io<ST>::st4(a.g_e, gr_ + 4 * g, f4{d_b0[4], d_b0[5], d_b0[6], d_b0[7]});
+        Io<ST>::st4(a.g_e, gr_ + 16 + 4 * g, f4{d_b0[8], d_b0[9], d_b0[10], d_b0[11]});
         if (g == 0) {
 #pragma unroll
-          for (int d = 0; d < 3; ++d) gr_[ES + d] = d_bv0[d][2];
+          for (int d = 0; d < 3; ++d) Io<ST>::st(a.g_e, gr_ + ES + d, d_bv0[d][2]);
         }
       }
       STAMP(5);
@@ -945,13 +945,13 @@ __global__ __launch_bounds__(WAVE * C2_WPB) __attribute__((amdgpu_waves_per_eu(C
     // ---- d(edge embedding) of this layer -> g_e (plain stores, sorted-edge order)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-      if (active[j]) {
-        float* gr_ = a.g_e + (int64_t)(base + j * TILE + i) * EROW;
-        *reinterpret_cast<f4*>(gr_ + 4 * g) = f4{d_b0[j][4], d_b0[j][5], d_b0[j][6], d_b0[j][7]};
-        *reinterpret_cast<f4*>(gr_ + 16 + 4 * g) = f4{d_b0[j][8], d_b0[j][9], d_b0[j][10], d_b0[j][11]};
+      if (active[j]) {          // in the storage type (bf16 storage: the rows the edge stage re-reads are half the bytes)
+        const int64_t gr_ = (int64_t)(base + j * TILE + i) * EROW;
+        Io<ST>::st4(a.g_e, gr_ + 4 * g, f4{d_b0[j][4], d_b0[j][5], d_b0[j][6], d_b0[j][7]});
+        Io<ST>::st4(a.g_e, gr_ + 16 + 4 * g, f4{d_b0[j][8], d_b0[j][9], d_b0[j][10], d_b0[j][11]});
         if (g == 0) {
 #pragma unroll
-          for (int d = 0; d < 3; ++d) gr_[ES + d] = d_bv0[j][d][2];
+          for (int d = 0; d < 3; ++d) Io<ST>::st(a.g_e, gr_ + ES + d, d_bv0[j][d][2]);
         }
       }
     STAMP(5);
@@ -1077,6 +1077,11 @@ __device__ __forceinline__ void edge_bwd_body(const EdgeBArgs& a, float* lds, in
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
   const bool first = false;
   const int64_t tiles = (a.E + TILE - 1) / TILE;
+  // gvp_edge's weight gradients stay in registers over all of the wave's tiles (GvpQ::WAcc, as in the conv backward: a
+  // wave walks ~20 tiles at long_graph_x64) and go to the wave's LDS block once, after the loop; inactive lanes carry
+  // zero gradients (d_es / d_ev are zero there and the LayerNorm backward is linear in them)
+  typename QEdge<NTE>::WAcc wacc;
+  QEdge<NTE>::wacc_zero(wacc);
   for (int64_t t = (int64_t)w * nblk + bid; t < tiles; t += (int64_t)nblk * BW_WPB) {
     const int lane = opaque_lane(lane0), i = lane & 15, g = lane >> 4;
     const int64_t p = t * TILE + i;
@@ -1102,12 +1107,12 @@ __device__ __forceinline__ void edge_bwd_body(const EdgeBArgs& a, float* lds, in
         et[0] = et[0] < 0 ? 0 : (et[0] >= NTE ? NTE - 1 : et[0]);
       }
       for (int l = 0; l < a.n_g; ++l) {                    // sum of the conv layers' d(edge embedding)
-        const float* gr_ = a.g_e[l] + p * EROW;
-        d_es[0] += *reinterpret_cast<const f4*>(gr_ + 4 * g);
-        d_es[1] += *reinterpret_cast<const f4*>(gr_ + 16 + 4 * g);
+        const int64_t gr_ = p * EROW;
+        d_es[0] += Io<ST>::ld4(a.g_e[l], gr_ + 4 * g);
+        d_es[1] += Io<ST>::ld4(a.g_e[l], gr_ + 16 + 4 * g);
         if (g == 0) {
 #pragma unroll
-          for (int d = 0; d < 3; ++d) d_ev[d][0] += gr_[ES + d];
+          for (int d = 0; d < 3; ++d) d_ev[d][0] += Io<ST>::ld(a.g_e[l], gr_ + ES + d);
         }
       }
     }
@@ -1124,8 +1129,8 @@ __device__ __forceinline__ void edge_bwd_body(const EdgeBArgs& a, float* lds, in
     ln_quad_bwd<ES, EV>(img + IM::CV_ELN, lane, e_pre[0], ev_pre[0], d_es, d_ev, dga, dbe);
     ln_param_grads<AccPriv, ES>(gblk + B::LN, first, lane, active, dga, dbe);
     float d_in[8], d_inv[3][1];
-    typename QEdge<NTE>::Grads gr;
-    QEdge<NTE>::template backward<Io<ST>::BF>(imgT + IM::TC_EDGE, lane, ce[0], d_es, d_ev, d_in, d_inv, gr);
+    typename QEdge<NTE>::Grads gr[1];
+    QEdge<NTE>::template backward<Io<ST>::BF>(imgT + IM::TC_EDGE, lane, ce[0], d_es, d_ev, d_in, d_inv, gr[0]);
     if (DX && active) {               // gradients of the raw features: every valid edge id is written exactly once
       const int64_t er = (int64_t)eid * EDGE_IN_S;
       *reinterpret_cast<f4*>(a.g_e_s + er + 4 * g) = f4{d_in[0], d_in[1], d_in[2], d_in[3]};
@@ -1135,12 +1140,13 @@ __device__ __forceinline__ void edge_bwd_body(const EdgeBArgs& a, float* lds, in
         for (int d = 0; d < 3; ++d) a.g_e_v[(int64_t)eid * 3 + d] = d_inv[d][0];
       }
     }
-    QEdge<NTE>::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::GVP, first, lane, et[0], active, bse[0], bve[0], ce[0], gr, tscr);
+    QEdge<NTE>::template wacc_accumulate<1, Io<ST>::BF>(wacc, lane, et, bse, bve, ce, gr, tscr);
   }
+  QEdge<NTE>::template wacc_flush<AccStoreOnce>(wacc, gblk + B::GVP, lane0);
   write_slab_row<B::SIZE, PW>(a.slab, blocks, bid);
 }
 template <int NTE, typename ST, bool DX = false>
-__global__ __launch_bounds__(BW_TPB, 2) void edge_bwd_kernel(EdgeBArgs a) {
+__global__ __launch_bounds__(BW_TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void edge_bwd_kernel(EdgeBArgs a) {
   WALL_STAMP(3);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   edge_bwd_body<NTE, ST, DX>(a, lds, blockIdx.x, gridDim.x);
@@ -1238,20 +1244,6 @@ __global__ __launch_bounds__(BW_TPB, 2) void embed_bwd_kernel(EmbBArgs a) {
   WALL_STAMP(4);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   embed_bwd_body<NTN, ST>(a, lds, blockIdx.x, gridDim.x);
-}
-
-// The two embedding stages as ONE launch at the end of the backward chain: every workgroup runs its edge tiles, writes
-// its edge slab row, then (same LDS) its share of the node tiles and its node slab row.  The stages are independent
-// of each other; as launches of their own each paid the launch ramp / image staging / drain for ~one tile of work
-// per wave (round 4, davis_b64: 8.8 + 19.7 us).  Four waves per SIMD (two workgroups per CU, as the edge kernel
-// alone): the node stage alone would take ~160 VGPRs and spills a few here.
-template <int NTN, int NTE, typename ST>
-__global__ __launch_bounds__(BW_TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void tail_bwd_kernel(EdgeBArgs e, EmbBArgs m) {
-  WALL_STAMP(3);
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  edge_bwd_body<NTE, ST, false>(e, lds, blockIdx.x, gridDim.x);
-  __syncthreads();
-  embed_bwd_body<NTN, ST>(m, lds, blockIdx.x, gridDim.x);
 }
 
 // dst[j] += sum_r slab[r][col0 + j], j < len.  A block owns 64 columns; its 16
@@ -1543,7 +1535,7 @@ int conv_bwd(int nt_edge, const float* img, const float* imgT, const float* h, c
 
 template <int NTE>
 int edge_bwd_impl(EdgeBArgs& a, int* grid, int bf16, hipStream_t st) {
-  // 66 KB of LDS and ~115 VGPRs per workgroup: TWO workgroups share a CU (4 waves per SIMD), so up to 2 x 240 slab rows
+  // 66 KB of LDS and 128 VGPRs per workgroup (capped: 4-8 spilled): TWO workgroups share a CU (4 waves per SIMD), so up to 2 x 240 slab rows
   const int64_t tiles = (a.E + TILE - 1) / TILE;
   const int G = (int)(tiles < 1 ? 1 : (tiles > 2 * bwd_grid_cap((tiles + 1) / 2) ? 2 * bwd_grid_cap((tiles + 1) / 2) : tiles));
   *grid = G;
@@ -1593,35 +1585,5 @@ int node_embed_bwd(int nt_node, const float* img, const float* imgT, const float
   return CGVP_ERR_UNSUPPORTED_DIMS;
 }
 
-
-template <int NTN, int NTE>
-int tail_bwd_impl(EdgeBArgs& e, EmbBArgs& m, int* grid, int bf16, hipStream_t st) {
-  const int64_t tiles = (e.E + TILE - 1) / TILE;
-  const int G = (int)(tiles < 1 ? 1 : (tiles > 2 * bwd_grid_cap((tiles + 1) / 2) ? 2 * bwd_grid_cap((tiles + 1) / 2) : tiles));
-  *grid = G;
-  constexpr int F = cmax(edge_bwd_lds_floats<NTE>(), embed_bwd_lds_floats<NTN>());
-  static_assert(F * 4 <= 80 * 1024, "two workgroups of the tail kernel share a CU's LDS");
-  const size_t lds = (size_t)F * sizeof(float);
-#define K_(ST) tail_bwd_kernel<NTN, NTE, ST>
-  BWD_LAUNCH(K_, G, BW_TPB, lds, e, m);
-#undef K_
-  return 0;
-}
-
-// edge_embed_bwd + node_embed_bwd in one launch (no gradients of the raw edge features); both slabs get `*grid` rows
-int embed_tail_bwd(int nt_node, int nt_edge, const float* img_edge, const float* imgT_edge, const float* e_s,
-                   const float* e_v, const int64_t* etypes, const int32_t* eperm, int64_t E, const float* const* g_e,
-                   int n_g, float* edge_slab, const float* img_node, const float* imgT_node, const float* x_s,
-                   const float* x_v, const int64_t* ntypes, int64_t N, const float* g_up0, const float* g_up1,
-                   const float* g_up2, float* g_x_s, float* g_x_v, float* node_slab, int* grid, int bf16, hipStream_t st) {
-  if (n_g < 1 || n_g > EB_MAX_LAYERS) return CGVP_ERR_BAD_ARG;
-  EdgeBArgs e{img_edge, imgT_edge, e_s, e_v, etypes, eperm, E, {}, n_g, edge_slab, nullptr, nullptr};
-  for (int l = 0; l < n_g; ++l) e.g_e[l] = g_e[l];
-  EmbBArgs m{img_node, imgT_node, x_s, x_v, ntypes, N, g_up0, g_up1, g_up2, g_x_s, g_x_v, node_slab};
-#define T_(NTN_, NTE_) if (nt_node == NTN_ && nt_edge == NTE_) return tail_bwd_impl<NTN_, NTE_>(e, m, grid, bf16, st)
-  T_(0, 0); T_(20, 0); T_(21, 0); T_(0, 1); T_(20, 1); T_(21, 1);
-#undef T_
-  return CGVP_ERR_UNSUPPORTED_DIMS;
-}
 
 }  // namespace quad

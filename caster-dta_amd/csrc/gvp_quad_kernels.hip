@@ -573,10 +573,10 @@ __device__ __forceinline__ void conv_tiles(const float* img, const ConvIn& in, i
 // segment total into the wave's private LDS accumulator.  Ownership makes the
 // result independent of scheduling: no atomics on HBM, bitwise reproducible.
 // FUSE: 0 = conv only; 1 = + node update; 2 = + node update with the output head
-// CW = waves per workgroup: 8 (default) = ONE workgroup per CU, so a launch of <= 240 workgroups leaves whole CUs free
-// for the drug encoder's kernels on the side stream (with 4-wave workgroups the dispatcher spread 480 of them over all
-// 256 CUs and the drug forward found no CU to start on until both conv launches had drained: 54 us late in the round-4
-// step trace); 4 = the round-1..3 shape (CGVP_CONV_FWD_WAVES=4, A/B).
+// CW = waves per workgroup: 8 = ONE workgroup per CU, so a launch of <= 240 workgroups leaves whole CUs free for the
+// drug encoder's kernels on the side stream (with 4-wave workgroups the dispatcher spread 480 of them over all 256 CUs
+// and the drug forward found no CU to start on until both conv launches had drained: 54 us late in the round-4 step
+// trace); 4 = two workgroups per CU, the shape of larger launches (conv_fwd_waves below picks).
 template <int NTE, int FUSE, int EMODE, typename ST, int CW = 4>
 __global__ __launch_bounds__(WAVE * CW) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_quad_kernel(ConvQArgs a) {
   constexpr int WPB = CW, TPB = WAVE * CW;
@@ -766,9 +766,13 @@ int pass_begin(const EncLayout& L, int num_convs, int bf16, const float* params,
   return 0;
 }
 
-inline int conv_fwd_waves() {
-  static const int w = [] { const char* e = getenv("CGVP_CONV_FWD_WAVES"); return (e && e[0] == '4') ? 4 : 8; }();
-  return w;
+// 8-wave workgroups only while they all fit one-per-CU in a single round (their 100 KB of LDS allows no second
+// workgroup on a CU: kiba_b32's 288 of them ran as 256 + a 32-workgroup second round, 0.275 -> 0.288 ms per step);
+// CGVP_CONV_FWD_WAVES=4|8 in the environment (read once) forces a shape: A/B knob.
+inline int conv_fwd_waves(int64_t groups) {
+  static const int forced = [] { const char* e = getenv("CGVP_CONV_FWD_WAVES"); return (e && e[0] == '4') ? 4 : ((e && e[0] == '8') ? 8 : 0); }();
+  if (forced) return forced;
+  return groups <= 8 * (int64_t)kBwdMaxGrid ? 8 : 4;
 }
 template <int NTE, int FUSE, int EMODE, typename ST, int CW>
 int conv_launch_w(const ConvQArgs& a, int64_t groups, hipStream_t st) {
@@ -780,7 +784,7 @@ int conv_launch_w(const ConvQArgs& a, int64_t groups, hipStream_t st) {
 }
 template <int NTE, int FUSE, int EMODE, typename ST>
 int conv_launch_e(const ConvQArgs& a, int64_t groups, hipStream_t st) {
-  if (conv_fwd_waves() == 4) return conv_launch_w<NTE, FUSE, EMODE, ST, 4>(a, groups, st);
+  if (conv_fwd_waves(groups) == 4) return conv_launch_w<NTE, FUSE, EMODE, ST, 4>(a, groups, st);
   return conv_launch_w<NTE, FUSE, EMODE, ST, 8>(a, groups, st);
 }
 template <int NTE, int FUSE, typename ST>

@@ -362,21 +362,6 @@ int cgvp_lba_backward_pass(const cgvp_dims* dims, const cgvp_layout* layout, con
     nseg += cnt;
     up0 = g_h ? g_h : g_dh; up1 = g_src; up2 = g_dst;
   }
-  // CGVP_SPLIT_TAIL_BWD=1 keeps the two embedding stages in launches of their own (A/B switch; same results)
-  static const bool split_tail = [] { const char* e = getenv("CGVP_SPLIT_TAIL_BWD"); return e && e[0] == '1'; }();
-  if (E > 0 && !g_e_s && nc <= 16 && !split_tail) {
-    const float* ge[16];
-    for (int l = 0; l < nc; ++l) ge[l] = g_e + (int64_t)l * bw.g_e_stride;
-    float* node_ws = region();
-    float* edge_ws = region();
-    if (int rc = quad::lba_embed_tail_bwd(dims, layout, image, batch->x_s, batch->x_v, batch->ntypes, N, up0, up1, up2, g_x_s,
-                                          g_x_v, batch->e_s, batch->e_v, batch->etypes, eperm, E, ge, nc, node_ws, edge_ws,
-                                          segs + nseg, &cnt, st))
-      return rc;
-    nseg += cnt;
-    if (int rc = cgvp_bwd_reduce(segs, nseg, grad_params, 1, stream)) return rc;
-    return launch_status();
-  }
   if (int rc = cgvp_node_embed_bwd(dims, layout, image, batch->x_s, batch->x_v, batch->ntypes, N, up0, up1, up2, g_x_s, g_x_v,
                                    grad_params, region(), segs + nseg, &cnt, stream))
     return rc;

@@ -318,8 +318,10 @@ int cgvp_node_update_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const
  * embedding store the forward wrote ([E][CGVP_EDGE_ROW], sorted-edge order).  Gradients w.r.t. the node rows
  * arrive in two buffers that the consumer sums: g_src [N][28] (scatter over the unsorted sources; float atomics;
  * zeroed by this call unless g_src_zeroed != 0) and g_dst [N][28] (segmented sums over the sorted targets; every
- * row written).  g_e [E][CGVP_EDGE_ROW] receives this layer's d(edge embedding) (plain stores, every row); the
- * gradients of gvp_edge's own weights come from ONE cgvp_edge_embed_bwd over all layers' g_e. */
+ * row written).  g_e [E][CGVP_EDGE_ROW] receives this layer's d(edge embedding) (plain stores, every row, in the
+ * storage type of dims->storage like e_emb -- the only gradient buffer that is not fp32 under CGVP_BF16: it is the
+ * largest one and cgvp_edge_embed_bwd rounds it to bf16 matrix operands anyway); the gradients of gvp_edge's own
+ * weights come from ONE cgvp_edge_embed_bwd over all layers' g_e. */
 int cgvp_conv_bwd(const cgvp_dims* dims, const cgvp_layout* layout, const float* image, int32_t layer,
                   const float* h, const float* e_emb, const int32_t* rowptr, const int32_t* esrc,
                   const int32_t* edst, int64_t num_nodes, int64_t num_edges, int32_t aggr_mean,
