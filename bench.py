@@ -590,6 +590,24 @@ def main():
         dist.destroy_process_group()
 
 
+EPOCH_PASSES = 3      # timed passes of every host-bound epoch leg; the MEDIAN pass is reported, all of them listed
+
+
+def _timed_passes(run_epoch, steps, passes=EPOCH_PASSES):
+    """(wall ms/step, host-issue ms/step) of the median pass + every pass's wall ms/step.  Host-bound legs swing by up to
+    2x between passes on a GPU box whose host cores are shared (0.33-0.79 ms per step measured back to back, one process):
+    one pass is not a measurement."""
+    res = []
+    for _ in range(passes):
+        t0 = time.perf_counter()
+        run_epoch()
+        t_issue = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        res.append((time.perf_counter() - t0, t_issue))
+    med = sorted(res)[len(res) // 2]
+    return med[0], med[1], [round(r[0] / steps * 1e3, 4) for r in res]
+
+
 def epoch_leg(args, model, dev, train, prot_params, drug_params, variant="nominal", light=False):
     """BASELINE config 2 as stated ("Davis full epoch ... batch 64"): every step a DIFFERENT batch -- other proteins, other
     N / E, a new edge_index -- launched eagerly through the nn.Module API, exactly the call pattern of
@@ -659,20 +677,19 @@ def epoch_leg(args, model, dev, train, prot_params, drug_params, variant="nomina
     from gvp_hip import _lib as _l
     br = _l.bridge()
     with torch.set_grad_enabled(train):
-        # untimed first pass over the epoch's batches: the timed pass is a SECOND epoch, i.e. the caching allocator already
-        # holds blocks for every workspace size the epoch asks for (a first epoch pays one hipMalloc per new size:
-        # 0.59 vs 0.32 ms per step measured on one box) -- the same footing as the bucketed leg, whose graphs are
-        # captured in an untimed pass
+        # untimed first pass over the epoch's batches: the timed passes are later epochs, i.e. the caching allocator already
+        # holds blocks for every workspace size the epoch asks for -- the same footing as the bucketed leg, whose graphs
+        # are captured in an untimed pass
         for b in batches:
             step(*b)
         torch.cuda.synchronize()
         fast0 = br.fast_leaf_passes() if br is not None else 0
-        t0 = time.perf_counter()
-        for b in batches:
-            step(*b)
-        t_issue = time.perf_counter() - t0
-        torch.cuda.synchronize()
-        t_all = time.perf_counter() - t0
+
+        def run_epoch():
+            for b in batches:
+                step(*b)
+
+        t_all, t_issue, eager_passes = _timed_passes(run_epoch, steps)
         fast_passes = (br.fast_leaf_passes() - fast0) if br is not None else 0
     # ---- the WHOLE model over the same epoch (encoders + cross-attention head + MSE loss, all 764k gradients):
     # eager `loss.backward()` and shape-bucketed whole-step graphs (gvp_hip.graphed.GraphedTrainStep)
@@ -715,18 +732,13 @@ def epoch_leg(args, model, dev, train, prot_params, drug_params, variant="nomina
             for b in batches:                                   # untimed first pass, as above
                 step(*b)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for b in batches:
-                step(*b)
-            t_fi = time.perf_counter() - t0
-            torch.cuda.synchronize()
-            t_fa = time.perf_counter() - t0
-        fused = {"what": "same eager epoch after JointGNN.fuse_encoder_parameters(): each encoder's parameter arena is its "
+            t_fa, t_fi, fused_passes = _timed_passes(run_epoch, steps)
+        fused = {"passes_ms": fused_passes, "what": "same eager epoch after JointGNN.fuse_encoder_parameters(): each encoder's parameter arena is its "
                          "one trainable leaf (checkpoint keys unchanged)", "leaves": len(prot_params) + len(drug_params),
                  "ms_per_step": round(t_fa / steps * 1e3, 4), "host_issue_ms_per_step": round(t_fi / steps * 1e3, 4),
                  "pairs_per_s": round(B * steps / t_fa, 1)}
     edges = [int(b[0]["edge_index"].shape[1]) for b in batches]
-    ret_extra = {"eager_fused_parameters": fused, "joint": joint,
+    ret_extra = {"eager_fused_parameters": fused, "joint": joint, "passes_ms": eager_passes,
                  # backward passes of the eager leg whose node wrote the leaves' .grad itself (csrc/torch_bridge.cpp LeafScatter)
                  "eager_backward_passes_without_leaf_tasks": int(fast_passes)}
     return {**_epoch_summary(args, variant, steps, B, n_prot, n_drug, t_all, t_issue, batches, edges, t_gen, graphed), **ret_extra}
@@ -752,13 +764,14 @@ def joint_epoch(args, model, dev, batches, B, steps):
         for pd, md in dicts:                                      # untimed first pass (allocator pool of a second epoch, see epoch_leg)
             eager(pd, md)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for pd, md in dicts:
-            eager(pd, md)
-        t_i = time.perf_counter() - t0
-        torch.cuda.synchronize()
-        t_a = time.perf_counter() - t0
-        out["eager"] = {"what": "model(pdata, mdata) -> mse_loss -> loss.backward() -> zero_grad(), every step a different batch",
+
+        def run_eager():
+            for pd, md in dicts:
+                eager(pd, md)
+
+        t_a, t_i, jp = _timed_passes(run_eager, steps)
+        out["eager"] = {"what": "model(pdata, mdata) -> mse_loss -> loss.backward() -> zero_grad(), every step a different batch; "
+                                "median of the timed passes", "passes_ms": jp,
                         "ms_per_step": round(t_a / steps * 1e3, 4), "host_issue_ms_per_step": round(t_i / steps * 1e3, 4),
                         "pairs_per_s": round(B * steps / t_a, 1)}
         runner = GraphedTrainStep(model, loss_fn)
@@ -780,9 +793,9 @@ def joint_epoch(args, model, dev, batches, B, steps):
 
 
 def _epoch_summary(args, variant, steps, B, n_prot, n_drug, t_all, t_issue, batches, edges, t_gen, graphed):
-    return {"what": "one epoch of DIFFERENT batches (timed on its second pass), eager (no HIP graph), nn.Module API (forward, backward(), gradient reset), C++ autograd fast path" if
+    return {"what": "one epoch of DIFFERENT batches (untimed first pass, then the median of %d timed passes), eager (no HIP graph), nn.Module API (forward, backward(), gradient reset), C++ autograd fast path" % EPOCH_PASSES if
             __import__("gvp_hip._lib", fromlist=["bridge"]).bridge() is not None else
-            "one epoch of DIFFERENT batches (timed on its second pass), eager (no HIP graph), nn.Module API, Python custom ops",
+            "one epoch of DIFFERENT batches (untimed first pass, then the median of %d timed passes), eager (no HIP graph), nn.Module API, Python custom ops" % EPOCH_PASSES,
             "variant": variant, "steps": steps, "pairs_per_step": B, "unique_proteins": n_prot, "unique_drugs": n_drug,
             "ms_per_step": round(t_all / steps * 1e3, 4), "host_issue_ms_per_step": round(t_issue / steps * 1e3, 4),
             "pairs_per_s": round(B * steps / t_all, 1),
