@@ -21,6 +21,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gvp_internal.h"
 #include "gvp_quad.h"
 
@@ -114,6 +116,10 @@ __device__ __forceinline__ void stage_slice(float* lds, const float* __restrict_
 }
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
+// ONE = every wave of the launch has at most one tile (the host checks tiles <= grid x waves): a wave's private block is
+// still all zeros when its only tile adds to it, so the adds are plain stores -- no LDS read in front of each write
+// (the node / head / embed stages at 64 x 300 residues are exactly this case)
+template <bool ONE> using AccFor = typename std::conditional<ONE, AccStoreOnce, AccPriv>::type;
 constexpr int pad4(int x) { return (x + 3) / 4 * 4; }
 
 // LayerNorm parameter gradients of a tile -> [gamma | beta] block in LDS.
@@ -171,9 +177,10 @@ static_assert(node_bwd_lds_floats() * 4 <= 160 * 1024, "node backward LDS plan e
 
 // g_up0 may alias g_dh (the head backward leaves d h_out there): a tile's rows are read
 // by the same lanes that overwrite them at the end of the tile.
-template <typename ST>
+template <typename ST, bool ONE = false>
 __device__ __forceinline__ void node_bwd_body(const NodeBArgs& a, float* lds) {
   typedef Image<0, 0> IM;
+  typedef AccFor<ONE> Acc;
   float* f_node = lds + BW_TPB;                                     // lds[0..BW_TPB): AccPriv::trash()
   float* t_node = f_node + IM::ND_SIZE;
   float* blocks = t_node + IM::TN_SIZE;
@@ -251,7 +258,7 @@ __device__ __forceinline__ void node_bwd_body(const NodeBArgs& a, float* lds) {
     {
       f4 dga[1], dbe[1];
       ln_quad_bwd<NS, NV>(f_node + IM::ND_LN1, lane, z, zv, gs, gv, dga, dbe);      // gs/gv := d z
-      ln_param_grads<AccPriv, NS>(gblk + NB_LN1, first, lane, active, dga, dbe);
+      ln_param_grads<Acc, NS>(gblk + NB_LN1, first, lane, active, dga, dbe);
     }
     float d_hs[16], d_hv[3][2];
     {
@@ -261,7 +268,7 @@ __device__ __forceinline__ void node_bwd_body(const NodeBArgs& a, float* lds) {
       STAMP(4);
       Ff1<ST>::template backward<Io<ST>::BF>(t_node + IM::TN_FF1, lane, c1[0], d_so, d_vo, d_hs, d_hv, gr1);
       STAMP(5);
-      Ff1<ST>::template weight_grads<AccPriv, Io<ST>::BF>(gblk + NB_FF1, first, lane, 0, active, bs1[0], bv1[0], c1[0], gr1, tscr);
+      Ff1<ST>::template weight_grads<Acc, Io<ST>::BF>(gblk + NB_FF1, first, lane, 0, active, bs1[0], bv1[0], c1[0], gr1, tscr);
     }
     {
       f4 d_so[4];
@@ -272,7 +279,7 @@ __device__ __forceinline__ void node_bwd_body(const NodeBArgs& a, float* lds) {
       STAMP(6);
       Ff0<ST>::template backward<Io<ST>::BF>(t_node + IM::TN_FF0, lane, c0[0], d_so, d_hv, d_ys, d_yv, gr0);
       STAMP(7);
-      Ff0<ST>::template weight_grads<AccPriv, Io<ST>::BF>(gblk + NB_FF0, first, lane, 0, active, bs0[0], bv0[0], c0[0], gr0, tscr);
+      Ff0<ST>::template weight_grads<Acc, Io<ST>::BF>(gblk + NB_FF0, first, lane, 0, active, bs0[0], bv0[0], c0[0], gr0, tscr);
 #pragma unroll
       for (int r = 0; r < 4; ++r) gs[0][r] += d_ys[r];
 #pragma unroll
@@ -282,7 +289,7 @@ __device__ __forceinline__ void node_bwd_body(const NodeBArgs& a, float* lds) {
     {
       f4 dga[1], dbe[1];
       ln_quad_bwd<NS, NV>(f_node + IM::ND_LN0, lane, x0, xv0, gs, gv, dga, dbe);    // gs/gv := d (h + dh)
-      ln_param_grads<AccPriv, NS>(gblk + NB_LN0, first, lane, active, dga, dbe);
+      ln_param_grads<Acc, NS>(gblk + NB_LN0, first, lane, active, dga, dbe);
     }
     if (active) {               // d h (residual path) and d dh = mask0 * d h (equal without dropout)
       if (a.g_h) {
@@ -307,11 +314,11 @@ __device__ __forceinline__ void node_bwd_body(const NodeBArgs& a, float* lds) {
   write_slab_row<NODE_GB, NODE_GB>(a.slab, blocks);
   STAMP(10);
 }
-template <typename ST>
+template <typename ST, bool ONE = false>
 __global__ __launch_bounds__(BW_TPB, 2) void node_bwd_kernel(NodeBArgs a) {
   WALL_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  node_bwd_body<ST>(a, lds);
+  node_bwd_body<ST, ONE>(a, lds);
 }
 
 // ===================================================================== output head
@@ -323,9 +330,10 @@ struct HeadBArgs {
 };
 constexpr int head_bwd_lds_floats() { return BW_TPB + Image<0, 0>::HD_SIZE + Image<0, 0>::TH_SIZE + BW_WPB * (HEAD_GB + TSCR_FLOATS); }
 
-template <typename ST>
+template <typename ST, bool ONE = false>
 __device__ __forceinline__ void head_bwd_body(const HeadBArgs& a, float* lds) {
   typedef Image<0, 0> IM;
+  typedef AccFor<ONE> Acc;
   float* f_head = lds + BW_TPB;
   float* t_head = f_head + IM::HD_SIZE;
   float* blocks = t_head + IM::TH_SIZE;
@@ -371,12 +379,12 @@ __device__ __forceinline__ void head_bwd_body(const HeadBArgs& a, float* lds) {
     float d_vo[3][1] = {{0.f}, {0.f}, {0.f}}, d_bs[4], d_bv[3][1];
     QHead::Grads grh;
     QHead::template backward<Io<ST>::BF>(t_head, lane, ch[0], d_o, d_vo, d_bs, d_bv, grh);
-    QHead::template weight_grads<AccPriv, Io<ST>::BF>(gblk + HB_GVP, first, lane, 0, active, bsh[0], bvh[0], ch[0], grh, tscr);
+    QHead::template weight_grads<Acc, Io<ST>::BF>(gblk + HB_GVP, first, lane, 0, active, bsh[0], bvh[0], ch[0], grh, tscr);
     f4 dws[1] = {f4{d_bs[0], d_bs[1], d_bs[2], d_bs[3]}};
     float dwv[3][1] = {{d_bv[0][0]}, {d_bv[1][0]}, {d_bv[2][0]}};
     f4 dga[1], dbe[1];
     ln_quad_bwd<NS, NV>(f_head + IM::HD_LN, lane, o1, ov1, dws, dwv, dga, dbe);
-    ln_param_grads<AccPriv, NS>(gblk + HB_LN, first, lane, active, dga, dbe);
+    ln_param_grads<Acc, NS>(gblk + HB_LN, first, lane, active, dga, dbe);
     if (active) {
       float* row = a.g_h_out + n * ROW;
       *reinterpret_cast<f4*>(row + 4 * g) = dws[0];
@@ -398,13 +406,13 @@ __global__ __launch_bounds__(BW_TPB, 2) void head_bwd_kernel(HeadBArgs a) {
 // of the head stage wrote (g_h_out = the node stage's g_up0), so the hand-over needs no grid-wide ordering -- only a
 // workgroup barrier before the node stage reuses the head stage's LDS.  Saves a launch, its ramp and its drain on
 // the backward's critical path (round 4: head_bwd alone was 10.4 us at davis_b64 for ~3 us of tile work).
-template <typename ST>
+template <typename ST, bool ONE = false>
 __global__ __launch_bounds__(BW_TPB, 2) void node_head_bwd_kernel(HeadBArgs hd, NodeBArgs a) {
   WALL_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  head_bwd_body<ST>(hd, lds);
+  head_bwd_body<ST, ONE>(hd, lds);
   __syncthreads();
-  node_bwd_body<ST>(a, lds);
+  node_bwd_body<ST, ONE>(a, lds);
 }
 
 // ===================================================================== conv
@@ -1166,9 +1174,10 @@ struct EmbBArgs {
 template <int NTN>
 constexpr int embed_bwd_lds_floats() { return BW_TPB + Image<NTN, 0>::EMB_SIZE + Image<NTN, 0>::TE_SIZE + BW_WPB * (EmbBlk<NTN>::SIZE + TSCR_FLOATS); }
 
-template <int NTN, typename ST>
+template <int NTN, typename ST, bool ONE = false>
 __device__ __forceinline__ void embed_bwd_body(const EmbBArgs& a, float* lds, int bid, int nblk) {
   typedef Image<NTN, 0> IM;
+  typedef AccFor<ONE> Acc;
   typedef QNode<NTN> Q;
   typedef EmbBlk<NTN> B;
   float* img = lds + BW_TPB;
@@ -1220,11 +1229,11 @@ __device__ __forceinline__ void embed_bwd_body(const EmbBArgs& a, float* lds, in
     }
     f4 dga[1], dbe[1];
     ln_quad_bwd<NS, NV>(img + IM::EMB_LN, lane, s_pre[0], v_pre[0], gs, gv, dga, dbe);
-    ln_param_grads<AccPriv, NS>(gblk + B::LN, first, lane, active, dga, dbe);
+    ln_param_grads<Acc, NS>(gblk + B::LN, first, lane, active, dga, dbe);
     float d_bs[Q::SSTEPS], d_bv[3][1];
     typename Q::Grads gr;
     Q::template backward<Io<ST>::BF>(imgT, lane, c[0], gs, gv, d_bs, d_bv, gr);
-    Q::template weight_grads<AccPriv, Io<ST>::BF>(gblk + B::GVP, first, lane, type[0], active, bs[0], bv[0], c[0], gr, tscr);
+    Q::template weight_grads<Acc, Io<ST>::BF>(gblk + B::GVP, first, lane, type[0], active, bs[0], bv[0], c[0], gr, tscr);
     if (active && a.g_x_s) {
 #pragma unroll
       for (int s = 0; s < Q::SSTEPS; ++s) {
@@ -1239,11 +1248,11 @@ __device__ __forceinline__ void embed_bwd_body(const EmbBArgs& a, float* lds, in
   }
   write_slab_row<B::SIZE, B::SIZE>(a.slab, blocks, bid);
 }
-template <int NTN, typename ST>
+template <int NTN, typename ST, bool ONE = false>
 __global__ __launch_bounds__(BW_TPB, 2) void embed_bwd_kernel(EmbBArgs a) {
   WALL_STAMP(4);
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  embed_bwd_body<NTN, ST>(a, lds, blockIdx.x, gridDim.x);
+  embed_bwd_body<NTN, ST, ONE>(a, lds, blockIdx.x, gridDim.x);
 }
 
 // dst[j] += sum_r slab[r][col0 + j], j < len.  A block owns 64 columns; its 16
@@ -1340,6 +1349,11 @@ inline int bwd_grid_cap(int64_t units) {
   constexpr int SMALL = BW_MAX_GRID - 8;
   return units <= (int64_t)SMALL * BW_WPB ? SMALL : BW_MAX_GRID;
 }
+// CGVP_BWD_STORE_ONCE=0 in the environment (read once) keeps the read-add-write accumulation at every size: A/B knob
+inline bool one_tile_per_wave(int64_t tiles, int grid) {
+  static const bool on = [] { const char* e = getenv("CGVP_BWD_STORE_ONCE"); return !(e && e[0] == '0'); }();
+  return on && tiles <= (int64_t)grid * BW_WPB;
+}
 inline int grid_for(int64_t tiles) {          // workgroups = slab rows; tiles go round-robin over them
   const int cap = bwd_grid_cap(tiles);
   return (int)(tiles < 1 ? 1 : (tiles > cap ? cap : tiles));
@@ -1422,6 +1436,12 @@ int node_update_bwd(const float* img_node, const float* imgT_node, const float* 
   const int G = grid_for((N + TILE - 1) / TILE);
   *grid = G;
   const size_t lds = (size_t)node_bwd_lds_floats() * sizeof(float);
+  if (one_tile_per_wave((N + TILE - 1) / TILE, G)) {
+#define K_(ST) node_bwd_kernel<ST, true>
+    BWD_LAUNCH_KIND(K_, G, BW_TPB, lds, a);
+#undef K_
+    return 0;
+  }
 #define K_(ST) node_bwd_kernel<ST>
   BWD_LAUNCH_KIND(K_, G, BW_TPB, lds, a);
 #undef K_
@@ -1439,6 +1459,12 @@ int node_head_bwd(const float* img_head, const float* imgT_head, const float* h_
   *grid = G;
   const int f = node_bwd_lds_floats() > head_bwd_lds_floats() ? node_bwd_lds_floats() : head_bwd_lds_floats();
   const size_t lds = (size_t)f * sizeof(float);
+  if (one_tile_per_wave((N + TILE - 1) / TILE, G)) {
+#define K_(ST) node_head_bwd_kernel<ST, true>
+    BWD_LAUNCH(K_, G, BW_TPB, lds, hd, a);
+#undef K_
+    return 0;
+  }
 #define K_(ST) node_head_bwd_kernel<ST>
   BWD_LAUNCH(K_, G, BW_TPB, lds, hd, a);
 #undef K_
@@ -1569,6 +1595,12 @@ int embed_bwd_impl(EmbBArgs& a, int* grid, int bf16, hipStream_t st) {
   const int G = grid_for((a.N + TILE - 1) / TILE);
   *grid = G;
   const size_t lds = (size_t)embed_bwd_lds_floats<NTN>() * sizeof(float);
+  if (one_tile_per_wave((a.N + TILE - 1) / TILE, G)) {
+#define K_(ST) embed_bwd_kernel<NTN, ST, true>
+    BWD_LAUNCH(K_, G, BW_TPB, lds, a);
+#undef K_
+    return 0;
+  }
 #define K_(ST) embed_bwd_kernel<NTN, ST>
   BWD_LAUNCH(K_, G, BW_TPB, lds, a);
 #undef K_
