@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/caster_gvp.h"
 
 namespace {
@@ -29,6 +31,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int WAVE = 64, TILE = 16, HD = 16, WPB = 4, TPB = WAVE * WPB;
 
 __device__ __forceinline__ f4 mfma(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// exp through v_exp_f32 (2^x of x * log2 e): one multiply and one transcendental instead of expf's range reduction
+// (~12 VALU); every argument here is <= 0 or a difference from a saved log-sum-exp, nowhere near overflow.
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float quad_max(float x) {
   x = fmaxf(x, __shfl_xor(x, 16));
   return fmaxf(x, __shfl_xor(x, 32));
@@ -100,14 +105,17 @@ __global__ __launch_bounds__(TPB) void attn_fwd_kernel(Args a) {
   if (u >= (int64_t)P.units_q * a.H) return;
   const int h = (int)(u % a.H), t = (int)(u / a.H);
   int b;
-  int64_t q0, q_end;
-  if (!locate(P.q_ptr, a.B, t, lane, b, q0, q_end)) return;
-  const int64_t k0 = P.k_ptr[b], k_end = P.k_ptr[b + 1];
-  const int64_t qr = q0 + n;
+  int64_t q0_, q_end_;
+  if (!locate(P.q_ptr, a.B, t, lane, b, q0_, q_end_)) return;
+  // rows and element offsets in 32 bits (the host checks rows x E < 2^31): a load is then base (SGPR pair) + one 32-bit
+  // VGPR offset instead of a 64-bit multiply-add chain per address
+  const int q0 = (int)q0_, q_end = (int)q_end_;
+  const int k0 = (int)P.k_ptr[b], k_end = (int)P.k_ptr[b + 1];
+  const int qr = q0 + n;
   const bool qv = qr < q_end;
-  const int E = a.E, col = h * HD;
+  const unsigned E = a.E, col = h * HD;
   f4 qs = {0.f, 0.f, 0.f, 0.f};
-  if (qv) qs = *reinterpret_cast<const f4*>(P.q + qr * E + col + 4 * g) * a.scale;
+  if (qv) qs = *reinterpret_cast<const f4*>(P.q + ((unsigned)qr * E + col + 4 * g)) * a.scale;
   f4 acc = {0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, l = 0.f;
   // The key-tile loop is a dependent chain (loads -> 4 MFMAs -> exp -> 4 MFMAs) and a pair's atoms attend to ~19 residue
@@ -117,49 +125,59 @@ __global__ __launch_bounds__(TPB) void attn_fwd_kernel(Args a) {
   //   V^T operand: lane (m = d, g), slot r <-> key kb + 4g + r
   // (loads are UNCONDITIONAL on rows clamped to the pair's last key and zeroed afterwards: with loads under lane masks
   // the compiler cannot count what is outstanding and waits for vmcnt(0), i.e. for the prefetch it has just issued)
-  const int64_t k_last = k_end - 1;
-  auto load_tile = [&](int64_t kb, f4& kk, float (&va)[4]) {
-    const int64_t kr = kb + n;
-    kk = *reinterpret_cast<const f4*>(P.k + (kr < k_end ? kr : k_last) * E + col + 4 * g);
-    if (kr >= k_end) kk = f4{0.f, 0.f, 0.f, 0.f};
+  // element offsets of the tile's five loads, advanced by 16 rows per call and clamped to the pair's last key with one
+  // 32-bit min each (offsets are monotone in the row)
+  const unsigned k_step = TILE * E;
+  const unsigned ko_last = (unsigned)(k_end - 1) * E + col + 4 * g, vo_last = (unsigned)(k_end - 1) * E + col + n;
+  unsigned ko = (unsigned)(k0 + n) * E + col + 4 * g;
+  unsigned vo[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) vo[r] = (unsigned)(k0 + 4 * g + r) * E + col + n;
+  // Rows past the pair's last key are never zeroed: the clamp makes them copies of the last key's (finite) row, the tail
+  // iteration sets their scores to -inf, and exp2(-inf) = 0 removes them from both sums.  Only the LAST tile of a pair can
+  // be partial, so the loop over full tiles carries no masks at all (peeled tail).
+  auto load_tile = [&](f4& kk, float (&va)[4]) {                   // the next 16 keys, call by call
+    kk = *reinterpret_cast<const f4*>(P.k + (ko < ko_last ? ko : ko_last));
+    ko += k_step;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int64_t key = kb + 4 * g + r;
-      const float x = P.v[(key < k_end ? key : k_last) * E + col + n];
-      va[r] = key < k_end ? x : 0.f;
+      va[r] = P.v[vo[r] < vo_last ? vo[r] : vo_last];
+      vo[r] += k_step;
     }
   };
   f4 kk_n = {0.f, 0.f, 0.f, 0.f};
   float va_n[4] = {0.f, 0.f, 0.f, 0.f};
-  if (k0 < k_end) load_tile(k0, kk_n, va_n);
-  for (int64_t kb = k0; kb < k_end; kb += TILE) {
+  if (k0 < k_end) load_tile(kk_n, va_n);
+  auto tile = [&](int kb, auto tail) {
     const f4 kk = kk_n;
     const float va[4] = {va_n[0], va_n[1], va_n[2], va_n[3]};
-    load_tile(kb + TILE, kk_n, va_n);                       // past the end: all-zero tile, never used
+    load_tile(kk_n, va_n);                                  // past the end: copies of the last key, never used
     f4 st = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4; ++s) st = mfma(kk[s], qs[s], st);
-    float mx = -INFINITY;
+    if constexpr (decltype(tail)::value) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (kb + 4 * g + r >= k_end) st[r] = -INFINITY;
-      mx = fmaxf(mx, st[r]);
+      for (int r = 0; r < 4; ++r)
+        if (kb + 4 * g + r >= k_end) st[r] = -INFINITY;
     }
-    const float m_new = fmaxf(m, quad_max(mx));
-    const float alpha = (m == -INFINITY) ? 0.f : expf(m - m_new);
+    const float m_new = fmaxf(m, quad_max(fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]))));   // finite: a tile holds a valid key
+    const float alpha = fexp(m - m_new);                    // m = -inf before the first tile: exp2(-inf) = 0
     float p[4], ps = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { p[r] = (st[r] == -INFINITY) ? 0.f : expf(st[r] - m_new); ps += p[r]; }
+    for (int r = 0; r < 4; ++r) { p[r] = fexp(st[r] - m_new); ps += p[r]; }
     l = l * alpha + quad_sum(ps);
     acc *= alpha;
     m = m_new;
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc = mfma(va[r], p[r], acc);
-  }
+  };
+  int kb = k0;
+  for (; kb + TILE <= k_end; kb += TILE) tile(kb, std::false_type{});
+  if (kb < k_end) tile(kb, std::true_type{});
   if (qv) {
     const float inv = l > 0.f ? 1.0f / l : 0.f;
-    *reinterpret_cast<f4*>(P.out + qr * E + col + 4 * g) = acc * inv;
-    if (g == 0 && P.lse) P.lse[qr * a.H + h] = (l > 0.f) ? m + logf(l) : -INFINITY;
+    *reinterpret_cast<f4*>(P.out + ((unsigned)qr * E + col + 4 * g)) = acc * inv;
+    if (g == 0 && P.lse) P.lse[(unsigned)qr * a.H + h] = (l > 0.f) ? m + logf(l) : -INFINITY;
   }
 }
 
@@ -175,57 +193,67 @@ __global__ __launch_bounds__(TPB) void attn_bwd_dq_kernel(Args a) {
   if (u >= (int64_t)P.units_q * a.H) return;
   const int h = (int)(u % a.H), t = (int)(u / a.H);
   int b;
-  int64_t q0, q_end;
-  if (!locate(P.q_ptr, a.B, t, lane, b, q0, q_end)) return;
-  const int64_t k0 = P.k_ptr[b], k_end = P.k_ptr[b + 1];
-  const int64_t qr = q0 + n;
+  int64_t q0_, q_end_;
+  if (!locate(P.q_ptr, a.B, t, lane, b, q0_, q_end_)) return;
+  const int q0 = (int)q0_, q_end = (int)q_end_;                 // 32-bit rows / offsets, see attn_fwd_kernel
+  const int k0 = (int)P.k_ptr[b], k_end = (int)P.k_ptr[b + 1];
+  const int qr = q0 + n;
   const bool qv = qr < q_end;
-  const int E = a.E, col = h * HD;
+  const unsigned E = a.E, col = h * HD;
   f4 qs = {0.f, 0.f, 0.f, 0.f}, go = {0.f, 0.f, 0.f, 0.f};
   float lse = 0.f, dl = 0.f;
   if (qv) {
-    qs = *reinterpret_cast<const f4*>(P.q + qr * E + col + 4 * g) * a.scale;
-    go = *reinterpret_cast<const f4*>(P.g_out + qr * E + col + 4 * g);
-    const f4 o = *reinterpret_cast<const f4*>(P.out + qr * E + col + 4 * g);
-    lse = P.lse[qr * a.H + h];
+    const unsigned qo = (unsigned)qr * E + col + 4 * g;
+    qs = *reinterpret_cast<const f4*>(P.q + qo) * a.scale;
+    go = *reinterpret_cast<const f4*>(P.g_out + qo);
+    const f4 o = *reinterpret_cast<const f4*>(P.out + qo);
+    lse = P.lse[(unsigned)qr * a.H + h];
     dl = go[0] * o[0] + go[1] * o[1] + go[2] * o[2] + go[3] * o[3];
   }
   dl = quad_sum(dl);
-  if (qv && g == 0) P.delta[qr * a.H + h] = dl;
+  if (qv && g == 0) P.delta[(unsigned)qr * a.H + h] = dl;
   f4 acc = {0.f, 0.f, 0.f, 0.f};
   // next key tile prefetched while the current one is computed (see attn_fwd_kernel)
   //   ka: K^T operand for d Qs: lane (m = d, g), slot r <-> key kb + 4g + r
-  const int64_t k_last = k_end - 1;
-  auto load_tile = [&](int64_t kb, f4& kk, f4& vv, float (&ka)[4]) {
-    const int64_t kr = kb + n, krc = kr < k_end ? kr : k_last;
-    kk = *reinterpret_cast<const f4*>(P.k + krc * E + col + 4 * g);
-    vv = *reinterpret_cast<const f4*>(P.v + krc * E + col + 4 * g);
-    if (kr >= k_end) { kk = f4{0.f, 0.f, 0.f, 0.f}; vv = f4{0.f, 0.f, 0.f, 0.f}; }
+  const unsigned k_step = TILE * E;                                // offsets advanced per call and clamped, see attn_fwd_kernel
+  const unsigned ko_last = (unsigned)(k_end - 1) * E + col + 4 * g, to_last = (unsigned)(k_end - 1) * E + col + n;
+  unsigned ko = (unsigned)(k0 + n) * E + col + 4 * g;
+  unsigned to[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) to[r] = (unsigned)(k0 + 4 * g + r) * E + col + n;
+  auto load_tile = [&](f4& kk, f4& vv, float (&ka)[4]) {           // the next 16 keys; no zeroing, tail peeled (attn_fwd_kernel)
+    const unsigned o = ko < ko_last ? ko : ko_last;
+    kk = *reinterpret_cast<const f4*>(P.k + o);
+    vv = *reinterpret_cast<const f4*>(P.v + o);
+    ko += k_step;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int64_t key = kb + 4 * g + r;
-      const float x = P.k[(key < k_end ? key : k_last) * E + col + n];
-      ka[r] = key < k_end ? x : 0.f;
+      ka[r] = P.k[to[r] < to_last ? to[r] : to_last];
+      to[r] += k_step;
     }
   };
   f4 kk_n = {0.f, 0.f, 0.f, 0.f}, vv_n = {0.f, 0.f, 0.f, 0.f};
   float ka_n[4] = {0.f, 0.f, 0.f, 0.f};
-  if (k0 < k_end) load_tile(k0, kk_n, vv_n, ka_n);
-  for (int64_t kb = k0; kb < k_end; kb += TILE) {
+  if (k0 < k_end) load_tile(kk_n, vv_n, ka_n);
+  auto tile = [&](int kb, auto tail) {
     const f4 kk = kk_n, vv = vv_n;
     const float ka[4] = {ka_n[0], ka_n[1], ka_n[2], ka_n[3]};
-    load_tile(kb + TILE, kk_n, vv_n, ka_n);
+    load_tile(kk_n, vv_n, ka_n);
     f4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4; ++s) { st = mfma(kk[s], qs[s], st); dp = mfma(vv[s], go[s], dp); }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const bool kv = kb + 4 * g + r < k_end;
-      const float p = (kv && qv) ? expf(st[r] - lse) : 0.f;
-      acc = mfma(ka[r], p * (dp[r] - dl), acc);
+      // (a lane without a query computes a finite column that is never stored; keys past the pair's end only in the tail)
+      float pr = fexp(st[r] - lse);
+      if constexpr (decltype(tail)::value) pr = kb + 4 * g + r < k_end ? pr : 0.f;
+      acc = mfma(ka[r], pr * (dp[r] - dl), acc);
     }
-  }
-  if (qv) *reinterpret_cast<f4*>(P.g_q + qr * E + col + 4 * g) = acc * a.scale;
+  };
+  int kb = k0;
+  for (; kb + TILE <= k_end; kb += TILE) tile(kb, std::false_type{});
+  if (kb < k_end) tile(kb, std::true_type{});
+  if (qv) *reinterpret_cast<f4*>(P.g_q + ((unsigned)qr * E + col + 4 * g)) = acc * a.scale;
 }
 
 // ------------------------------------------------------------------------------------------------ backward: d K, d V
@@ -244,42 +272,48 @@ __global__ __launch_bounds__(TPB) void attn_bwd_dkv_kernel(Args a) {
   if (u >= (int64_t)P.units_k * a.H) return;
   const int h = (int)(u % a.H), t = (int)(u / a.H);
   int b;
-  int64_t kt0, k_end;
-  if (!locate(P.k_ptr, a.B, t, lane, b, kt0, k_end)) return;
-  const int64_t q0 = P.q_ptr[b], q_end = P.q_ptr[b + 1];
-  const int64_t kr = kt0 + n;
+  int64_t kt0_, k_end_;
+  if (!locate(P.k_ptr, a.B, t, lane, b, kt0_, k_end_)) return;
+  const int kt0 = (int)kt0_, k_end = (int)k_end_;               // 32-bit rows / offsets, see attn_fwd_kernel
+  const int q0 = (int)P.q_ptr[b], q_end = (int)P.q_ptr[b + 1];
+  const int kr = kt0 + n;
   const bool kv = kr < k_end;
-  const int E = a.E, col = h * HD;
+  const unsigned E = a.E, col = h * HD, H = a.H;
   f4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
   if (kv) {
-    kk = *reinterpret_cast<const f4*>(P.k + kr * E + col + 4 * g);
-    vv = *reinterpret_cast<const f4*>(P.v + kr * E + col + 4 * g);
+    kk = *reinterpret_cast<const f4*>(P.k + ((unsigned)kr * E + col + 4 * g));
+    vv = *reinterpret_cast<const f4*>(P.v + ((unsigned)kr * E + col + 4 * g));
   }
   f4 accv = {0.f, 0.f, 0.f, 0.f}, acck = {0.f, 0.f, 0.f, 0.f};
   // next query tile prefetched while the current one is computed (an atom-key tile loops over ~19 residue tiles)
   struct QT { f4 qa, ga; float lse[4], dl[4], qt[4], gt[4]; };
-  const int64_t q_last = q_end - 1;
-  auto load_tile = [&](int64_t qb, QT& T) {
-    const int64_t qm = qb + n, qmc = qm < q_end ? qm : q_last;     // this lane's row as the M index of the two score products
-    T.qa = *reinterpret_cast<const f4*>(P.q + qmc * E + col + 4 * g) * a.scale;
-    T.ga = *reinterpret_cast<const f4*>(P.g_out + qmc * E + col + 4 * g);
-    if (qm >= q_end) { T.qa = f4{0.f, 0.f, 0.f, 0.f}; T.ga = f4{0.f, 0.f, 0.f, 0.f}; }
+  const unsigned q_step = TILE * E, h_step = TILE * H;              // offsets advanced per call and clamped, see attn_fwd_kernel
+  const unsigned qo_last = (unsigned)(q_end - 1) * E + col + 4 * g, to_last = (unsigned)(q_end - 1) * E + col + n,
+                 ho_last = (unsigned)(q_end - 1) * H + h;
+  unsigned qo = (unsigned)(q0 + n) * E + col + 4 * g;
+  unsigned to[4], ho[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { to[r] = (unsigned)(q0 + 4 * g + r) * E + col + n; ho[r] = (unsigned)(q0 + 4 * g + r) * H + h; }
+  auto load_tile = [&](QT& T) {                                     // the next 16 queries; no zeroing, tail peeled (attn_fwd_kernel)
+    const unsigned qmo = qo < qo_last ? qo : qo_last;               // this lane's row as the M index of the two score products
+    T.qa = *reinterpret_cast<const f4*>(P.q + qmo) * a.scale;
+    T.ga = *reinterpret_cast<const f4*>(P.g_out + qmo);
+    qo += q_step;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {                           // per k-slot r <-> query qb + 4g + r
-      const int64_t q = qb + 4 * g + r, qc = q < q_end ? q : q_last;
-      const bool ok = q < q_end;
-      const float x0 = P.lse[qc * a.H + h], x1 = P.delta[qc * a.H + h], x2 = P.q[qc * E + col + n], x3 = P.g_out[qc * E + col + n];
-      T.lse[r] = ok ? x0 : 0.f;
-      T.dl[r] = ok ? x1 : 0.f;
-      T.qt[r] = ok ? x2 * a.scale : 0.f;                    // Qs^T operand: lane (m = d, g)
-      T.gt[r] = ok ? x3 : 0.f;                              // dO^T operand
+      const unsigned tc = to[r] < to_last ? to[r] : to_last, hc = ho[r] < ho_last ? ho[r] : ho_last;
+      to[r] += q_step; ho[r] += h_step;
+      T.lse[r] = P.lse[hc];
+      T.dl[r] = P.delta[hc];
+      T.qt[r] = P.q[tc] * a.scale;                          // Qs^T operand: lane (m = d, g)
+      T.gt[r] = P.g_out[tc];                                // dO^T operand
     }
   };
   QT nxt = {};
-  if (q0 < q_end) load_tile(q0, nxt);
-  for (int64_t qb = q0; qb < q_end; qb += TILE) {
+  if (q0 < q_end) load_tile(nxt);
+  auto tile = [&](int qb, auto tail) {
     const QT cur = nxt;
-    load_tile(qb + TILE, nxt);
+    load_tile(nxt);
     const f4 qa = cur.qa, ga = cur.ga;
     const float (&lse)[4] = cur.lse, (&dl)[4] = cur.dl, (&qt)[4] = cur.qt, (&gt)[4] = cur.gt;
     f4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -287,15 +321,19 @@ __global__ __launch_bounds__(TPB) void attn_bwd_dkv_kernel(Args a) {
     for (int x = 0; x < 4; ++x) { s = mfma(qa[x], kk[x], s); dp = mfma(ga[x], vv[x], dp); }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const bool ok = kv && (qb + 4 * g + r < q_end);
-      const float p = ok ? expf(s[r] - lse[r]) : 0.f;
-      accv = mfma(gt[r], p, accv);
-      acck = mfma(qt[r], p * (dp[r] - dl[r]), acck);
+      // (a lane without a key computes a finite column that is never stored; queries past the pair's end only in the tail)
+      float pr = fexp(s[r] - lse[r]);
+      if constexpr (decltype(tail)::value) pr = qb + 4 * g + r < q_end ? pr : 0.f;
+      accv = mfma(gt[r], pr, accv);
+      acck = mfma(qt[r], pr * (dp[r] - dl[r]), acck);
     }
-  }
+  };
+  int qb = q0;
+  for (; qb + TILE <= q_end; qb += TILE) tile(qb, std::false_type{});
+  if (qb < q_end) tile(qb, std::true_type{});
   if (kv) {
-    *reinterpret_cast<f4*>(P.g_v + kr * E + col + 4 * g) = accv;
-    *reinterpret_cast<f4*>(P.g_k + kr * E + col + 4 * g) = acck;
+    *reinterpret_cast<f4*>(P.g_v + ((unsigned)kr * E + col + 4 * g)) = accv;
+    *reinterpret_cast<f4*>(P.g_k + ((unsigned)kr * E + col + 4 * g)) = acck;
   }
 }
 
@@ -332,7 +370,7 @@ __global__ __launch_bounds__(TPB) void attn_weights_kernel(Args a) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) st = mfma(kk[s], qs[s], st);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) w[r] += (qv && kb + 4 * g + r < k_end) ? expf(st[r] - lse) * invh : 0.f;
+      for (int r = 0; r < 4; ++r) w[r] += (qv && kb + 4 * g + r < k_end) ? fexp(st[r] - lse) * invh : 0.f;
     }
     if (qv) {
       float* row = P.w + ((int64_t)b * P.w_lq + (qr - qbase)) * P.w_lk + (kb - k0) + 4 * g;
@@ -348,15 +386,23 @@ int status() {
   return e == hipSuccess ? 0 : (int)e;
 }
 
-int fill(Args& a, const cgvp_attn_problem* probs, int nprob, int64_t B, int H) {
+// `long_first`: which of two problems gets the low workgroup indices -- the one whose waves loop longest (1: over the
+// keys, the forward and d Q kernels; 2: over the queries, the d K / d V kernel).  Workgroups start in index order: with
+// the residues -> atoms direction first, its 10k three-tile waves filled the chip and the 1.8k nineteen-tile waves of the
+// other direction started last and ran alone at the end of the launch.
+int fill(Args& a, const cgvp_attn_problem* probs, int nprob, int64_t B, int H, int long_first = 0) {
   if (!probs || nprob < 1 || nprob > 2 || B < 0 || H < 1) return CGVP_ERR_BAD_ARG;
   a.nprob = nprob; a.B = (int)B; a.H = H; a.E = H * HD;
+  const bool swap = nprob == 2 && ((long_first == 1 && probs[1].num_k > probs[0].num_k) ||
+                                   (long_first == 2 && probs[1].num_q > probs[0].num_q));
   for (int i = 0; i < 2; ++i) {
     Prob& p = a.p[i];
     p = Prob{};
     if (i >= nprob) continue;
-    const cgvp_attn_problem& s = probs[i];
+    const cgvp_attn_problem& s = probs[swap ? 1 - i : i];
     if (s.num_q < 0 || s.num_k < 0 || !s.q_ptr || !s.k_ptr) return CGVP_ERR_BAD_ARG;
+    if ((s.num_q + TILE) * (int64_t)(H * HD) >= ((int64_t)1 << 31) || (s.num_k + TILE) * (int64_t)(H * HD) >= ((int64_t)1 << 31))
+      return CGVP_ERR_BAD_ARG;                             // the kernels address rows with 32-bit element offsets
     if (s.num_q > 0 && (!s.q || !s.out || !s.lse)) return CGVP_ERR_BAD_ARG;
     if (s.num_k > 0 && (!s.k || !s.v)) return CGVP_ERR_BAD_ARG;
     const void* al[] = {s.q, s.k, s.v, s.out, s.g_out, s.g_q, s.g_k, s.g_v};
@@ -377,7 +423,7 @@ extern "C" {
 int cgvp_attn_fwd(const cgvp_attn_problem* probs, int32_t num_problems, int64_t num_pairs, int32_t heads, float scale,
                   void* stream) {
   Args a;
-  if (int rc = fill(a, probs, num_problems, num_pairs, heads)) return rc;
+  if (int rc = fill(a, probs, num_problems, num_pairs, heads, 1)) return rc;
   a.scale = scale;
   if (num_pairs == 0) return 0;
   const int64_t units = ((int64_t)a.p[0].units_q + a.p[1].units_q) * heads;
@@ -400,9 +446,10 @@ int cgvp_attn_weights(const cgvp_attn_problem* probs, int32_t num_problems, int6
 
 int cgvp_attn_bwd(const cgvp_attn_problem* probs, int32_t num_problems, int64_t num_pairs, int32_t heads, float scale,
                   void* stream) {
-  Args a;
-  if (int rc = fill(a, probs, num_problems, num_pairs, heads)) return rc;
-  a.scale = scale;
+  Args a, ak;
+  if (int rc = fill(a, probs, num_problems, num_pairs, heads, 1)) return rc;
+  if (int rc = fill(ak, probs, num_problems, num_pairs, heads, 2)) return rc;
+  a.scale = ak.scale = scale;
   for (int i = 0; i < num_problems; ++i) {
     const cgvp_attn_problem& s = probs[i];
     if ((s.num_q > 0 && (!s.g_out || !s.g_q || !s.delta)) || (s.num_k > 0 && (!s.g_k || !s.g_v))) return CGVP_ERR_BAD_ARG;
@@ -411,7 +458,7 @@ int cgvp_attn_bwd(const cgvp_attn_problem* probs, int32_t num_problems, int64_t 
   const int64_t uq = ((int64_t)a.p[0].units_q + a.p[1].units_q) * heads;
   const int64_t uk = ((int64_t)a.p[0].units_k + a.p[1].units_k) * heads;
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)((uq + WPB - 1) / WPB)), dim3(TPB), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)((uk + WPB - 1) / WPB)), dim3(TPB), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)((uk + WPB - 1) / WPB)), dim3(TPB), 0, (hipStream_t)stream, ak);
   return status();
 }
 
