@@ -754,10 +754,13 @@ def joint_epoch(args, model, dev, batches, B, steps):
     loss_fn = torch.nn.functional.mse_loss
     dicts = [(dict(b[0], ptr=b[4]), dict(b[1], ptr=b[5])) for b in batches]
 
+    leaves = [p for p in model.parameters()]
+
     def eager(pd, md):
         pred, _ = model(pd, md)
         loss_fn(pred, target).backward()
-        model.zero_grad(set_to_none=True)
+        for p in leaves:                  # what optimizer.zero_grad(set_to_none=True) does (train_model.py:566); nn.Module.zero_grad
+            p.grad = None                 # walks the module tree instead: 0.8 ms of Python per step for this model
 
     out = {}
     with torch.enable_grad():
@@ -770,7 +773,7 @@ def joint_epoch(args, model, dev, batches, B, steps):
                 eager(pd, md)
 
         t_a, t_i, jp = _timed_passes(run_eager, steps)
-        out["eager"] = {"what": "model(pdata, mdata) -> mse_loss -> loss.backward() -> zero_grad(), every step a different batch; "
+        out["eager"] = {"what": "model(pdata, mdata) -> mse_loss -> loss.backward() -> gradient reset as optimizer.zero_grad() does it, every step a different batch; "
                                 "median of the timed passes", "passes_ms": jp,
                         "ms_per_step": round(t_a / steps * 1e3, 4), "host_issue_ms_per_step": round(t_i / steps * 1e3, 4),
                         "pairs_per_s": round(B * steps / t_a, 1)}

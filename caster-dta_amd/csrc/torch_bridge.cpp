@@ -583,6 +583,159 @@ std::tuple<at::Tensor, at::Tensor> gine_encoder(std::vector<at::Tensor> params_i
   return {out, ws};
 }
 
+// =================================================================================== the joint head's row-wise ops
+// The same entry points gvp_hip/head_ops.py reaches through torch.library custom ops (which stay the path torch.compile
+// traces), as C++ autograd functions for the EAGER loop: a Python custom op costs 60-70 us of host time per call each
+// way (dispatcher -> Python -> ctypes, a Python autograd.Function around it), the head makes ~35 such calls per step
+// and an eager whole-model step was host-bound at 4.3-5.3 ms for 1.6 ms of device work (tools/host_profile_joint.py).
+// No arithmetic here: shapes, allocation from the caching allocator, one C call each.
+using torch::autograd::AutogradContext;
+using torch::autograd::Function;
+
+at::Tensor rows_f32(const at::Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kFloat, name, ": expected an fp32 tensor on the GPU");
+  return t.is_contiguous() ? t : t.contiguous();
+}
+inline cgvp_rng rng_of(const at::Tensor& pair, double p, int64_t site) {
+  return cgvp_rng{reinterpret_cast<const uint64_t*>(pair.data_ptr()), (float)p, (int32_t)site};
+}
+inline void rows_dim(const at::Tensor& t, int64_t* R, int32_t* D) {
+  *D = (int32_t)t.size(-1);
+  *R = t.numel() / (*D > 0 ? *D : 1);
+}
+
+at::Tensor head_rng_next(at::Tensor state) {
+  at::Tensor out = at::empty({2}, state.options());
+  check(cgvp_rng_next(reinterpret_cast<uint64_t*>(state.data_ptr()), reinterpret_cast<uint64_t*>(out.data_ptr()),
+                      current_stream(state)), "cgvp_rng_next");
+  return out;
+}
+
+// dropout_p(LeakyReLU_slope(t)); slope 0 = ReLU   (joint_gnn.py:188-198, :388)
+struct ActDropout : public Function<ActDropout> {
+  static at::Tensor forward(AutogradContext* ctx, at::Tensor t_in, at::Tensor pair, int64_t site, double p, double slope) {
+    at::Tensor t = rows_f32(t_in, "act_dropout");
+    int64_t R; int32_t D;
+    rows_dim(t, &R, &D);
+    at::Tensor y = at::empty_like(t);
+    const cgvp_rng rng = rng_of(pair, p, site);
+    check(cgvp_act_dropout_fwd((const float*)t.data_ptr(), p > 0 ? &rng : nullptr, (float)slope, R, D, (float*)y.data_ptr(),
+                               current_stream(t)), "cgvp_act_dropout_fwd");
+    ctx->save_for_backward({y, pair});
+    ctx->saved_data["site"] = site; ctx->saved_data["p"] = p; ctx->saved_data["slope"] = slope;
+    return y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list go) {
+    auto saved = ctx->get_saved_variables();
+    at::Tensor g = rows_f32(go[0], "act_dropout backward");
+    const at::Tensor &y = saved[0], &pair = saved[1];
+    const double p = ctx->saved_data["p"].toDouble();
+    int64_t R; int32_t D;
+    rows_dim(g, &R, &D);
+    at::Tensor gt = at::empty_like(g);
+    const cgvp_rng rng = rng_of(pair, p, ctx->saved_data["site"].toInt());
+    check(cgvp_act_dropout_bwd((const float*)g.data_ptr(), (const float*)y.data_ptr(), p > 0 ? &rng : nullptr,
+                               (float)ctx->saved_data["slope"].toDouble(), R, D, (float*)gt.data_ptr(), current_stream(g)),
+          "cgvp_act_dropout_bwd");
+    return {gt, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+  }
+};
+
+// x + dropout_p(a)   (x undefined: dropout_p(a) alone)
+struct DropoutAdd : public Function<DropoutAdd> {
+  static at::Tensor forward(AutogradContext* ctx, at::Tensor a_in, at::Tensor x_in, at::Tensor pair, int64_t site, double p) {
+    at::Tensor a = rows_f32(a_in, "dropout_add");
+    const bool has_x = x_in.defined() && x_in.numel() > 0;
+    at::Tensor x = has_x ? rows_f32(x_in, "dropout_add") : at::Tensor();
+    int64_t R; int32_t D;
+    rows_dim(a, &R, &D);
+    at::Tensor y = at::empty_like(a);
+    const cgvp_rng rng = rng_of(pair, p, site);
+    check(cgvp_dropout_add((const float*)a.data_ptr(), has_x ? (const float*)x.data_ptr() : nullptr, p > 0 ? &rng : nullptr, R, D,
+                           (float*)y.data_ptr(), current_stream(a)), "cgvp_dropout_add");
+    ctx->save_for_backward({pair});
+    ctx->saved_data["site"] = site; ctx->saved_data["p"] = p; ctx->saved_data["has_x"] = has_x;
+    return y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list go) {
+    const at::Tensor pair = ctx->get_saved_variables()[0];
+    at::Tensor g = rows_f32(go[0], "dropout_add backward");
+    at::Tensor ga;
+    if (ctx->needs_input_grad(0)) {
+      const double p = ctx->saved_data["p"].toDouble();
+      int64_t R; int32_t D;
+      rows_dim(g, &R, &D);
+      ga = at::empty_like(g);
+      const cgvp_rng rng = rng_of(pair, p, ctx->saved_data["site"].toInt());
+      check(cgvp_dropout_scale((const float*)g.data_ptr(), p > 0 ? &rng : nullptr, R, D, (float*)ga.data_ptr(), current_stream(g)),
+            "cgvp_dropout_scale");
+    }
+    return {ga, (ctx->saved_data["has_x"].toBool() && ctx->needs_input_grad(1)) ? g : at::Tensor(), at::Tensor(), at::Tensor(),
+            at::Tensor()};
+  }
+};
+
+// nn.LayerNorm over the last dim of compact rows [R, D]   (joint_gnn.py:376-389)
+struct RowLayerNorm : public Function<RowLayerNorm> {
+  static at::Tensor forward(AutogradContext* ctx, at::Tensor x_in, at::Tensor w, at::Tensor b, double eps) {
+    at::Tensor x = rows_f32(x_in, "layer_norm");
+    const int64_t R = x.size(0);
+    const int32_t D = (int32_t)x.size(1);
+    at::Tensor y = at::empty_like(x), mean = at::empty({R}, x.options()), rstd = at::empty({R}, x.options());
+    check(cgvp_layer_norm_fwd((const float*)x.data_ptr(), (const float*)w.data_ptr(), (const float*)b.data_ptr(), R, D, (float)eps,
+                              (float*)y.data_ptr(), (float*)mean.data_ptr(), (float*)rstd.data_ptr(), current_stream(x)),
+          "cgvp_layer_norm_fwd");
+    ctx->save_for_backward({x, mean, rstd, w});
+    return y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list go) {
+    auto sv = ctx->get_saved_variables();
+    const at::Tensor &x = sv[0], &mean = sv[1], &rstd = sv[2], &w = sv[3];
+    at::Tensor gy = rows_f32(go[0], "layer_norm backward");
+    const int64_t R = x.size(0);
+    const int32_t D = (int32_t)x.size(1);
+    const int64_t n = cgvp_layer_norm_bwd_workspace_floats(R, D);
+    if (n < 0) check((int)n, "cgvp_layer_norm_bwd_workspace_floats");
+    at::Tensor ws = at::empty({n > 0 ? n : 1}, x.options()), gx = at::empty_like(x), gwb = at::empty({2 * (int64_t)D}, x.options());
+    check(cgvp_layer_norm_bwd((const float*)gy.data_ptr(), (const float*)x.data_ptr(), (const float*)mean.data_ptr(),
+                              (const float*)rstd.data_ptr(), (const float*)w.data_ptr(), R, D, (float*)gx.data_ptr(),
+                              (float*)ws.data_ptr(), (float*)gwb.data_ptr(), current_stream(x)), "cgvp_layer_norm_bwd");
+    return {gx, gwb.narrow(0, 0, D), gwb.narrow(0, D, D), at::Tensor()};
+  }
+};
+
+// F.linear whose weight / bias gradients come from the split-row kernel   (joint_gnn.py:188-198, :376-389)
+struct FastLinear : public Function<FastLinear> {
+  static at::Tensor forward(AutogradContext* ctx, at::Tensor x, at::Tensor w, at::Tensor b) {
+    ctx->save_for_backward({x, w});
+    return at::linear(x, w, b);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list go) {
+    auto sv = ctx->get_saved_variables();
+    const at::Tensor &x = sv[0], &w = sv[1];
+    at::Tensor gy = rows_f32(go[0], "linear backward");
+    at::Tensor gx = ctx->needs_input_grad(0) ? at::matmul(gy, w) : at::Tensor();
+    const int64_t R = x.size(0);
+    const int32_t I = (int32_t)w.size(1), O = (int32_t)w.size(0);
+    const int64_t n = cgvp_linear_wgrad_workspace_floats(R, I, O);
+    if (n < 0) check((int)n, "cgvp_linear_wgrad_workspace_floats");
+    at::Tensor xs = rows_f32(x, "linear backward");
+    at::Tensor ws = at::empty({n > 0 ? n : 1}, gy.options()), flat = at::empty({(int64_t)O * I + O}, gy.options());
+    check(cgvp_linear_wgrad((const float*)xs.data_ptr(), (const float*)gy.data_ptr(), R, I, O, (float*)ws.data_ptr(),
+                            (float*)flat.data_ptr(), current_stream(gy)), "cgvp_linear_wgrad");
+    return {gx, flat.narrow(0, 0, (int64_t)O * I).view({O, I}), flat.narrow(0, (int64_t)O * I, O)};
+  }
+};
+
+at::Tensor head_act_dropout(at::Tensor t, at::Tensor pair, int64_t site, double p, double slope) {
+  return ActDropout::apply(t, pair, site, p, slope);
+}
+at::Tensor head_dropout_add(at::Tensor a, c10::optional<at::Tensor> x, at::Tensor pair, int64_t site, double p) {
+  return DropoutAdd::apply(a, x ? *x : at::Tensor(), pair, site, p);
+}
+at::Tensor head_layer_norm(at::Tensor x, at::Tensor w, at::Tensor b, double eps) { return RowLayerNorm::apply(x, w, b, eps); }
+at::Tensor head_linear(at::Tensor x, at::Tensor w, at::Tensor b) { return FastLinear::apply(x, w, b); }
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -593,6 +746,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "eager fast path of caster-dta_amd: C++ autograd nodes over the whole-pass C ABI of libcaster_gvp.so";
   m.def("lba_encoder", &lba_encoder, "VectorProteinGNN_LBAModel.forward (protein_gnn.py:361-388) with autograd");
   m.def("gine_encoder", &gine_encoder, "HomoMoleculeGNN_GINE.forward (molecule_gnn.py:254-268) with autograd");
+  // the joint head's row-wise ops (gvp_hip/head_ops.py uses them in eager mode, the torch.library ops under torch.compile)
+  m.def("head_rng_next", &head_rng_next, "advance the persistent {seed, offset} state, return this step's pair");
+  m.def("head_act_dropout", &head_act_dropout, "dropout_p(LeakyReLU_slope(t)) with autograd");
+  m.def("head_dropout_add", &head_dropout_add, "x + dropout_p(a) with autograd (x may be None)");
+  m.def("head_layer_norm", &head_layer_norm, "row-wise LayerNorm with autograd");
+  m.def("head_linear", &head_linear, "F.linear with the split-row weight / bias gradient kernel");
   // the version of include/caster_gvp.h this bridge was COMPILED against (struct layouts, argument lists); the library
   // loaded at run time reports its own through cgvp_abi_version(): _lib.bridge() requires all three to agree
   m.def("abi_version", []() { return (int)CGVP_ABI_VERSION; });

@@ -68,9 +68,22 @@ class _FastLinear(torch.autograd.Function):
         return gx, flat[:O * I].view(O, I), flat[O * I:]
 
 
+def _bridge():
+    """The C++ eager fast path (csrc/torch_bridge.cpp: the same C entry points behind C++ autograd functions, ~60 us of
+    host time less per call and direction than a torch.library op), or None: under torch.compile (Dynamo traces the
+    custom ops), with `CGVP_BRIDGE=0`, or when the extension is not built."""
+    if torch.compiler.is_compiling() or not hasattr(_lib, "bridge"):
+        return None
+    br = _lib.bridge()
+    return br if (br is not None and hasattr(br, "head_linear")) else None
+
+
 def fast_linear(x, weight, bias):
     """F.linear(x, weight, bias) whose weight / bias gradients come from the split-row kernel when the shape qualifies."""
     if supported(x, weight, bias):
+        br = _bridge()
+        if br is not None:
+            return br.head_linear(x, weight, bias)
         return _FastLinear.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
 
@@ -152,6 +165,9 @@ def fast_layer_norm(x, norm):
             and norm.elementwise_affine and norm.bias is not None and len(norm.normalized_shape) == 1
             and norm.normalized_shape[0] == x.shape[1] and x.shape[1] in (64, 128, 256, 512)
             and norm.weight.dtype == torch.float32 and x.shape[0] >= LN_MIN_ROWS):
+        br = _bridge()
+        if br is not None and not torch.is_autocast_enabled("cuda"):
+            return br.head_layer_norm(x, norm.weight, norm.bias, float(norm.eps))
         return torch.ops.caster_gvp.layer_norm(x, norm.weight, norm.bias, float(norm.eps))[0]
     return norm(x)
 
@@ -311,7 +327,13 @@ class DropSites:
                            and not torch.compiler.is_compiling() and not torch.is_autocast_enabled("cuda")
                            and torch.is_grad_enabled())
         self.site = 0
-        self.pair = torch.ops.caster_gvp.rng_next(_head_rng_state(rows.device)) if self.active else None
+        self._br = _bridge() if self.active else None
+        if not self.active:
+            self.pair = None
+        elif self._br is not None:
+            self.pair = self._br.head_rng_next(_head_rng_state(rows.device))
+        else:
+            self.pair = torch.ops.caster_gvp.rng_next(_head_rng_state(rows.device))
         self._none = rows.new_empty(0) if self.active else None
 
     def _ok(self, t):
@@ -325,6 +347,8 @@ class DropSites:
     def dropout_add(self, x, a, dropout):
         """x + dropout(a)."""
         if self._ok(a) and self._ok(x) and abs(dropout.p - self.p) < 1e-12:
+            if self._br is not None:
+                return self._br.head_dropout_add(a, x, self.pair, self._next(), self.p)
             return torch.ops.caster_gvp.dropout_add(a, x, self.pair, self._next(), self.p)
         return x + dropout(a)
 
@@ -332,6 +356,8 @@ class DropSites:
         """dropout(activation(t)) for ReLU / LeakyReLU activations."""
         slope = _slope(activation)
         if slope is not None and self._ok(t) and abs(dropout.p - self.p) < 1e-12:
+            if self._br is not None:
+                return self._br.head_act_dropout(t, self.pair, self._next(), self.p, slope)
             return torch.ops.caster_gvp.act_dropout(t, self.pair, self._next(), self.p, slope)
         return dropout(activation(t))
 

@@ -39,3 +39,34 @@ torch.cuda.synchronize()
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
 print(s.getvalue()[:9000])
+
+# ---- the TRAINING step on the host: forward, mse loss, backward(), zero_grad -- what train_model.py:548-587 issues
+model.train()
+target = torch.randn(64, 1, device=dev)
+
+
+def train_step():
+    pred, _ = model(pd, md)
+    torch.nn.functional.mse_loss(pred, target).backward()
+    model.zero_grad(set_to_none=True)
+
+
+with torch.enable_grad():
+    for _ in range(5):
+        train_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        train_step()
+    ti = (time.perf_counter() - t0) / 20 * 1e3
+    torch.cuda.synchronize()
+    print(f"TRAIN step: host issue {ti:.3f} ms/step")
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(10):
+        train_step()
+    pr.disable()
+    torch.cuda.synchronize()
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40)
+    print(s.getvalue()[:7000])
