@@ -727,6 +727,68 @@ struct FastLinear : public Function<FastLinear> {
   }
 };
 
+// The varlen cross-attention core, both directions in one launch (gvp_hip/attention_ops.py caster_gvp::cross_attention)
+struct CrossAttention : public Function<CrossAttention> {
+  static void fill(cgvp_attn_problem* P, const at::Tensor& q_r, const at::Tensor& k_a, const at::Tensor& v_a, const at::Tensor& q_a,
+                   const at::Tensor& k_r, const at::Tensor& v_r, const at::Tensor& rptr, const at::Tensor& aptr) {
+    P[0] = cgvp_attn_problem{};
+    P[1] = cgvp_attn_problem{};
+    P[0].q = (const float*)q_r.data_ptr(); P[0].k = (const float*)k_a.data_ptr(); P[0].v = (const float*)v_a.data_ptr();
+    P[0].q_ptr = (const int64_t*)rptr.data_ptr(); P[0].k_ptr = (const int64_t*)aptr.data_ptr();
+    P[0].num_q = q_r.size(0); P[0].num_k = k_a.size(0);
+    P[1].q = (const float*)q_a.data_ptr(); P[1].k = (const float*)k_r.data_ptr(); P[1].v = (const float*)v_r.data_ptr();
+    P[1].q_ptr = (const int64_t*)aptr.data_ptr(); P[1].k_ptr = (const int64_t*)rptr.data_ptr();
+    P[1].num_q = q_a.size(0); P[1].num_k = k_r.size(0);
+  }
+  static variable_list forward(AutogradContext* ctx, at::Tensor q_r_, at::Tensor k_a_, at::Tensor v_a_, at::Tensor q_a_, at::Tensor k_r_,
+                               at::Tensor v_r_, at::Tensor rptr_, at::Tensor aptr_, int64_t heads) {
+    const int64_t E = heads * 16;
+    at::Tensor t[6] = {rows_f32(q_r_, "q_r"), rows_f32(k_a_, "k_a"), rows_f32(v_a_, "v_a"), rows_f32(q_a_, "q_a"),
+                       rows_f32(k_r_, "k_r"), rows_f32(v_r_, "v_r")};
+    for (const at::Tensor& x : t)
+      if (x.dim() != 2 || x.size(1) != E) throw NotImplemented("cross_attention: the kernels are compiled for head_dim 16 (embed = 16 * heads)");
+    TORCH_CHECK(t[0].size(0) == t[4].size(0) && t[0].size(0) == t[5].size(0) && t[3].size(0) == t[1].size(0) && t[3].size(0) == t[2].size(0),
+                "row counts of the residue / atom tensors disagree");
+    at::Tensor rptr = rptr_.to(at::kLong).contiguous(), aptr = aptr_.to(at::kLong).contiguous();
+    TORCH_CHECK(rptr.is_cuda() && aptr.is_cuda() && rptr.dim() == 1 && rptr.sizes() == aptr.sizes() && rptr.numel() >= 1,
+                "rptr / aptr must both be [num_pairs + 1] on the GPU");
+    const int64_t N = t[0].size(0), Na = t[3].size(0), B = rptr.numel() - 1;
+    at::Tensor o_r = at::empty({N, E}, t[0].options()), o_a = at::empty({Na, E}, t[0].options());
+    at::Tensor lse_r = at::empty({N, heads}, t[0].options()), lse_a = at::empty({Na, heads}, t[0].options());
+    cgvp_attn_problem P[2];
+    fill(P, t[0], t[1], t[2], t[3], t[4], t[5], rptr, aptr);
+    P[0].out = (float*)ptr(o_r); P[0].lse = (float*)ptr(lse_r);
+    P[1].out = (float*)ptr(o_a); P[1].lse = (float*)ptr(lse_a);
+    check(cgvp_attn_fwd(P, 2, B, (int32_t)heads, 0.25f, current_stream(t[0])), "cgvp_attn_fwd");
+    ctx->save_for_backward({t[0], t[1], t[2], t[3], t[4], t[5], o_r, o_a, lse_r, lse_a, rptr, aptr});
+    ctx->saved_data["heads"] = heads;
+    ctx->mark_non_differentiable({lse_r, lse_a});
+    return {o_r, o_a, lse_r, lse_a};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list go) {
+    auto sv = ctx->get_saved_variables();
+    const int64_t heads = ctx->saved_data["heads"].toInt();
+    at::Tensor g_o_r = go[0].defined() ? rows_f32(go[0], "d o_r") : at::zeros_like(sv[6]);
+    at::Tensor g_o_a = go[1].defined() ? rows_f32(go[1], "d o_a") : at::zeros_like(sv[7]);
+    at::Tensor outs[6];
+    for (int i = 0; i < 6; ++i) outs[i] = at::empty_like(sv[i]);
+    at::Tensor d_r = at::empty_like(sv[8]), d_a = at::empty_like(sv[9]);
+    cgvp_attn_problem P[2];
+    fill(P, sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[10], sv[11]);
+    P[0].out = (float*)ptr(sv[6]); P[0].lse = (float*)ptr(sv[8]); P[0].g_out = (const float*)ptr(g_o_r); P[0].delta = (float*)ptr(d_r);
+    P[0].g_q = (float*)ptr(outs[0]); P[0].g_k = (float*)ptr(outs[1]); P[0].g_v = (float*)ptr(outs[2]);
+    P[1].out = (float*)ptr(sv[7]); P[1].lse = (float*)ptr(sv[9]); P[1].g_out = (const float*)ptr(g_o_a); P[1].delta = (float*)ptr(d_a);
+    P[1].g_q = (float*)ptr(outs[3]); P[1].g_k = (float*)ptr(outs[4]); P[1].g_v = (float*)ptr(outs[5]);
+    check(cgvp_attn_bwd(P, 2, sv[10].numel() - 1, (int32_t)heads, 0.25f, current_stream(sv[0])), "cgvp_attn_bwd");
+    // the two directions share no operand: a residue-side tensor gets its gradient from exactly one of them
+    return {outs[0], outs[1], outs[2], outs[3], outs[4], outs[5], at::Tensor(), at::Tensor(), at::Tensor()};
+  }
+};
+std::vector<at::Tensor> head_cross_attention(at::Tensor q_r, at::Tensor k_a, at::Tensor v_a, at::Tensor q_a, at::Tensor k_r, at::Tensor v_r,
+                                             at::Tensor rptr, at::Tensor aptr, int64_t heads) {
+  return CrossAttention::apply(q_r, k_a, v_a, q_a, k_r, v_r, rptr, aptr, heads);
+}
+
 at::Tensor head_act_dropout(at::Tensor t, at::Tensor pair, int64_t site, double p, double slope) {
   return ActDropout::apply(t, pair, site, p, slope);
 }
@@ -752,6 +814,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("head_dropout_add", &head_dropout_add, "x + dropout_p(a) with autograd (x may be None)");
   m.def("head_layer_norm", &head_layer_norm, "row-wise LayerNorm with autograd");
   m.def("head_linear", &head_linear, "F.linear with the split-row weight / bias gradient kernel");
+  m.def("head_cross_attention", &head_cross_attention, "varlen residue <-> atom cross attention (both directions) with autograd");
   // the version of include/caster_gvp.h this bridge was COMPILED against (struct layouts, argument lists); the library
   // loaded at run time reports its own through cgvp_abi_version(): _lib.bridge() requires all three to agree
   m.def("abi_version", []() { return (int)CGVP_ABI_VERSION; });

@@ -523,7 +523,12 @@ class CrossAttentionModule(nn.Module):
             k1, v1 = self._kv(p12, n2, E)
         lanes.join(q2, k1, v1)
         heads = self.embed1_to_2.num_heads
-        o1, o2, lse1, lse2 = torch.ops.caster_gvp.cross_attention(q1, k1, v1, q2, k2, v2, ptr1, ptr2, heads)
+        from gvp_hip import head_ops
+        br = head_ops._bridge()
+        if br is not None and hasattr(br, "head_cross_attention") and not torch.is_autocast_enabled("cuda"):
+            o1, o2, lse1, lse2 = br.head_cross_attention(q1, k1, v1, q2, k2, v2, ptr1, ptr2, heads)     # eager: C++ autograd function
+        else:
+            o1, o2, lse1, lse2 = torch.ops.caster_gvp.cross_attention(q1, k1, v1, q2, k2, v2, ptr1, ptr2, heads)
         from gvp_hip.head_ops import fast_linear
         lanes.fork(o2)
         a1 = fast_linear(o1, self.embed1_to_2.out_proj.weight, self.embed1_to_2.out_proj.bias)
