@@ -320,3 +320,44 @@ def test_fused_dropout_sites_vs_stock_ops_with_the_same_mask(rows, dim, p):
         assert torch.allclose(y, y2, atol=1e-6) and torch.allclose(gt, gt2, atol=1e-6)
     # p = 0: no generator needed, identity factors
     assert torch.equal(torch.ops.caster_gvp.dropout_add(a.detach(), x.detach(), pair, 1, 0.0), x.detach() + a.detach())
+
+
+@pytest.mark.gpu
+def test_bridge_head_ops_equal_the_custom_ops():
+    """Eager mode drives the head's row-wise ops and the attention core through C++ autograd functions of the bridge
+    (csrc/torch_bridge.cpp), torch.compile through the torch.library ops: same C entry points, so outputs and every
+    gradient must agree bitwise."""
+    from gvp_hip import _lib, attention_ops, head_ops  # noqa: F401
+    br = _lib.bridge()
+    if br is None or not hasattr(br, "head_cross_attention"):
+        pytest.skip("C++ bridge not built")
+    g = torch.Generator(device=DEV).manual_seed(3)
+    f = lambda *s: torch.randn(*s, device=DEV, generator=g)
+
+    def both(run_a, run_b, leaves):
+        outs = []
+        for run in (run_a, run_b):
+            ls = [t.clone().requires_grad_() for t in leaves]
+            y = run(*ls)
+            ys = y if isinstance(y, (tuple, list)) else (y,)
+            ys = [t for t in ys if t.requires_grad]
+            torch.autograd.backward(ys, [torch.ones_like(t) * 0.5 for t in ys])
+            outs.append(([t.detach() for t in ys], [t.grad for t in ls]))
+        for a, b in zip(outs[0][0] + outs[0][1], outs[1][0] + outs[1][1]):
+            assert torch.equal(a, b)
+
+    x, w, b = f(2048, 128), f(256, 128), f(256)
+    both(lambda x, w, b: br.head_linear(x, w, b), lambda x, w, b: head_ops._FastLinear.apply(x, w, b), [x, w, b])
+    gam, bet = f(128), f(128)
+    both(lambda x, w, b: br.head_layer_norm(x, w, b, 1e-5), lambda x, w, b: torch.ops.caster_gvp.layer_norm(x, w, b, 1e-5)[0],
+         [x, gam, bet])
+    state = head_ops._head_rng_state(torch.device(DEV))
+    pair = br.head_rng_next(state)
+    a = f(2048, 128)
+    both(lambda a, x: br.head_dropout_add(a, x, pair, 3, 0.2), lambda a, x: torch.ops.caster_gvp.dropout_add(a, x, pair, 3, 0.2),
+         [a, x])
+    both(lambda t: br.head_act_dropout(t, pair, 5, 0.2, 0.01), lambda t: torch.ops.caster_gvp.act_dropout(t, pair, 5, 0.2, 0.01),
+         [a])
+    (q_r, k_a, v_a, q_a, k_r, v_r), rptr, aptr = _ragged([40, 17, 300], [9, 33, 16], 7, DEV)
+    both(lambda *t: br.head_cross_attention(*t, rptr, aptr, H)[:2], lambda *t: torch.ops.caster_gvp.cross_attention(*t, rptr, aptr, H)[:2],
+         [q_r, k_a, v_a, q_a, k_r, v_r])
