@@ -97,6 +97,9 @@ def parse():
                     help="which encoder's launches are issued (and captured) first in a step (A/B)")
     ap.add_argument("--drug-priority", type=int, default=0,
                     help="diagnostic: priority of the drug encoder's side stream (-1 = high)")
+    ap.add_argument("--drug-atoms", type=int, default=0,
+                    help="diagnostic: every drug graph gets exactly this many atoms (0 = the Davis-like size distribution); "
+                         "with 1-2 atoms the drug chain is launches only: what it then adds to the step is queue / graph overhead")
     ap.add_argument("--gine-bwd-wgs", type=int, default=0,
                     help="diagnostic: workgroup cap of the GINE backward (0 = library default of 16)")
     ap.add_argument("--only", default=None, choices=["protein", "drug"],
@@ -252,6 +255,10 @@ def main():
     lengths = ds.real_lengths(wl["lengths"], wl["pairs"], seed=1000 + rank) if "lengths" in wl else None
     pb, mb = ds.pair_batch(wl["pairs"], seed=rank, length=wl.get("length", 300), thresh=wl["thresh"],
                            thresh_type=wl["thresh_type"], lengths=lengths)
+    if args.drug_atoms > 0:
+        import numpy as np
+        rng_d = np.random.default_rng(77 + rank)
+        mb = ds.collate([ds.drug_graph(rng_d, n_atoms=args.drug_atoms) for _ in range(wl["pairs"])])
     to = lambda d: {k: (tuple(t.to(dev) for t in v) if isinstance(v, tuple) else v.to(dev)) for k, v in d.items()}
     pdata_cpu, mdata_cpu = ds.to_torch(pb), ds.to_torch(mb)
     pdata, mdata = to(pdata_cpu), to(mdata_cpu)
