@@ -164,9 +164,7 @@ def _check_no_foreign_graph(params):
     What such a graph keeps alive are the leaves' AccumulateGrad nodes, which remember the stream they were created under
     (csrc/torch_bridge.cpp, stale_grad_accumulators); the engine synchronises gradient hand-offs with that stream.  The
     encoder-only captures of GraphedEncoderStep never showed it.  Refuse with a message instead of crashing."""
-    br = _lib.bridge()
-    if br is None:
-        return
+    br = _lib.bridge()                     # (GraphedTrainStep refuses to exist without it)
     n = int(br.stale_grad_accumulators(list(params)))
     if n:
         raise RuntimeError(
@@ -212,6 +210,11 @@ class GraphedTrainStep:
     static tensors: consume them (optimizer step) before the next `run` of the same bucket."""
 
     def __init__(self, model, loss_fn, scaler=None, autocast=None, quantum=bucket_size):
+        if _lib.bridge() is None:
+            # the capture-safety check below (_check_no_foreign_graph) lives in the C++ bridge: without it a forgotten eager
+            # `loss` / `pred` turns the next capture into a segmentation fault inside hipStreamEndCapture
+            raise RuntimeError("GraphedTrainStep needs the C++ eager bridge (lib/caster_gvp_torch.so, built by "
+                               "__graft_entry__.build(); CGVP_BRIDGE=0 / CGVP_LIB_PATH turn it off)")
         self.model, self.loss_fn, self.scaler, self.autocast, self.quantum = model, loss_fn, scaler, autocast, quantum
         self.params = [p for p in model.parameters() if p.numel() and p.requires_grad]
         self.device = self.params[0].device
